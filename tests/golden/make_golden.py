@@ -1,0 +1,564 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  Nothing of the reference's source is
+copied: the fixtures are inputs + the reference's outputs (and two of its own test *data* files,
+test.vcf / expected_genotype.vcf).  The GPU box never runs this script.
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+Fixture groups:
+  testdir/   G1  graph of the reference's test-dir (edges JSON + GFA with ref sequences elided)
+             G2  count-matched GAF for that graph: reference filter+genotyper reproduce the 40
+                 data rows of expected_genotype.vcf byte for byte
+  quirks/    G3  hand-made graph + GAF lines exercising the quirks of SURVEY Appendix D,
+                 with the reference's JSON (or the exception class it dies with)
+  lik/       G4  known answers of the reference's likelihood()
+  vcf/       G5  VCF-parsing cases through the reference's decision_vcf()
+  synth/     G6  medium synthetic case from tools/svjg_synth (inputs regenerated from the seed):
+                 sha256 of the reference JSON/VCF + the full count vector
+"""
+import hashlib
+import importlib.util
+import io
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import contextlib
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ref_filter = _load("ref_filter", f"{REF}/filter-alignments.py")
+ref_geno = _load("ref_geno", f"{REF}/predict-genotype.py")
+
+
+def run_ref_filter(gaf, gfa, prefix):
+    """-> (returncode, last stderr line)"""
+    p = subprocess.run([sys.executable, f"{REF}/filter-alignments.py", "-a", gaf, "-g", gfa, "-p", prefix],
+                       capture_output=True, text=True)
+    err = p.stderr.strip().splitlines()[-1] if p.stderr.strip() else ""
+    return p.returncode, err
+
+
+def run_ref_genotype(js, vcf, out, ms=3, err=None):
+    cmd = [sys.executable, f"{REF}/predict-genotype.py", "-d", js, "-v", vcf, "-o", out, "--minsupport", str(ms)]
+    if err is not None:
+        cmd += ["-e", str(err)]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    return p.returncode, p.stdout
+
+
+# ----------------------------------------------------------------------------------------------
+# G1 + G2
+# ----------------------------------------------------------------------------------------------
+
+def gaf_line(name, path_nodes, orients, node_len, ts=0, te_back=0, extra="tp:A:P\tcm:i:50\ts1:i:500\ts2:i:0\tdv:f:0.0100"):
+    tlen = sum(node_len[n] for n in path_nodes)
+    te = tlen - te_back
+    path = "".join(o + n for o, n in zip(orients, path_nodes))
+    qlen = te - ts
+    cols = [name, str(qlen), "0", str(qlen), "+", path, str(tlen), str(ts), str(te), str(qlen), str(qlen), "60"]
+    return "\t".join(cols) + ("\t" + extra if extra else "") + "\n"
+
+
+def make_testdir():
+    out = f"{HERE}/testdir"
+    os.makedirs(out, exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    subprocess.run([sys.executable, f"{REF}/construct-graph.py", "-v", f"{REF}/test-dir/test.vcf",
+                    "-r", f"{REF}/test-dir/reference_genome.fasta", "-o", f"{tmp}/test.gfa"], check=True)
+    shutil.copy(f"{tmp}/test_svs_edges.json", f"{out}/test_svs_edges.json")
+    shutil.copy(f"{REF}/test-dir/test.vcf", f"{out}/test.vcf")
+    shutil.copy(f"{REF}/test-dir/expected_genotype.vcf", f"{out}/expected_genotype.vcf")
+    # GFA with reference-node sequences elided (the filter only measures alt-node sequences)
+    node_len, order = {}, {}
+    with open(f"{tmp}/test.gfa") as fi, open(f"{out}/test.gfa", "w") as fo:
+        for ln in fi:
+            if ln.startswith("S"):
+                _, name, seq = ln.rstrip("\n").split("\t")
+                node_len[name] = len(seq)
+                if "." in name.split(":")[-1]:
+                    fo.write(ln)
+                else:
+                    fo.write(f"S\t{name}\t*\n")
+                    order.setdefault(name.split(":")[0], []).append(name)
+            elif ln.startswith("P"):
+                c = ln.rstrip("\n").split("\t")
+                fo.write("\t".join([c[0], c[1], c[2], "*"]) + "\n")
+            else:
+                fo.write(ln)
+    edges = json.load(open(f"{out}/test_svs_edges.json"))
+
+    # target raw counts implied by expected_genotype.vcf
+    target = {}
+    ins_seen = {}
+    for ln in open(f"{out}/expected_genotype.vcf"):
+        if ln.startswith("#"):
+            continue
+        c = ln.rstrip("\n").split("\t")
+        info = c[7]
+        svt = info.split("SVTYPE=")[1].split(";")[0]
+        ad = c[9].split(":")[2].split(",")
+        a0, a1 = float(ad[0]), float(ad[1])
+        if svt == "DEL":
+            key = f"{c[0]}:DEL-{c[1]}-{info.split('END=')[1].split(';')[0]}"
+            raw = (int(round(a0 * 2)), int(a1))
+        elif svt == "INS":
+            ins_seen[c[1]] = ins_seen.get(c[1], 0) + 1
+            key = f"{c[0]}:INS-{c[1]}-{ins_seen[c[1]]}"
+            raw = (int(a0), int(round(a1 * 2)))
+        elif svt == "INV":
+            key = f"{c[0]}:INV-{c[1]}-{info.split('END=')[1].split(';')[0]}"
+            raw = (int(a0), int(a1))
+        else:
+            alt = c[4]
+            br = "[" if "[" in alt else "]"
+            p = [x for x in alt.split(br) if x]
+            key = f"{c[0]}:BND-{c[1]}{br}{p[1]}{br}" if ":" in p[1] else f"{c[0]}:BND-{br}{p[0]}{br}{c[1]}"
+            raw = (int(a0), int(a1))
+        target[key] = raw
+
+    # candidate path templates: each edge, extended along the reference path until both flanks >= 100 bp
+    def ref_neighbour(node, direction):
+        chrom = node.split(":")[0]
+        if "." in node.split(":")[-1]:
+            return None
+        lst = order[chrom]
+        i = lst.index(node) + direction
+        return lst[i] if 0 <= i < len(lst) else None
+
+    templates = []
+    for key in edges:
+        ln_, ls, rn, rs = key.split("@")
+        nodes = [ln_, rn]
+        ori = [">" if ls == "+" else "<", ">" if rs == "+" else "<"]
+        for _ in range(6):  # extend left flank
+            if sum(node_len[n] for n in nodes[:1]) >= 100 and len(nodes) >= 2:
+                break
+            nb = ref_neighbour(nodes[0], -1 if ori[0] == ">" else +1)
+            if nb is None:
+                break
+            nodes.insert(0, nb)
+            ori.insert(0, ori[0])
+        for _ in range(6):  # extend right flank
+            if node_len[nodes[-1]] >= 100:
+                break
+            nb = ref_neighbour(nodes[-1], +1 if ori[-1] == ">" else -1)
+            if nb is None:
+                break
+            nodes.append(nb)
+            ori.append(ori[-1])
+        templates.append((nodes, ori))
+        # reverse-strand twin of the same walk
+        flip = {">": "<", "<": ">"}
+        templates.append((nodes[::-1], [flip[o] for o in ori[::-1]]))
+
+    # contribution vector of each template, measured with the reference filter itself
+    tdir = tempfile.mkdtemp()
+    with open(f"{tdir}/t.gaf", "w") as fh:
+        for i, (nodes, ori) in enumerate(templates):
+            fh.write(gaf_line(f"tmpl{i}", nodes, ori, node_len))
+    shutil.copy(f"{out}/test_svs_edges.json", f"{tdir}/t_svs_edges.json")
+    rc, err = run_ref_filter(f"{tdir}/t.gaf", f"{out}/test.gfa", f"{tdir}/t")
+    assert rc == 0, err
+    contrib = json.load(open(f"{tdir}/t_informative_aln.json"))
+    keys = sorted(set(contrib) | set(target))
+    rows = [(k, a) for k in keys for a in (0, 1)]
+    A = np.zeros((len(rows), len(templates)))
+    for ri, (k, a) in enumerate(rows):
+        for txt in contrib.get(k, [[], []])[a]:
+            A[ri, int(txt.split("\t")[0][4:])] += 1
+    b = np.array([target.get(k, (None, None))[a] if k in target else -1 for k, a in rows], dtype=float)
+
+    from scipy.optimize import milp, LinearConstraint, Bounds
+    constrained = b >= 0          # orphan BND-mate keys are unconstrained
+    res = milp(c=np.ones(len(templates)), integrality=np.ones(len(templates)),
+               bounds=Bounds(0, np.inf),
+               constraints=LinearConstraint(A[constrained], b[constrained], b[constrained]))
+    assert res.success, res.message
+    x = np.round(res.x).astype(int)
+
+    rng = np.random.default_rng(20260515)
+    lines = []
+    rid = 0
+    for ti, n in enumerate(x):
+        nodes, ori = templates[ti]
+        for _ in range(n):
+            # jitter Ts / Te inside the slack so the 100-bp rule is exercised but still passes
+            slack_l = node_len[nodes[0]] - 100 if len(nodes) == 2 else 0
+            slack_r = node_len[nodes[-1]] - 100 if len(nodes) == 2 else 0
+            ts = int(rng.integers(0, max(1, min(slack_l, 300) + 1)))
+            teb = int(rng.integers(0, max(1, min(slack_r, 300) + 1)))
+            lines.append(gaf_line(f"read{rid}", nodes, ori, node_len, ts=ts, te_back=teb))
+            rid += 1
+    # single-node alignments and one too-short overlap per template: must not change any count
+    for ti in range(0, len(templates), 7):
+        nodes, ori = templates[ti]
+        lines.append(gaf_line(f"read{rid}", nodes[:1], ori[:1], node_len)); rid += 1
+        if len(nodes) == 2 and node_len[nodes[0]] > 150:
+            lines.append(gaf_line(f"read{rid}", nodes, ori, node_len, ts=node_len[nodes[0]] - 99)); rid += 1
+    order_ix = rng.permutation(len(lines))
+    with open(f"{out}/test.gaf", "w") as fh:
+        for i in order_ix:
+            fh.write(lines[i])
+
+    work = tempfile.mkdtemp()
+    for f in ("test.gaf", "test.gfa", "test_svs_edges.json"):
+        shutil.copy(f"{out}/{f}", f"{work}/{f}")
+    rc, err = run_ref_filter(f"{work}/test.gaf", f"{work}/test.gfa", f"{work}/test")
+    assert rc == 0, err
+    rc, so = run_ref_genotype(f"{work}/test_informative_aln.json", f"{out}/test.vcf", f"{work}/test_genotype.vcf")
+    assert rc == 0
+    got = [l for l in open(f"{work}/test_genotype.vcf") if not l.startswith("#")]
+    exp = [l for l in open(f"{out}/expected_genotype.vcf") if not l.startswith("#")]
+    assert got == exp, "count-matched GAF does not reproduce expected_genotype.vcf"
+    shutil.copy(f"{work}/test_informative_aln.json", f"{out}/ref_informative_aln.json")
+    shutil.copy(f"{work}/test_genotype.vcf", f"{out}/ref_genotype.vcf")
+    with open(f"{out}/ref_stdout.txt", "w") as fh:
+        fh.write(so)
+    print(f"testdir: {len(lines)} alignments, {len(templates)} templates, 40/40 expected rows reproduced")
+
+
+# ----------------------------------------------------------------------------------------------
+# G3 quirks
+# ----------------------------------------------------------------------------------------------
+
+def make_quirks():
+    out = f"{HERE}/quirks"
+    os.makedirs(out, exist_ok=True)
+    # Hand-made graph (not from construct-graph.py) so that hazard names can coexist.
+    # chromosomes "1" and "11" (substring hazard Q6), alt nodes .1 / .10 at one position.
+    nodes = {
+        "1:1-1000": 1000, "1:1001-1500": 500, "1:1501-3000": 1500, "1:3001-3040": 40, "1:3041-5000": 1960,
+        "11:1-1000": 1000, "11:1001-2000": 1000, "11:2001-4000": 2000,
+        "1:1001.1": 250, "1:1001.10": 300, "1:3001.1": 120,
+        "chrA:1-700": 700, "chrA:701-900": 200, "chrA:901-2000": 1100,
+    }
+    E = {}
+
+    def add(l, ls, r, rs, sv, a):
+        E.setdefault("@".join((l, ls, r, rs)), []).append([sv, a])
+
+    # DEL 1000-1500 on chr 1
+    add("1:1-1000", "+", "1:1001-1500", "+", "1:DEL-1000-1500", 0)
+    add("1:1001-1500", "+", "1:1501-3000", "+", "1:DEL-1000-1500", 0)
+    add("1:1-1000", "+", "1:1501-3000", "+", "1:DEL-1000-1500", 1)
+    # two INS at the same position 1000 (ids .1 and .10 to build the '.1' in '.10' hazard) sharing the ref link
+    add("1:1-1000", "+", "1:1001-1500", "+", "1:INS-1000-1", 0)
+    add("1:1-1000", "+", "1:1001-1500", "+", "1:INS-1000-10", 0)
+    add("1:1-1000", "+", "1:1001.1", "+", "1:INS-1000-1", 1)
+    add("1:1001.1", "+", "1:1001-1500", "+", "1:INS-1000-1", 1)
+    add("1:1-1000", "+", "1:1001.10", "+", "1:INS-1000-10", 1)
+    add("1:1001.10", "+", "1:1001-1500", "+", "1:INS-1000-10", 1)
+    # short DEL 3000-3040 (40-bp inner node: flank sums needed)
+    add("1:1501-3000", "+", "1:3001-3040", "+", "1:DEL-3000-3040", 0)
+    add("1:3001-3040", "+", "1:3041-5000", "+", "1:DEL-3000-3040", 0)
+    add("1:1501-3000", "+", "1:3041-5000", "+", "1:DEL-3000-3040", 1)
+    # INS at 3000 (alt node 1:3001.1)
+    add("1:1501-3000", "+", "1:3001-3040", "+", "1:INS-3000-1", 0)
+    add("1:1501-3000", "+", "1:3001.1", "+", "1:INS-3000-1", 1)
+    add("1:3001.1", "+", "1:3001-3040", "+", "1:INS-3000-1", 1)
+    # chr 11: INV 1000-2000
+    add("11:1-1000", "+", "11:1001-2000", "+", "11:INV-1000-2000", 0)
+    add("11:1001-2000", "+", "11:2001-4000", "+", "11:INV-1000-2000", 0)
+    add("11:1-1000", "+", "11:1001-2000", "-", "11:INV-1000-2000", 1)
+    add("11:1001-2000", "-", "11:2001-4000", "+", "11:INV-1000-2000", 1)
+    # BND 1 -> 11 with orphan mate key and a key stored in "reverse" form only
+    add("1:3041-5000", "+", "11:2001-4000", "-", "1:BND-5000]11:4000]", 1)
+    add("11:2001-4000", "-", "11:1001-2000", "-", "11:BND-5000]11:4000]", 0)
+    # palindromic link: key equals its own reverse -> processed twice
+    add("chrA:701-900", "+", "chrA:701-900", "-", "chrA:INV-700-900", 1)
+    add("chrA:1-700", "+", "chrA:701-900", "+", "chrA:INV-700-900", 0)
+    add("chrA:701-900", "+", "chrA:901-2000", "+", "chrA:INV-700-900", 0)
+    # fwd and rev keys both present with different payloads
+    add("chrA:901-2000", "-", "chrA:701-900", "-", "chrA:DEL-700-900", 0)
+    # same (sv, allele) listed twice under one key (multiplicity)
+    add("chrA:1-700", "+", "chrA:901-2000", "+", "chrA:DEL-700-900", 1)
+    add("chrA:1-700", "+", "chrA:901-2000", "+", "chrA:DEL-700-900", 1)
+
+    with open(f"{out}/q_svs_edges.json", "w") as fh:
+        fh.write(json.dumps(E, sort_keys=True, indent=4))
+    with open(f"{out}/q.gfa", "w") as fh:
+        for n, l in nodes.items():
+            if "." in n.split(":")[-1]:
+                fh.write(f"S\t{n}\t{'A' * l}\n")
+            else:
+                fh.write(f"S\t{n}\t*\n")
+
+    L = nodes
+    tags = "tp:A:P\tcm:i:9\ts1:i:90\ts2:i:0\tdv:f:0.0200"
+
+    def g(name, nodes_, ori, **kw):
+        return gaf_line(name, nodes_, list(ori), L, extra=kw.pop("extra", tags), **kw)
+
+    cases = {}
+    cases["plain_ref_del"] = [g("r0", ["1:1-1000", "1:1001-1500", "1:1501-3000"], ">>>")]
+    cases["alt_del"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>")]
+    cases["reverse_strand"] = [g("r0", ["1:1501-3000", "1:1001-1500", "1:1-1000"], "<<<"),
+                               g("r1", ["1:1501-3000", "1:1-1000"], "<<")]
+    cases["shared_ref_link_ins_pair"] = [g("r0", ["1:1-1000", "1:1001-1500"], ">>")]
+    cases["ins_alt_1"] = [g("r0", ["1:1-1000", "1:1001.1", "1:1001-1500"], ">>>")]
+    cases["ins_alt_10_then_1_hazard"] = [
+        # '1:1001.1' is a substring of '1:1001.10' placed earlier in the path (Q6)
+        g("r0", ["1:1001.10", "1:1001-1500", "1:1-1000", "1:1001.1", "1:1001-1500"], "<><>>"),
+        g("r1", ["1:1-1000", "1:1001.10", "1:1001-1500"], ">>>"),
+    ]
+    cases["chrom_1_in_11_hazard"] = [
+        # '1:1-1000' is a substring of '11:1-1000' placed earlier (Q6): strand read from the wrong char
+        g("r0", ["11:1-1000", "1:1-1000", "1:1001-1500"], "<>>"),
+        g("r1", ["11:1001-2000", "11:1-1000", "1:1-1000", "1:1501-3000"], "<<>>"),
+    ]
+    cases["repeat_flipped"] = [
+        # a node visited twice with opposite orientations: first-occurrence strand/index (Q4/Q5)
+        g("r0", ["1:1-1000", "1:1001-1500", "1:1-1000", "1:1501-3000"], "><<>"),
+        g("r1", ["1:1001-1500", "1:1-1000", "1:1001-1500", "1:1501-3000"], "<<>>"),
+        g("r2", ["1:1-1000", "1:1001-1500", "1:1501-3000", "1:1-1000", "1:1001-1500"], ">>>>>"),
+    ]
+    cases["short_inner_node"] = [
+        g("r0", ["1:1501-3000", "1:3001-3040"], ">>"),                     # right flank 40 (+1) < 100
+        g("r1", ["1:1501-3000", "1:3001-3040", "1:3041-5000"], ">>>"),
+        g("r2", ["1:1501-3000", "1:3001.1", "1:3001-3040", "1:3041-5000"], ">>>>"),
+    ]
+    b = []
+    for d in (98, 99, 100, 101):                                            # left flank boundary
+        b.append(g(f"l{d}", ["1:1-1000", "1:1001-1500"], ">>", ts=1000 - d))
+    for d in (98, 99, 100, 101):                                            # right flank: len - (Tlen-Te-1)
+        b.append(g(f"r{d}", ["1:1-1000", "1:1001-1500"], ">>", te_back=500 + 1 - d))
+    cases["dover_boundaries"] = b
+    cases["single_node_and_unoriented"] = [
+        g("r0", ["1:1-1000"], ">"),
+        "r1\t500\t0\t500\t+\t1:1-1000\t1000\t0\t500\t500\t500\t60\t" + tags + "\n",
+        g("r2", ["1:1-1000", "1:1001-1500"], ">>"),
+    ]
+    cases["inv_paths"] = [
+        g("r0", ["11:1-1000", "11:1001-2000", "11:2001-4000"], "><>"),
+        g("r1", ["11:2001-4000", "11:1001-2000", "11:1-1000"], "<><"),
+        g("r2", ["11:1-1000", "11:1001-2000", "11:2001-4000"], ">>>"),
+    ]
+    cases["bnd_and_orphan"] = [
+        g("r0", ["1:3041-5000", "11:2001-4000", "11:1001-2000"], "><<"),
+        g("r1", ["11:1001-2000", "11:2001-4000", "1:3041-5000"], ">><"),
+    ]
+    cases["palindromic_link"] = [
+        g("r0", ["chrA:1-700", "chrA:701-900", "chrA:701-900", "chrA:901-2000"], ">><>"),
+        g("r1", ["chrA:701-900", "chrA:701-900"], "><"),
+    ]
+    cases["fwd_and_rev_keys"] = [
+        g("r0", ["chrA:701-900", "chrA:901-2000"], ">>"),
+        g("r1", ["chrA:901-2000", "chrA:701-900"], "<<"),
+        g("r2", ["chrA:1-700", "chrA:901-2000"], ">>"),
+    ]
+    cases["cg_tag"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>", extra=tags + "\tcg:Z:100M5D200M"),
+                       g("r1", ["1:1-1000", "1:1501-3000"], ">>", extra="cg:Z:300M\t" + tags)]
+    cases["id_tag"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>", extra="NM:i:3\tid:f:0.987\t" + tags)]
+    cases["json_escapes"] = [g('r"q\\x', ["1:1-1000", "1:1501-3000"], ">>"),
+                             g("ré中", ["1:1-1000", "1:1501-3000"], ">>"),
+                             g("r\x01\x7f", ["1:1-1000", "1:1501-3000"], ">>")]
+    cases["no_trailing_newline"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>"),
+                                    g("r1", ["1:1-1000", "1:1501-3000"], ">>").rstrip("\n")]
+    cases["crlf_and_trailing_ws"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>").rstrip("\n") + "\r\n",
+                                     g("r1", ["1:1-1000", "1:1501-3000"], ">>").rstrip("\n") + " \t\n"]
+    cases["unknown_nodes"] = [
+        g("r0", ["1:1-1000", "1:1001-1500"], ">>").replace("1:1001-1500", "1:1001-1400"),   # name not in graph
+        g("r1", ["1:1-1000", "1:1001-1500"], ">>").replace(">1:1-1000", ">9:1-1000"),
+        g("r2", ["1:1-1000", "1:1001-1500"], ">>").replace("1:1001-1500", "1:01001-1500"),  # non-canonical digits
+    ]
+    cases["tlen_mismatch"] = [
+        # Tlen column disagrees with the node-name sum: the reference trusts the names for the sums
+        g("r0", ["1:1-1000", "1:1001-1500"], ">>").replace("\t1500\t0\t1500\t", "\t1400\t0\t1400\t"),
+        g("r1", ["1:1-1000", "1:1001-1500"], ">>").replace("\t1500\t0\t1500\t", "\t1700\t0\t1500\t"),
+    ]
+    cases["empty_file"] = []
+    cases["many_nodes"] = [g("r0", ["1:1-1000", "1:1001-1500", "1:1501-3000", "1:3001-3040", "1:3041-5000",
+                                    "11:2001-4000", "11:1001-2000", "11:1-1000"], ">>>>><<<")]
+    # inputs the reference dies on (exit code 1): recorded with the exception class
+    cases["err_few_columns"] = ["r0\t10\t0\t10\t+\t>1:1-1000>1:1001-1500\t1500\t0\n"]
+    cases["err_nonint"] = [g("r0", ["1:1-1000", "1:1001-1500"], ">>").replace("\t60\t", "\tx\t")]
+    cases["err_empty_line"] = [g("r0", ["1:1-1000", "1:1001-1500"], ">>"), "\n"]
+    cases["err_zero_alen"] = ["r0\t500\t0\t500\t+\t>1:1-1000>1:1001-1500\t1500\t0\t1500\t0\t0\t60\t" + tags + "\n"]
+    cases["ok_zero_alen_with_id"] = ["r0\t500\t0\t500\t+\t>1:1-1000>1:1001-1500\t1500\t0\t1500\t0\t0\t60\tid:f:0.5\n"]
+    cases["err_unknown_alt_node"] = [g("r0", ["1:1-1000", "1:1001-1500"], ">>").replace(">1:1-1000", ">1:7.1>1:1-1000")
+                                     .replace("\t1500\t0\t1500\t", "\t1600\t0\t1600\t")]
+    cases["ok_unknown_alt_node_no_hit"] = ["r0\t500\t0\t500\t+\t>1:7.1>1:1-1000\t1100\t0\t1100\t500\t500\t60\t" + tags + "\n"]
+    cases["err_unoriented_two"] = ["r0\t500\t0\t500\t+\t1:1-1000+,1:1001-1500+\t1500\t0\t1500\t500\t500\t60\t" + tags + "\n"]
+    cases["err_bad_ref_coords"] = ["r0\t500\t0\t500\t+\t>1:1-1000>1:1001-1500>1:abc\t1500\t0\t1500\t500\t500\t60\t" + tags + "\n"]
+
+    manifest = {}
+    tdir = tempfile.mkdtemp()
+    shutil.copy(f"{out}/q_svs_edges.json", f"{tdir}/q_svs_edges.json")
+    for name, lines in cases.items():
+        gaf = f"{out}/{name}.gaf"
+        with open(gaf, "w", encoding="utf-8") as fh:
+            fh.write("".join(lines))
+        js = f"{tdir}/q_informative_aln.json"
+        if os.path.exists(js):
+            os.remove(js)
+        rc, err = run_ref_filter(gaf, f"{out}/q.gfa", f"{tdir}/q")
+        if rc == 0:
+            shutil.copy(js, f"{out}/{name}.ref.json")
+            manifest[name] = {"rc": 0, "n_lines": len(lines)}
+        else:
+            assert rc == 1
+            manifest[name] = {"rc": 1, "error": err.split(":")[0], "n_lines": len(lines)}
+    with open(f"{out}/manifest.json", "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+    print("quirks:", {k: (v["rc"], v.get("error", "")) for k, v in manifest.items() if v["rc"]},
+          f"{len(manifest)} cases")
+
+
+# ----------------------------------------------------------------------------------------------
+# G4 likelihood known answers
+# ----------------------------------------------------------------------------------------------
+
+def make_lik():
+    out = f"{HERE}/lik"
+    os.makedirs(out, exist_ok=True)
+    types = ["DEL", "INS", "INV", "BND"]
+    rows = []
+    rng = np.random.default_rng(4)
+    cases = [(t, a, b, ms, 5e-5) for t in range(4) for a in range(61) for b in range(61) for ms in (1, 3)]
+    for _ in range(3000):
+        cases.append((int(rng.integers(4)), int(rng.integers(0, 5001)), int(rng.integers(0, 5001)), 3, 5e-5))
+    for _ in range(1500):
+        cases.append((int(rng.integers(4)), int(rng.integers(0, 300)), int(rng.integers(0, 300)),
+                      int(rng.integers(0, 8)), [1e-3, 1e-2, 5e-5][int(rng.integers(3))]))
+    for _ in range(300):
+        cases.append((int(rng.integers(4)), int(rng.integers(0, 60001)), int(rng.integers(0, 60001)), 3, 5e-5))
+    gtc = {"0/0": 0, "0/1": 1, "1/1": 2, "./.": 3}
+    for t, a, b, ms, e in cases:
+        cnt = [a, b]
+        gt, pl = ref_geno.likelihood(cnt, types[t], ms, e)
+        dp = str(round(sum(cnt), 3))
+        rows.append((t, a, b, ms, e, gtc[gt], int(pl[0]), int(pl[1]), int(pl[2]), f"{dp}:{cnt[0]},{cnt[1]}"))
+    arr = np.array([r[:4] + r[5:9] for r in rows], dtype=np.int64)
+    errs = np.array([r[4] for r in rows], dtype=np.float64)
+    txt = np.array([r[9] for r in rows])
+    np.savez_compressed(f"{out}/lik_kat.npz", cases=arr, err=errs, dp_ad=txt)
+    print(f"lik: {len(rows)} known answers")
+
+
+# ----------------------------------------------------------------------------------------------
+# G5 VCF parsing
+# ----------------------------------------------------------------------------------------------
+
+def make_vcf():
+    out = f"{HERE}/vcf"
+    os.makedirs(out, exist_ok=True)
+    hdr = ["##fileformat=VCFv4.2\n", "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"old\">\n",
+           "##INFO=<ID=SVTYPE,Number=1,Type=String,Description=\"t\">\n",
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2\n"]
+    seq60 = "ACGT" * 15
+    rows = [
+        "1\t1000\ta\tN\t<DEL>\t.\t.\tSVTYPE=DEL;END=1500;SVLEN=-500\tGT\t0/1\t1/1\n",       # SVTYPE first
+        "1\t2000\tb\tN\t<DEL>\t.\t.\tEND=2600;SVTYPE=DEL\n",                                 # SVTYPE last, 8 cols
+        "1\t3000\tc\tN\t<DEL>\t.\t.\tSVLEN=-40;SVTYPE=DEL;END=3040\tGT\t0/1\n",             # len < 50 -> ./.
+        "1\t4000\td\tN\t<DEL>\t.\t.\tX=1;END=4100;SVTYPE=DEL;Y=2\tGT\t0/1\n",               # both in the middle
+        f"1\t5000\te\tN\t{seq60}\t.\t.\tSVTYPE=INS;END=5001\tGT\t0/1\n",
+        f"2\t5000\tf\tN\t{seq60}A\t.\t.\tSVTYPE=INS\n",                                      # same POS other chrom (Q8)
+        f"1\t5000\tg\tN\t{seq60}C\t.\t.\tSVTYPE=INS;END=5001\n",                            # third INS at POS 5000
+        "1\t6000\th\tN\t<INS>\t.\t.\tSVTYPE=INS;SEQ=" + seq60 + "\n",                        # symbolic: len 5 (Q12)
+        "1\t7000\ti\tN\t<INV>\t.\t.\tSVTYPE=INV;END=7800\tGT\t1/1\n",
+        "1\t8000\tj\tN\tN[2:9000[\t.\t.\tSVTYPE=BND\n",
+        "1\t8100\tk\tN\tN]2:9100]\t.\t.\tSVTYPE=BND\n",
+        "1\t8200\tl\tN\t[2:9200[N\t.\t.\tSVTYPE=BND\n",
+        "1\t8300\tm\tN\t]2:9300]N\t.\t.\tSVTYPE=BND\n",
+        "1\t8400\tn\tN\t<BND>\t.\t.\tSVTYPE=BND\n",                                          # wrong_format
+        "1\t9000\to\tN\t<DUP>\t.\t.\tSVTYPE=DUP;END=9900\n",                                 # unsupported
+        "1\t9500\tp\tN\t<DEL>\t.\t.\tEND=9900\n",                                            # no SVTYPE
+        "1\t9700\tq\tN\t<DEL>\t.\t.\tSVTYPE=DEL;END=9990\tGT\t0/1\n",                        # no informative aln
+    ]
+    D = {
+        "1:DEL-1000-1500": [["x\n"] * 9, ["y\n"] * 4],
+        "1:DEL-2000-2600": [[], ["y\n"] * 7],
+        "1:DEL-3000-3040": [["x\n"] * 9, ["y\n"] * 4],
+        "1:DEL-4000-4100": [["x\n"] * 5, []],
+        "1:INS-5000-1": [["x\n"] * 6, ["y\n"] * 6],
+        "2:INS-5000-2": [["x\n"] * 1, ["y\n"] * 1],
+        "1:INS-5000-3": [[], ["y\n"] * 3],
+        "1:INS-6000-1": [["x\n"] * 6, ["y\n"] * 6],
+        "1:INV-7000-7800": [["x\n"] * 3, ["y\n"] * 3],
+        "1:BND-8000[2:9000[": [["x\n"] * 2, ["y\n"] * 12],
+        "1:BND-8100]2:9100]": [["x\n"] * 12, ["y\n"] * 2],
+        "1:BND-[2:9200[8200": [["x\n"] * 10, ["y\n"] * 10],
+        "1:BND-]2:9300]8300": [["x\n"] * 1, ["y\n"] * 1],
+        "2:BND-9000[1:8000[": [["x\n"] * 5, []],          # orphan key, matches no row
+        "wrong_format": [["x\n"] * 5, ["y\n"] * 5],
+        "unsupported_type": [["x\n"] * 5, ["y\n"] * 5],
+    }
+    with open(f"{out}/cases.vcf", "w") as fh:
+        fh.write("".join(hdr + rows))
+    with open(f"{out}/cases_informative_aln.json", "w") as fh:
+        fh.write(json.dumps(D, sort_keys=True, indent=4))
+    for ms, e, tag in ((3, None, "ms3"), (1, None, "ms1"), (3, 0.001, "ms3_e1e-3"), (0, None, "ms0")):
+        rc, so = run_ref_genotype(f"{out}/cases_informative_aln.json", f"{out}/cases.vcf", f"{out}/ref_{tag}.vcf", ms, e)
+        assert rc == 0
+        with open(f"{out}/ref_{tag}.stdout", "w") as fh:
+            fh.write(so)
+    # crash case: unsupported type without END -> IndexError in the reference
+    with open(f"{out}/err_no_end.vcf", "w") as fh:
+        fh.write("".join(hdr) + "1\t9000\to\tN\t<DUP>\t.\t.\tSVTYPE=DUP\n")
+    rc, so = run_ref_genotype(f"{out}/cases_informative_aln.json", f"{out}/err_no_end.vcf", f"{out}/_tmp.vcf")
+    assert rc == 1
+    os.remove(f"{out}/_tmp.vcf")
+    print("vcf: ok")
+
+
+# ----------------------------------------------------------------------------------------------
+# G6 medium synthetic (needs tools/svjg_synth built)
+# ----------------------------------------------------------------------------------------------
+
+def make_synth():
+    out = f"{HERE}/synth"
+    os.makedirs(out, exist_ok=True)
+    sys.path.insert(0, f"{ROOT}/tools")
+    import synth
+    import time
+    res = {}
+    for tag, kw in (("g6_mixed", dict(n_aln=50000, n_sv=2000, n_chrom=4, mix="mixed", seed=20260515 + 6)),
+                    ("g6_del", dict(n_aln=20000, n_sv=500, n_chrom=1, mix="del", seed=20260515 + 1))):
+        tmp = tempfile.mkdtemp()
+        synth.generate(prefix=f"{tmp}/s", **kw)
+        t0 = time.time()
+        rc, err = run_ref_filter(f"{tmp}/s.gaf", f"{tmp}/s.gfa", f"{tmp}/s")
+        t1 = time.time()
+        assert rc == 0, err
+        rc, so = run_ref_genotype(f"{tmp}/s_informative_aln.json", f"{tmp}/s.vcf", f"{tmp}/s_genotype.vcf")
+        t2 = time.time()
+        assert rc == 0
+        D = json.load(open(f"{tmp}/s_informative_aln.json"))
+        res[tag] = {
+            "args": kw,
+            "sha256_inputs": {f: hashlib.sha256(open(f"{tmp}/s{f}", "rb").read()).hexdigest()
+                              for f in (".gaf", ".gfa", "_svs_edges.json", ".vcf")},
+            "sha256_json": hashlib.sha256(open(f"{tmp}/s_informative_aln.json", "rb").read()).hexdigest(),
+            "sha256_vcf": hashlib.sha256(open(f"{tmp}/s_genotype.vcf", "rb").read()).hexdigest(),
+            "stdout": so,
+            "ref_seconds": {"filter": round(t1 - t0, 2), "genotype": round(t2 - t1, 2)},
+            "counts": {k: [len(v[0]), len(v[1])] for k, v in sorted(D.items())},
+        }
+        shutil.copy(f"{tmp}/s_genotype.vcf", f"{out}/{tag}.ref_genotype.vcf")
+        shutil.rmtree(tmp)
+    with open(f"{out}/g6.json", "w") as fh:
+        json.dump(res, fh, indent=0, sort_keys=True)
+    print("synth:", {k: v["ref_seconds"] for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["testdir", "quirks", "lik", "vcf", "synth"]
+    for w in which:
+        globals()["make_" + w]()
