@@ -1,0 +1,314 @@
+/* CPU oracle (plain C) for the alignment-classification half of the hot path.
+ * TEST INFRASTRUCTURE ONLY — see oracle/oracle_py.py for the rules; the product never links this.
+ *
+ * Clean-room restatement of /root/reference/filter-alignments.py:119-166 (per-line loop) with the
+ * helper semantics of :181-225 (link keys, strands, reverse link), :258-273 (breakpoint overlap),
+ * :328-349 (node lengths) and :351-373 (path -> node names).  It works on strings exactly like the
+ * reference does (string-keyed link table, substring search for strands, first-occurrence indices);
+ * it does not share a line of code or a data structure with the HIP path.
+ *
+ * Pinned against the reference's own outputs: tests/test_oracle_golden.py (golden/quirks, golden/testdir,
+ * golden/synth).
+ *
+ * build: gcc -O2 -shared -fPIC -o oracle/_build/liboracle.so oracle/svjg_oracle.c
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { ORC_OK = 0, ORC_VALUE_ERROR = 1, ORC_INDEX_ERROR = 2, ORC_KEY_ERROR = 3, ORC_ZERO_DIVISION = 4, ORC_HIT_OVERFLOW = 9 };
+
+typedef struct { uint32_t sv, allele; } entry_t;
+typedef struct { char *key; uint32_t klen; entry_t *ent; uint32_t n, cap; } edge_t;
+typedef struct { char *key; uint32_t klen; int64_t len; } altnode_t;
+typedef struct { uint64_t line_index, line_start; uint32_t sv, allele; } orc_hit_t;
+
+typedef struct {
+    edge_t *edges; uint64_t ecap, ecount;
+    altnode_t *alts; uint64_t acap, acount;
+} oracle_t;
+
+static uint64_t fnv(const char *s, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+void *orc_new(void) {
+    oracle_t *o = (oracle_t *)calloc(1, sizeof(oracle_t));
+    o->ecap = 1024; o->edges = (edge_t *)calloc(o->ecap, sizeof(edge_t));
+    o->acap = 1024; o->alts = (altnode_t *)calloc(o->acap, sizeof(altnode_t));
+    return o;
+}
+
+void orc_free(void *p) {
+    oracle_t *o = (oracle_t *)p;
+    for (uint64_t i = 0; i < o->ecap; ++i) { free(o->edges[i].key); free(o->edges[i].ent); }
+    for (uint64_t i = 0; i < o->acap; ++i) free(o->alts[i].key);
+    free(o->edges); free(o->alts); free(o);
+}
+
+static edge_t *edge_slot(oracle_t *o, const char *k, size_t n) {
+    uint64_t m = o->ecap - 1, i = fnv(k, n) & m;
+    while (o->edges[i].key && !(o->edges[i].klen == n && memcmp(o->edges[i].key, k, n) == 0)) i = (i + 1) & m;
+    return &o->edges[i];
+}
+
+static void edges_grow(oracle_t *o) {
+    edge_t *old = o->edges; uint64_t oc = o->ecap;
+    o->ecap *= 2; o->edges = (edge_t *)calloc(o->ecap, sizeof(edge_t));
+    for (uint64_t i = 0; i < oc; ++i) if (old[i].key) *edge_slot(o, old[i].key, old[i].klen) = old[i];
+    free(old);
+}
+
+/* d_link_sv[key].append((sv, allele)) in JSON order (filter-alignments.py:95-98) */
+void orc_add_edge_entry(void *p, const char *key, uint32_t sv, uint32_t allele) {
+    oracle_t *o = (oracle_t *)p;
+    size_t n = strlen(key);
+    if ((o->ecount + 1) * 2 > o->ecap) edges_grow(o);
+    edge_t *e = edge_slot(o, key, n);
+    if (!e->key) { e->key = (char *)malloc(n + 1); memcpy(e->key, key, n + 1); e->klen = (uint32_t)n; o->ecount++; }
+    if (e->n == e->cap) { e->cap = e->cap ? e->cap * 2 : 2; e->ent = (entry_t *)realloc(e->ent, e->cap * sizeof(entry_t)); }
+    e->ent[e->n].sv = sv; e->ent[e->n].allele = allele; e->n++;
+}
+
+/* a key that is present with an empty list still counts as "present" but contributes nothing */
+void orc_add_edge_key(void *p, const char *key) {
+    oracle_t *o = (oracle_t *)p;
+    size_t n = strlen(key);
+    if ((o->ecount + 1) * 2 > o->ecap) edges_grow(o);
+    edge_t *e = edge_slot(o, key, n);
+    if (!e->key) { e->key = (char *)malloc(n + 1); memcpy(e->key, key, n + 1); e->klen = (uint32_t)n; o->ecount++; }
+}
+
+static altnode_t *alt_slot(oracle_t *o, const char *k, size_t n) {
+    uint64_t m = o->acap - 1, i = fnv(k, n) & m;
+    while (o->alts[i].key && !(o->alts[i].klen == n && memcmp(o->alts[i].key, k, n) == 0)) i = (i + 1) & m;
+    return &o->alts[i];
+}
+
+/* alt_node_len[name] = len (filter-alignments.py:103-113); a later S-line overwrites */
+void orc_add_alt_node(void *p, const char *name, int64_t len) {
+    oracle_t *o = (oracle_t *)p;
+    size_t n = strlen(name);
+    if ((o->acount + 1) * 2 > o->acap) {
+        altnode_t *old = o->alts; uint64_t oc = o->acap;
+        o->acap *= 2; o->alts = (altnode_t *)calloc(o->acap, sizeof(altnode_t));
+        for (uint64_t i = 0; i < oc; ++i) if (old[i].key) *alt_slot(o, old[i].key, old[i].klen) = old[i];
+        free(old);
+    }
+    altnode_t *a = alt_slot(o, name, n);
+    if (!a->key) { a->key = (char *)malloc(n + 1); memcpy(a->key, name, n + 1); a->klen = (uint32_t)n; o->acount++; }
+    a->len = len;
+}
+
+/* ---- Python-flavoured scalar parsing -------------------------------------------------------- */
+
+static int py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+
+#define BIG ((int64_t)1 << 61)
+
+/* int(str): optional blanks, sign, digits with single underscores; saturates far outside any length */
+static int py_int(const char *s, size_t n, int64_t *out) {
+    size_t i = 0;
+    while (i < n && py_space((unsigned char)s[i])) ++i;
+    while (n > i && py_space((unsigned char)s[n - 1])) --n;
+    int neg = 0;
+    if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
+    if (i >= n || s[i] < '0' || s[i] > '9') return 0;
+    int64_t v = 0; int prev_us = 0;
+    for (; i < n; ++i) {
+        if (s[i] == '_') { if (prev_us) return 0; prev_us = 1; continue; }
+        if (s[i] < '0' || s[i] > '9') return 0;
+        prev_us = 0;
+        if (v < BIG) v = v * 10 + (s[i] - '0');
+    }
+    if (prev_us) return 0;
+    if (v > BIG) v = BIG;
+    *out = neg ? -v : v;
+    return 1;
+}
+
+static int ieq(const char *s, size_t n, const char *w) {
+    size_t m = strlen(w);
+    if (n != m) return 0;
+    for (size_t i = 0; i < n; ++i) { char c = s[i]; if (c >= 'A' && c <= 'Z') c = (char)(c + 32); if (c != w[i]) return 0; }
+    return 1;
+}
+
+static size_t digits_us(const char *s, size_t i, size_t n, int *ok) {
+    size_t st = i; int prev_us = 1;                                   /* must start with a digit */
+    while (i < n) {
+        if (s[i] >= '0' && s[i] <= '9') { prev_us = 0; ++i; }
+        else if (s[i] == '_' && !prev_us) { prev_us = 1; ++i; }
+        else break;
+    }
+    if (i > st && prev_us) *ok = 0;                                   /* trailing underscore */
+    return i;
+}
+
+/* does float(str) succeed? */
+static int py_float_ok(const char *s, size_t n) {
+    size_t i = 0;
+    while (i < n && py_space((unsigned char)s[i])) ++i;
+    while (n > i && py_space((unsigned char)s[n - 1])) --n;
+    if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+    if (ieq(s + i, n - i, "inf") || ieq(s + i, n - i, "infinity") || ieq(s + i, n - i, "nan")) return 1;
+    int ok = 1;
+    size_t a = digits_us(s, i, n, &ok); int nd = (int)(a - i); i = a;
+    if (i < n && s[i] == '.') { ++i; a = digits_us(s, i, n, &ok); nd += (int)(a - i); i = a; }
+    if (!ok || nd == 0) return 0;
+    if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+        ++i;
+        if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+        a = digits_us(s, i, n, &ok);
+        if (a == i || !ok) return 0;
+        i = a;
+    }
+    return i == n;
+}
+
+static const char *find(const char *h, size_t hn, const char *nd, size_t nn) {
+    if (nn == 0) return h;
+    if (hn < nn) return NULL;
+    for (size_t i = 0; i + nn <= hn; ++i) if (h[i] == nd[0] && memcmp(h + i, nd, nn) == 0) return h + i;
+    return NULL;
+}
+
+static const char *rfind_char(const char *s, size_t n, char c) {
+    for (size_t i = n; i > 0; --i) if (s[i - 1] == c) return s + i - 1;
+    return NULL;
+}
+
+/* get_node_len (filter-alignments.py:343-349) */
+static int node_len(oracle_t *o, const char *nm, size_t n, int64_t *out) {
+    const char *colon = rfind_char(nm, n, ':');
+    const char *co = colon ? colon + 1 : nm; size_t cn = (size_t)(nm + n - co);
+    if (memchr(co, '.', cn)) {
+        altnode_t *a = alt_slot(o, nm, n);
+        if (!a->key) return ORC_KEY_ERROR;
+        *out = a->len; return ORC_OK;
+    }
+    const char *d1 = (const char *)memchr(co, '-', cn);
+    if (!d1) return ORC_INDEX_ERROR;                                   /* coords.split("-")[1] */
+    const char *e0 = d1 + 1; size_t rest = (size_t)(co + cn - e0);
+    const char *d2 = (const char *)memchr(e0, '-', rest);
+    size_t en = d2 ? (size_t)(d2 - e0) : rest;
+    int64_t s, e;
+    if (!py_int(e0, en, &e)) return ORC_VALUE_ERROR;
+    if (!py_int(co, (size_t)(d1 - co), &s)) return ORC_VALUE_ERROR;
+    *out = e - s + 1; return ORC_OK;
+}
+
+#define MAXN 4096
+
+typedef struct { const char *p; uint32_t n; char strand; } nm_t;
+
+static int same(const nm_t *a, const nm_t *b) { return a->n == b->n && memcmp(a->p, b->p, a->n) == 0; }
+
+/* one line, already stripped of its terminator; `ln`/`n` is the text before rstrip() */
+static int do_line(oracle_t *o, const char *ln, size_t n, uint64_t li, uint64_t lstart,
+                   uint64_t *counts, uint64_t n_sv, orc_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits)
+{
+    while (n > 0 && py_space((unsigned char)ln[n - 1])) --n;          /* line.rstrip() */
+    const char *f[12]; size_t fl[12]; int nf = 0;
+    { size_t st = 0;
+      for (size_t i = 0; i <= n && nf < 12; ++i)
+          if (i == n || ln[i] == '\t') { f[nf] = ln + st; fl[nf] = i - st; ++nf; st = i + 1; } }
+    if (nf < 12) return ORC_VALUE_ERROR;                              /* tuple unpacking of the slices */
+    int64_t v[12];
+    static const int intcols[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
+    for (int j = 0; j < 9; ++j) if (!py_int(f[intcols[j]], fl[intcols[j]], &v[intcols[j]])) return ORC_VALUE_ERROR;
+    { const char *last = NULL, *h = ln; size_t hn = n;
+      for (;;) { const char *q = find(h, hn, "id:f:", 5); if (!q) break; last = q; hn -= (size_t)(q + 1 - h); h = q + 1; }
+      if (last) {
+          const char *a = last + 5; size_t an = (size_t)(ln + n - a);
+          const char *t = (const char *)memchr(a, '\t', an);
+          if (!py_float_ok(a, t ? (size_t)(t - a) : an)) return ORC_VALUE_ERROR;
+      } else if (v[10] == 0) return ORC_ZERO_DIVISION; }
+    const char *path = f[5]; size_t pn = fl[5];
+    int64_t Tlen = v[6], Ts = v[7], Te = v[8];
+    if (pn == 0) return ORC_INDEX_ERROR;                              /* p[0] */
+    static nm_t nm[MAXN]; int k = 0;
+    if (path[0] != '<' && path[0] != '>') {
+        /* GFA-style path (:369-371): comma pieces minus their last character */
+        size_t st = 0;
+        for (size_t i = 0; i <= pn; ++i)
+            if (i == pn || path[i] == ',') {
+                if (i > st) { if (k >= MAXN) return ORC_VALUE_ERROR; nm[k].p = path + st; nm[k].n = (uint32_t)(i - st - 1); ++k; }
+                st = i + 1;
+            }
+    } else {
+        size_t st = 0;
+        for (size_t i = 0; i <= pn; ++i)
+            if (i == pn || path[i] == '<' || path[i] == '>') {
+                if (i > st) { if (k >= MAXN) return ORC_VALUE_ERROR; nm[k].p = path + st; nm[k].n = (uint32_t)(i - st); ++k; }
+                st = i + 1;
+            }
+    }
+    if (k < 2) return ORC_OK;
+    for (int i = 0; i < k; ++i) {                                     /* :203-209 */
+        if (nm[i].n == 0) return ORC_VALUE_ERROR;                     /* str.split("") */
+        const char *q = find(path, pn, nm[i].p, nm[i].n);
+        if (q == path) return ORC_INDEX_ERROR;                        /* ""[-1] */
+        nm[i].strand = (q[-1] == '>') ? '+' : '-';
+    }
+    static char key[2][8192];
+    for (int i = 0; i + 1 < k; ++i) {
+        const nm_t *L = &nm[i], *R = &nm[i + 1];
+        if ((size_t)L->n + R->n + 8 > sizeof key[0]) return ORC_VALUE_ERROR;
+        size_t kl[2];
+        { char *q = key[0]; memcpy(q, L->p, L->n); q += L->n; *q++ = '@'; *q++ = L->strand; *q++ = '@';
+          memcpy(q, R->p, R->n); q += R->n; *q++ = '@'; *q++ = R->strand; kl[0] = (size_t)(q - key[0]); }
+        { char *q = key[1]; memcpy(q, R->p, R->n); q += R->n; *q++ = '@'; *q++ = (R->strand == '+') ? '-' : '+'; *q++ = '@';
+          memcpy(q, L->p, L->n); q += L->n; *q++ = '@'; *q++ = (L->strand == '+') ? '-' : '+'; kl[1] = (size_t)(q - key[1]); }
+        int have_ok = 0, ok = 0;
+        for (int d = 0; d < 2; ++d) {
+            edge_t *e = edge_slot(o, key[d], kl[d]);
+            if (!e->key) continue;
+            for (uint32_t t = 0; t < e->n; ++t) {
+                if (!have_ok) {                                       /* :258-273, identical for every entry */
+                    int il = 0, ir = 0;
+                    while (!same(&nm[il], L)) ++il;
+                    while (!same(&nm[ir], R)) ++ir;
+                    int64_t left = 0, right = 0, l1; int rc;
+                    for (int j = 0; j <= il; ++j) { if ((rc = node_len(o, nm[j].p, nm[j].n, &l1))) return rc; left += l1; }
+                    for (int j = ir; j < k; ++j) { if ((rc = node_len(o, nm[j].p, nm[j].n, &l1))) return rc; right += l1; }
+                    ok = (left - Ts >= 100) && (right - (Tlen - Te - 1) >= 100);
+                    have_ok = 1;
+                }
+                if (!ok) continue;
+                if (e->ent[t].sv < n_sv) counts[(uint64_t)e->ent[t].sv * 2 + e->ent[t].allele]++;
+                if (hits) {
+                    if (*n_hits >= hit_cap) return ORC_HIT_OVERFLOW;
+                    hits[*n_hits].line_index = li; hits[*n_hits].line_start = lstart;
+                    hits[*n_hits].sv = e->ent[t].sv; hits[*n_hits].allele = e->ent[t].allele;
+                }
+                ++*n_hits;
+            }
+        }
+    }
+    return ORC_OK;
+}
+
+/* Whole buffer.  Lines end at \n, \r\n or a lone \r (Python universal newlines, the mode the
+ * reference opens its GAF in); the last line may lack a terminator.
+ * Returns ORC_*; on error *err_line is the 0-based line index. */
+int orc_filter(void *p, const char *gaf, uint64_t n, uint64_t *counts, uint64_t n_sv,
+               orc_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits, uint64_t *n_lines, uint64_t *err_line)
+{
+    oracle_t *o = (oracle_t *)p;
+    uint64_t pos = 0, li = 0;
+    *n_hits = 0;
+    while (pos < n) {
+        uint64_t e = pos;
+        while (e < n && gaf[e] != '\n' && gaf[e] != '\r') ++e;
+        int rc = do_line(o, gaf + pos, (size_t)(e - pos), li, pos, counts, n_sv, hits, hit_cap, n_hits);
+        if (rc) { *err_line = li; *n_lines = li; return rc; }
+        ++li;
+        if (e < n && gaf[e] == '\r' && e + 1 < n && gaf[e + 1] == '\n') ++e;
+        pos = e + 1;
+    }
+    *n_lines = li;
+    return ORC_OK;
+}

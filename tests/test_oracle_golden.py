@@ -78,3 +78,61 @@ def test_py_vcf_crash_case(golden):
     D = json.load(open(f"{v}/cases_informative_aln.json"))
     with pytest.raises(IndexError):
         O.genotype_vcf(_read_lines(f"{v}/err_no_end.vcf"), D)
+
+
+# ------------------------------------------------------------------------------------------------
+# C oracle
+# ------------------------------------------------------------------------------------------------
+from oracle import oracle_c as OC  # noqa: E402
+
+
+@pytest.mark.parametrize("name", QUIRKS)
+def test_c_filter_quirks(golden, name):
+    q = f"{golden}/quirks"
+    man = json.load(open(f"{q}/manifest.json"))[name]
+    orc = OC.COracle(O.load_edges(f"{q}/q_svs_edges.json"), O.load_alt_node_len(f"{q}/q.gfa"))
+    raw = open(f"{q}/{name}.gaf", "rb").read()
+    if man["rc"] == 0:
+        counts, hits, n_lines = orc.filter(raw)
+        D = OC.informative_dict(orc.sv_ids, hits, raw)
+        assert O.dump_informative(D) == open(f"{q}/{name}.ref.json").read()
+        ref = json.load(open(f"{q}/{name}.ref.json"))
+        for i, sv in enumerate(orc.sv_ids):
+            assert [int(counts[i, 0]), int(counts[i, 1])] == [len(x) for x in ref.get(sv, [[], []])]
+    else:
+        with pytest.raises(Exception) as ei:
+            orc.filter(raw)
+        assert type(ei.value).__name__ == man["error"]
+
+
+def test_c_testdir(golden):
+    t = f"{golden}/testdir"
+    orc = OC.COracle(O.load_edges(f"{t}/test_svs_edges.json"), O.load_alt_node_len(f"{t}/test.gfa"))
+    raw = open(f"{t}/test.gaf", "rb").read()
+    counts, hits, n_lines = orc.filter(raw)
+    assert n_lines == raw.count(b"\n")
+    D = OC.informative_dict(orc.sv_ids, hits, raw)
+    assert O.dump_informative(D) == open(f"{t}/ref_informative_aln.json").read()
+
+
+@pytest.mark.parametrize("tag", ["g6_mixed", "g6_del"])
+def test_c_synth_g6(golden, tag, tmp_path):
+    """Medium synthetic case: inputs regenerated from the seed, reference outputs pinned by sha256 + counts."""
+    import hashlib
+    import synth
+    g6 = json.load(open(f"{golden}/synth/g6.json"))[tag]
+    pre = str(tmp_path / "s")
+    synth.generate(prefix=pre, **g6["args"])
+    for ext, sha in g6["sha256_inputs"].items():
+        assert hashlib.sha256(open(pre + ext, "rb").read()).hexdigest() == sha, f"generator drifted: {ext}"
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    raw = open(pre + ".gaf", "rb").read()
+    counts, hits, n_lines = orc.filter(raw)
+    got = {sv: [int(counts[i, 0]), int(counts[i, 1])] for i, sv in enumerate(orc.sv_ids) if counts[i].sum()}
+    assert got == g6["counts"]
+    js = O.dump_informative(OC.informative_dict(orc.sv_ids, hits, raw))
+    assert hashlib.sha256(js.encode()).hexdigest() == g6["sha256_json"]
+    text, n = O.genotype_vcf(open(pre + ".vcf").readlines(), json.loads(js))
+    assert hashlib.sha256(text.encode()).hexdigest() == g6["sha256_vcf"]
+    assert text == open(f"{golden}/synth/{tag}.ref_genotype.vcf").read()
+    assert f"Genotyped svs: {n}\n" == g6["stdout"]
