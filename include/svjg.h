@@ -1,0 +1,163 @@
+/* svjg.h — C ABI of libsvjg_hip.so: the MI355X (gfx950) implementation of SVJedi-graph's
+ * alignment-classification + genotype-likelihood hot path.
+ *
+ * The reference (SandraLouise/SVJedi-graph) has no FFI for this path: its boundary is two Python
+ * scripts run as shell commands (svjedi-graph.py:114-115, :124-125).  The drop-in scripts in
+ * svjedi-graph_amd/ keep that command-line / file contract and call the entry points below through
+ * ctypes (svjedi-graph_amd/svjg/capi.py).  Each entry point names the reference code it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative SVJG_E_* code on failure (message via
+ * svjg_last_error).  The caller owns every host buffer it passes in or out; the library owns all device
+ * memory.  Calls on one context must be serialised by the caller.  All structs are fixed-width
+ * little-endian PODs.  No exceptions or aborts cross the boundary.  There is no CPU fallback: without a
+ * GPU svjg_init fails with SVJG_E_NO_DEVICE.
+ */
+#ifndef SVJG_H
+#define SVJG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVJG_ABI_VERSION 1
+
+/* error codes (negative returns) */
+#define SVJG_E_NO_DEVICE   (-1)   /* no usable HIP device */
+#define SVJG_E_HIP         (-2)   /* a HIP runtime call failed */
+#define SVJG_E_ARG         (-3)   /* bad argument / call order */
+#define SVJG_E_NOMEM       (-4)
+#define SVJG_E_RCCL        (-5)
+/* The input made the reference raise (it would exit 1, svjedi-graph.py:117-118).  svjg_input_error()
+ * tells which Python exception and at which byte offset of the GAF. */
+#define SVJG_E_INPUT       (-10)
+
+/* exception class the reference would have died with (svjg_input_error) */
+#define SVJG_EXC_NONE            0
+#define SVJG_EXC_VALUE_ERROR     1   /* int()/float() of a column, too few columns (filter-alignments.py:185-194) */
+#define SVJG_EXC_INDEX_ERROR     2   /* empty path column, unoriented multi-node path, node name without '-' */
+#define SVJG_EXC_KEY_ERROR       3   /* alt node missing from the GFA (filter-alignments.py:346) */
+#define SVJG_EXC_ZERO_DIVISION   4   /* Alen == 0 without an id:f: tag (filter-alignments.py:196) */
+
+typedef struct svjg_ctx svjg_ctx;
+
+/* ---- graph tables (built on the host by svjedi-graph_amd/svjg/graph.py) ---------------------------
+ * They replace d_link_sv (filter-alignments.py:95-98), alt_node_len (:103-113) and the node-name
+ * arithmetic of get_node_start/end/len (:328-349).
+ *
+ * Nodes are sorted by `key` = chrom_idx << 48 | pos << 16 | kind << 15 | cnt
+ *   reference node "chrom:start-end": pos = start, kind = 0, cnt = 0, aux = end
+ *   alt node       "chrom:pos.cnt"  : pos = pos,   kind = 1, cnt = cnt, aux = sequence length
+ *                                     (SVJG_LEN_UNKNOWN if the GFA has no S-line for it)
+ * row   = first entry of this node's links in the edge array (rows are contiguous, node n's links are
+ *         [row(n), row(n+1)); the node array carries one sentinel element at the end)
+ * flags = SVJG_NODE_HAZARD if the node's name is a proper substring of another node name of the graph
+ *         (the strand quirk of filter-alignments.py:206 can then depend on the other nodes of the path)
+ */
+#define SVJG_LEN_UNKNOWN 0xFFFFFFFFu
+#define SVJG_NODE_HAZARD 1u
+
+typedef struct {
+    uint64_t key;
+    uint32_t aux;
+    uint32_t row;      /* bit 31 = SVJG_NODE_HAZARD, bits 0..30 = row */
+} svjg_node;
+
+/* One directed link query (left node = the row it sits in).  The host stores, for every key K of
+ * *_svs_edges.json and its reversed form R (filter-alignments.py:221-225), the concatenation
+ * d[K] ++ d[R] under K and d[R] ++ d[K] under R, so that ONE probe per path step returns exactly what
+ * the reference collects with its two dictionary probes (:141-153), multiplicities included.
+ *   meta bit 0 = strand of the left node  (1 = '-'), bit 1 = strand of the right node, bits 2.. = n_hits
+ *   n_hits <= 2: h0, h1 are the hits;  n_hits > 2: h0 = first index into the hit array
+ *   a hit is slot << 1 | allele
+ */
+typedef struct {
+    uint32_t right;
+    uint32_t meta;
+    uint32_t h0;
+    uint32_t h1;
+} svjg_edge;
+
+/* chromosome dictionary: names concatenated in `chrom_names`, chrom i = [chrom_off[i], chrom_off[i+1]);
+ * chrom_node_lo[i] .. chrom_node_lo[i+1] is its node range. */
+typedef struct {
+    const svjg_node *nodes;        uint64_t n_nodes;       /* without the sentinel; nodes[n_nodes] is the sentinel */
+    const svjg_edge *edges;        uint64_t n_edges;
+    const uint32_t  *hits;         uint64_t n_hits;        /* overflow hit lists */
+    const char      *chrom_names;  const uint32_t *chrom_off;  const uint32_t *chrom_node_lo;  uint32_t n_chrom;
+    uint32_t         n_slots;      /* number of distinct sv_id keys = length of the count vector */
+    uint32_t         d_over;       /* minimum breakpoint overlap, 100 (filter-alignments.py:56,88) */
+    uint32_t         flags;        /* SVJG_GRAPH_* */
+} svjg_graph;
+
+#define SVJG_GRAPH_ALL_SLOW 1u     /* route every alignment through the exact string path (debug / odd names) */
+
+/* One informative (alignment, SV) pair: what filter-alignments.py:163-166 appends, run-length encoded —
+ * n_ref / n_alt = how many times the line is appended to the ref / alt list of that SV. */
+typedef struct {
+    uint64_t line_start;           /* byte offset of the line in the GAF given to svjg_classify */
+    uint32_t slot;
+    uint16_t n_ref;
+    uint16_t n_alt;
+} svjg_hitrec;
+
+typedef struct {
+    uint64_t n_lines;              /* GAF lines seen */
+    uint64_t n_deferred;           /* lines that took the exact string path */
+    uint64_t n_hitrecs;
+    uint64_t non_ascii;            /* 1 if any byte >= 0x80 was seen (host must validate UTF-8 like the reference's text-mode read) */
+} svjg_stats;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+int  svjg_abi_version(void);
+int  svjg_device_count(void);
+int  svjg_init(int device, svjg_ctx **out);
+void svjg_destroy(svjg_ctx *ctx);
+const char *svjg_last_error(const svjg_ctx *ctx);          /* ctx may be NULL: error of the last failed svjg_init */
+
+/* ---- graph (filter-alignments.py:95-113) ---------------------------------------------------------- */
+int svjg_load_graph(svjg_ctx *ctx, const svjg_graph *g);
+
+/* ---- alignments (filter-alignments.py:123-166) ----------------------------------------------------
+ * svjg_gaf_upload copies a GAF byte buffer to HBM (the PCIe leg); svjg_classify_resident runs the kernels
+ * over the resident buffer and ADDS to the per-SV counts; svjg_classify = upload + classify_resident.
+ * `base_offset` is added to the line offsets reported in hit records / input errors (for chunked files).
+ * Lines end at \n, \r\n or a lone \r and the last line may be unterminated, as in Python's text mode. */
+int svjg_gaf_upload(svjg_ctx *ctx, const char *gaf, uint64_t n_bytes);
+int svjg_classify_resident(svjg_ctx *ctx, uint64_t base_offset, int want_hits);
+int svjg_classify(svjg_ctx *ctx, const char *gaf, uint64_t n_bytes, uint64_t base_offset, int want_hits);
+int svjg_reset_counts(svjg_ctx *ctx);
+int svjg_get_stats(svjg_ctx *ctx, svjg_stats *out);
+int svjg_input_error(svjg_ctx *ctx, int *exc_class, uint64_t *line_offset);
+
+/* counts: out[slot*2 + 0] = ref, out[slot*2 + 1] = alt  (= len() of the two lists of
+ * dict_of_informative_aln[sv_id], filter-alignments.py:163-166) */
+int svjg_get_counts(svjg_ctx *ctx, uint32_t *out, uint32_t n_slots);
+int svjg_set_counts(svjg_ctx *ctx, const uint32_t *in, uint32_t n_slots);   /* predict-genotype.py run stand-alone from a JSON */
+/* hit records accumulated since the last svjg_reset_counts, unordered; copy at most `cap` */
+int svjg_get_hits(svjg_ctx *ctx, svjg_hitrec *out, uint64_t cap, uint64_t *n);
+
+/* ---- multi-GPU: one process per GPU, one all-reduce of the count vector over RCCL/xGMI ------------- */
+int svjg_comm_unique_id(char *out128);                                      /* rank 0, then broadcast by the launcher */
+int svjg_comm_init(svjg_ctx *ctx, const char *id128, int n_ranks, int rank);
+int svjg_allreduce_counts(svjg_ctx *ctx);
+
+/* ---- genotypes (predict-genotype.py:216-227 gate, :281-325 likelihood) -----------------------------
+ * Per VCF row r: sv_type[r] in {0 DEL, 1 INS, 2 INV, 3 BND}; slot[r] = count slot or 0xFFFFFFFF when the
+ * row's sv_id is not a key of the edge table; ok[r] = the reference's type/length gate (:216) passed.
+ * Outputs: gt[r] in {0 "0/0", 1 "0/1", 2 "1/1", 3 "./."}, pl[r*3..] = the three PL integers,
+ * raw[r*2..] = raw (ref, alt) counts, genotyped[r] = 1 if the row went through likelihood()
+ * (i.e. counted by "Genotyped svs", :229).  Rows with genotyped = 0 print "./.:0:0,0:.,.,." (:237-239). */
+int svjg_genotype(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok,
+                  uint64_t n_rows, uint32_t min_support, double err,
+                  uint8_t *gt, int64_t *pl, uint32_t *raw, uint8_t *genotyped);
+
+/* ---- measurement hooks (bench.py): HIP-event time of the kernels of the last classify / genotype ---- */
+int svjg_last_kernel_ms(svjg_ctx *ctx, float *classify_main_ms, float *classify_slow_ms, float *genotype_ms);
+int svjg_sync(svjg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

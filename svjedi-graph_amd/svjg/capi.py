@@ -1,0 +1,210 @@
+"""ctypes binding of libsvjg_hip.so (include/svjg.h).
+
+There is no fallback: if the shared library is missing, or no MI355X is visible, the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(HERE), "csrc", "libsvjg_hip.so")
+
+HITREC_DT = np.dtype([("line_start", "<u8"), ("slot", "<u4"), ("n_ref", "<u2"), ("n_alt", "<u2")])
+
+EXC_CLASS = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError}
+
+
+class SvjgError(RuntimeError):
+    pass
+
+
+class CGraph(ctypes.Structure):
+    _fields_ = [
+        ("nodes", ctypes.c_void_p), ("n_nodes", ctypes.c_uint64),
+        ("edges", ctypes.c_void_p), ("n_edges", ctypes.c_uint64),
+        ("hits", ctypes.c_void_p), ("n_hits", ctypes.c_uint64),
+        ("chrom_names", ctypes.c_char_p), ("chrom_off", ctypes.c_void_p), ("chrom_node_lo", ctypes.c_void_p),
+        ("n_chrom", ctypes.c_uint32),
+        ("n_slots", ctypes.c_uint32), ("d_over", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+    ]
+
+
+class CStats(ctypes.Structure):
+    _fields_ = [("n_lines", ctypes.c_uint64), ("n_deferred", ctypes.c_uint64), ("n_hitrecs", ctypes.c_uint64),
+                ("non_ascii", ctypes.c_uint64)]
+
+
+def cgraph_of(g):
+    """ctypes view of a svjg.graph.Graph (the Graph must stay alive while the struct is in use)."""
+    return CGraph(
+        g.nodes.ctypes.data, g.n_nodes, g.edges.ctypes.data, g.n_edges, g.hits.ctypes.data, g.n_hits,
+        g.chrom_names, g.chrom_off.ctypes.data, g.chrom_lo.ctypes.data, len(g.chroms),
+        g.n_slots, g.d_over, g.flags)
+
+
+_SIGS = {
+    "svjg_abi_version": (ctypes.c_int, []),
+    "svjg_device_count": (ctypes.c_int, []),
+    "svjg_init": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "svjg_destroy": (None, [ctypes.c_void_p]),
+    "svjg_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "svjg_load_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CGraph)]),
+    "svjg_gaf_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "svjg_classify_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
+    "svjg_classify": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
+    "svjg_reset_counts": (ctypes.c_int, [ctypes.c_void_p]),
+    "svjg_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CStats)]),
+    "svjg_input_error": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
+    "svjg_get_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "svjg_set_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "svjg_get_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
+    "svjg_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "svjg_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    "svjg_allreduce_counts": (ctypes.c_int, [ctypes.c_void_p]),
+    "svjg_genotype": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                     ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p]),
+    "svjg_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                           ctypes.POINTER(ctypes.c_float)]),
+    "svjg_sync": (ctypes.c_int, [ctypes.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise SvjgError(f"{p} not found: build it first (python __graft_entry__.py build, needs hipcc); there is no CPU fallback")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.svjg_abi_version() != 1:
+        raise SvjgError("libsvjg_hip.so ABI mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class Context:
+    """One GPU.  Thin, stateful wrapper over the C ABI."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.svjg_init(device, ctypes.byref(h))
+        if rc:
+            msg = self.lib.svjg_last_error(None)
+            raise SvjgError(f"svjg_init failed ({rc}): {msg.decode() if msg else ''}")
+        self.h = h
+        self.graph = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.svjg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc == -10:
+            cls, off = ctypes.c_int(0), ctypes.c_uint64(0)
+            self.lib.svjg_input_error(self.h, ctypes.byref(cls), ctypes.byref(off))
+            raise EXC_CLASS.get(cls.value, ValueError)(f"malformed GAF line at byte offset {off.value}")
+        if rc:
+            raise SvjgError(f"libsvjg_hip error {rc}: {self.lib.svjg_last_error(self.h).decode()}")
+
+    def load_graph(self, g):
+        self.graph = g
+        cg = cgraph_of(g)
+        self._chk(self.lib.svjg_load_graph(self.h, ctypes.byref(cg)))
+
+    def upload(self, gaf):
+        a = _as_u8(gaf)
+        self._chk(self.lib.svjg_gaf_upload(self.h, a.ctypes.data if a.size else None, a.size))
+
+    def classify_resident(self, base_offset=0, want_hits=False):
+        self._chk(self.lib.svjg_classify_resident(self.h, base_offset, int(want_hits)))
+
+    def classify(self, gaf, base_offset=0, want_hits=False):
+        a = _as_u8(gaf)
+        self._chk(self.lib.svjg_classify(self.h, a.ctypes.data if a.size else None, a.size, base_offset, int(want_hits)))
+
+    def reset_counts(self):
+        self._chk(self.lib.svjg_reset_counts(self.h))
+
+    def stats(self):
+        s = CStats()
+        self._chk(self.lib.svjg_get_stats(self.h, ctypes.byref(s)))
+        return {"n_lines": s.n_lines, "n_deferred": s.n_deferred, "n_hitrecs": s.n_hitrecs, "non_ascii": s.non_ascii}
+
+    def counts(self):
+        out = np.zeros((self.graph.n_slots, 2), dtype=np.uint32)
+        self._chk(self.lib.svjg_get_counts(self.h, out.ctypes.data, self.graph.n_slots))
+        return out
+
+    def set_counts(self, c):
+        c = np.ascontiguousarray(c, dtype=np.uint32)
+        assert c.shape == (self.graph.n_slots, 2)
+        self._chk(self.lib.svjg_set_counts(self.h, c.ctypes.data, self.graph.n_slots))
+
+    def hits(self):
+        n = self.stats()["n_hitrecs"]
+        out = np.zeros(n, dtype=HITREC_DT)
+        got = ctypes.c_uint64(0)
+        self._chk(self.lib.svjg_get_hits(self.h, out.ctypes.data, n, ctypes.byref(got)))
+        return out[: got.value]
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        self._chk(self.lib.svjg_comm_init(self.h, unique_id, n_ranks, rank))
+
+    def allreduce_counts(self):
+        self._chk(self.lib.svjg_allreduce_counts(self.h))
+
+    def genotype(self, sv_type, slot, ok, min_support, err):
+        n = len(sv_type)
+        sv_type = np.ascontiguousarray(sv_type, dtype=np.uint8)
+        slot = np.ascontiguousarray(slot, dtype=np.uint32)
+        ok = np.ascontiguousarray(ok, dtype=np.uint8)
+        gt = np.zeros(n, dtype=np.uint8)
+        pl = np.zeros((n, 3), dtype=np.int64)
+        raw = np.zeros((n, 2), dtype=np.uint32)
+        done = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.svjg_genotype(self.h, sv_type.ctypes.data, slot.ctypes.data, ok.ctypes.data, n, min_support,
+                                         float(err), gt.ctypes.data, pl.ctypes.data, raw.ctypes.data, done.ctypes.data))
+        return gt, pl, raw, done
+
+    def kernel_ms(self):
+        a, b, c = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
+        self._chk(self.lib.svjg_last_kernel_ms(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
+
+    def sync(self):
+        self._chk(self.lib.svjg_sync(self.h))
+
+
+def unique_id():
+    lib = load_library()
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.svjg_comm_unique_id(buf)
+    if rc:
+        raise SvjgError(f"svjg_comm_unique_id failed ({rc})")
+    return buf.raw
+
+
+def _as_u8(x):
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x.view(np.uint8))
+    return np.frombuffer(x, dtype=np.uint8)

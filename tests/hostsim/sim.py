@@ -1,0 +1,39 @@
+"""Build + call the host harness of the per-line device routines (tests only)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "_hostsim.so")
+EXC = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError}
+
+
+def build():
+    src = [os.path.join(HERE, "hostsim.cpp"),
+           os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_line.h"),
+           os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_host_tables.h"),
+           os.path.join(HERE, "..", "..", "include", "svjg.h")]
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in src):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-shared", "-fPIC", "-o", SO, src[0]], check=True)
+    return SO
+
+
+def classify(graph, gaf, force_slow=False, pend_cap=12):
+    from svjg import capi
+    lib = ctypes.CDLL(build())
+    lib.hostsim_classify.restype = ctypes.c_int
+    lib.hostsim_classify.argtypes = [ctypes.POINTER(capi.CGraph), ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int,
+                                     ctypes.c_uint32, ctypes.c_void_p] + [ctypes.c_void_p] * 4
+    cg = capi.cgraph_of(graph)
+    buf = np.frombuffer(gaf, dtype=np.uint8) if not isinstance(gaf, np.ndarray) else gaf
+    counts = np.zeros((max(graph.n_slots, 1), 2), dtype=np.uint32)
+    nl, nd, eo = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    ex = ctypes.c_int(0)
+    rc = lib.hostsim_classify(ctypes.byref(cg), buf.ctypes.data if buf.size else None, buf.size, int(force_slow), pend_cap,
+                              counts.ctypes.data, ctypes.addressof(nl), ctypes.addressof(nd), ctypes.addressof(ex),
+                              ctypes.addressof(eo))
+    if rc:
+        raise EXC[ex.value](f"offset {eo.value}")
+    return counts[: graph.n_slots], nl.value, nd.value
