@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the hot path (classify + all-reduce + genotype) on synthetic GAF, N GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4shard] [--aln N_ALN]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the path over one batch: zero the count vector, classify every alignment of this rank's
+GAF shard (text already resident in HBM), all-reduce the per-SV counts (N > 1), genotype every VCF row.
+value = alignments classified per second over all ranks.  One JSON line on rank 0.
+
+Workload at N = 1: BASELINE.json configs[2] (10 M alignments x 100 k mixed SVs, the largest single-GPU
+configuration); every further rank adds another 10 M alignments of the same synthetic stream on the same
+graph (weak scaling; the stream is a pure function of (seed, line index), so rank r writes lines
+[r*10M, (r+1)*10M)).  --workload c4shard = configs[3] / 8 per rank (12.5 M alignments x 500 k SVs).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "svjedi-graph_amd"), os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+
+WORKLOADS = {
+    # name: (alignments per rank, n_sv, n_chrom, mix, seed, description)
+    "c2": (1_000_000, 10_000, 1, "del", 20260515 + 1, "configs[1]: 1 M GAF alignments x 10 k DEL SVs"),
+    "c3": (10_000_000, 100_000, 4, "mixed", 20260515 + 2, "configs[2]: 10 M GAF alignments x 100 k mixed DEL/INS/INV/BND SVs"),
+    "c4shard": (12_500_000, 500_000, 24, "mixed", 20260515 + 3, "configs[3]/8: 12.5 M GAF alignments x 500 k mixed SVs per GPU"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--aln", type=int, default=0, help="override alignments per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")          # bootstrap + barriers only; the data-path collective is RCCL in libsvjg_hip
+
+    import synth
+    from svjg import capi, genotype, shard
+    from svjg.graph import Graph
+
+    n_aln, n_sv, n_chrom, mix, seed, desc = WORKLOADS[args.workload]
+    if args.aln:
+        n_aln = args.aln
+
+    # ---- inputs (untimed) --------------------------------------------------------------------------
+    t0 = time.time()
+    tmp = tempfile.mkdtemp(prefix="svjg_bench_")
+    pre = os.path.join(tmp, "w")
+    inf = synth.generate(pre, 0, n_sv, n_chrom, mix, seed, write_gaf=False)
+    gaf = synth.gaf_bytes(inf["tables"], seed, rank * n_aln, n_aln, threads=min(16, os.cpu_count() or 8))
+    graph = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    rows = genotype.VcfRows(pre + ".vcf", graph.slot_of)
+    t_setup = time.time() - t0
+
+    ctx = capi.Context(local_rank)
+    ctx.load_graph(graph)
+    t1 = time.time()
+    ctx.upload(gaf)
+    t_h2d = time.time() - t1
+    group = shard.RcclGroup(ctx, world, rank, shard.torch_exchange) if world > 1 else None
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        ctx.reset_counts()
+        ctx.classify_resident(base_offset=0, want_hits=False)
+        if group is not None:
+            group.allreduce_counts()
+        return ctx.genotype(rows.sv_type, rows.slot, rows.ok, 3, 0.00005)
+
+    for _ in range(args.warmup):
+        step()
+    main_ms, slow_ms, geno_ms = [], [], []
+    barrier()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        a, b, c = ctx.kernel_ms()
+        main_ms.append(a); slow_ms.append(b); geno_ms.append(c)
+    barrier()
+    dt = time.perf_counter() - t
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+
+    st = ctx.stats()
+    counts = ctx.counts()
+    gt, pl, raw, done = out
+
+    if rank == 0:
+        total_aln = n_aln * world
+        ms_per_step = dt / args.steps * 1e3
+        k_main = float(np.mean(main_ms))
+        achieved = gaf.size / (k_main * 1e-3) / 1e9
+        res = {
+            "metric": "GAF alignments classified/sec (classify + count all-reduce + genotype, text resident in HBM)",
+            "value": total_aln * args.steps / dt,
+            "unit": "alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int64 (classify), f64 (likelihood)", "data": "synthetic",
+            "config": {"workload": desc, "alignments_per_gpu": n_aln, "svs": n_sv, "gaf_bytes_per_gpu": int(gaf.size),
+                       "bytes_per_alignment": round(gaf.size / n_aln, 1), "count_slots": graph.n_slots,
+                       "graph_nodes": graph.n_nodes, "vcf_rows": int(len(rows.sv_type))},
+            "svs_genotyped_per_s": float(len(rows.sv_type) * world / (np.mean(geno_ms) * 1e-3)) if np.mean(geno_ms) > 0 else None,
+            "genotyped_rows": int(done.sum()),
+            "kernel_ms": {"classify_main": k_main, "classify_exact_path": float(np.mean(slow_ms)), "genotype": float(np.mean(geno_ms))},
+            "deferred_lines_per_step": st["n_deferred"] // max(1, args.steps + args.warmup),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_classify_main", "algorithmic_bytes_per_launch": int(gaf.size)},
+            "setup_s": {"generate_and_tables": round(t_setup, 1), "h2d_upload": round(t_h2d, 3),
+                        "pcie_inclusive_alignments_per_s": n_aln / (t_h2d + ms_per_step * 1e-3)},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(pre, gaf, graph, counts, rows)
+        print(json.dumps(res))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pre, gaf, graph, gpu_counts, rows):
+    """The CPU oracle (C restatement of the reference's per-line algorithm, 1 thread — the reference itself is
+    single-threaded Python) on a bounded sample of the same GAF, and a parity spot check of the GPU counts."""
+    from oracle import oracle_c, oracle_py
+    orc = oracle_c.COracle(oracle_py.load_edges(pre + "_svs_edges.json"), oracle_py.load_alt_node_len(pre + ".gfa"))
+    n_lines = 2_000_000
+    nl = np.flatnonzero(gaf[: min(gaf.size, 700 * n_lines)] == 10)
+    n_lines = min(n_lines, nl.size)
+    sample = gaf[: int(nl[n_lines - 1]) + 1]
+    t = time.perf_counter()
+    want, _, got_lines = orc.filter(sample, want_hits=False)
+    dt = time.perf_counter() - t
+    base = {"value": got_lines / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
+            "sample": f"first {got_lines} alignments of the same GAF ({sample.size} bytes), oracle/svjg_oracle.c, {dt:.1f} s; "
+                      f"host has {os.cpu_count()} cores"}
+    # parity spot check: classify the same sample on the GPU path and compare the whole count vector
+    from svjg import capi
+    c2 = capi.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    c2.load_graph(graph)
+    c2.classify(sample)
+    g = c2.counts()
+    c2.close()
+    exp = {sv: (int(want[i, 0]), int(want[i, 1])) for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
+    got = {graph.sv_ids[i]: (int(g[i, 0]), int(g[i, 1])) for i in range(graph.n_slots) if g[i].sum()}
+    base["parity_on_sample"] = "bit-exact" if exp == got else "MISMATCH"
+    # genotype leg: pure-Python restatement on a sample of rows
+    D = {graph.sv_ids[i]: [["x"] * int(gpu_counts[i, 0]), ["y"] * int(gpu_counts[i, 1])]
+         for i in range(graph.n_slots) if gpu_counts[i].sum()}
+    lines = open(pre + ".vcf").readlines()[:20000]
+    t = time.perf_counter()
+    oracle_py.genotype_vcf(lines, D)
+    dt = time.perf_counter() - t
+    base["genotype_svs_per_s"] = (len([l for l in lines if not l.startswith("#")])) / dt
+    return base
+
+
+if __name__ == "__main__":
+    main()

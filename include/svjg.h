@@ -135,6 +135,8 @@ int svjg_input_error(svjg_ctx *ctx, int *exc_class, uint64_t *line_offset);
  * dict_of_informative_aln[sv_id], filter-alignments.py:163-166) */
 int svjg_get_counts(svjg_ctx *ctx, uint32_t *out, uint32_t n_slots);
 int svjg_set_counts(svjg_ctx *ctx, const uint32_t *in, uint32_t n_slots);   /* predict-genotype.py run stand-alone from a JSON */
+/* size the count vector without a graph (stand-alone predict-genotype.py: counts come from the JSON) */
+int svjg_alloc_counts(svjg_ctx *ctx, uint32_t n_slots);
 /* hit records accumulated since the last svjg_reset_counts, unordered; copy at most `cap` */
 int svjg_get_hits(svjg_ctx *ctx, svjg_hitrec *out, uint64_t cap, uint64_t *n);
 
@@ -145,7 +147,8 @@ int svjg_allreduce_counts(svjg_ctx *ctx);
 
 /* ---- genotypes (predict-genotype.py:216-227 gate, :281-325 likelihood) -----------------------------
  * Per VCF row r: sv_type[r] in {0 DEL, 1 INS, 2 INV, 3 BND}; slot[r] = count slot or 0xFFFFFFFF when the
- * row's sv_id is not a key of the edge table; ok[r] = the reference's type/length gate (:216) passed.
+ * row's sv_id is not a key of the edge table; ok[r] bit 0 = the reference's type/length gate (:216) passed,
+ * bit 1 = a valid slot alone proves the sv_id is a key of the informative dict (counts loaded from a JSON).
  * Outputs: gt[r] in {0 "0/0", 1 "0/1", 2 "1/1", 3 "./."}, pl[r*3..] = the three PL integers,
  * raw[r*2..] = raw (ref, alt) counts, genotyped[r] = 1 if the row went through likelihood()
  * (i.e. counted by "Genotyped svs", :229).  Rows with genotyped = 0 print "./.:0:0,0:.,.,." (:237-239). */

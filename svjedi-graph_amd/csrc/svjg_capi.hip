@@ -1,0 +1,424 @@
+// libsvjg_hip.so — host side of the C ABI declared in include/svjg.h.
+// One context = one MI355X, one HIP stream; kernels live in svjg_kernels.h.
+#include "svjg_kernels.h"
+#include "svjg_host_tables.h"
+#include <rccl/rccl.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace svjg;
+
+static thread_local std::string g_init_error;
+
+struct svjg_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    std::string err;
+    // graph
+    bool have_graph = false, have_counts = false;
+    svjg_node *d_nodes = nullptr;  svjg_edge *d_edges = nullptr;  uint32_t *d_hits = nullptr;
+    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr;
+    GraphView gv{};
+    uint32_t names_len = 0, dict_bytes = 0, dict_in_lds = 0, gflags = 0, n_slots = 0;
+    unsigned long long *d_counts = nullptr, *d_snap = nullptr;
+    // text
+    uint8_t *d_gaf = nullptr;  uint64_t gaf_cap = 0, gaf_bytes = 0;  bool have_gaf = false;
+    // outputs
+    uint64_t *d_deferred = nullptr;  uint64_t deferred_cap = 0;
+    svjg_hitrec *d_recs = nullptr;   uint64_t rec_cap = 0;
+    DevStatus *d_st = nullptr;
+    DevStatus h_st{};
+    uint64_t total_deferred = 0;
+    // genotype scratch
+    dd *d_logfact = nullptr;  uint32_t logfact_n = 0;  dd *d_bsum = nullptr;
+    unsigned int *d_maxn = nullptr;
+    void *d_rows = nullptr;  uint64_t rows_cap = 0;
+    // timing of the last calls
+    float ms_main = 0, ms_slow = 0, ms_geno = 0;
+    // rccl
+    ncclComm_t comm = nullptr;
+};
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return SVJG_E_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+extern "C" int svjg_abi_version(void) { return SVJG_ABI_VERSION; }
+
+extern "C" int svjg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *svjg_last_error(const svjg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+extern "C" int svjg_init(int device, svjg_ctx **out) {
+    if (!out) return SVJG_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_init_error = "no HIP device visible (libsvjg_hip has no CPU fallback)";
+        return SVJG_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { g_init_error = "device index out of range"; return SVJG_E_ARG; }
+    svjg_ctx *c = new svjg_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        g_init_error = "hipSetDevice / hipStreamCreate failed";
+        delete c;
+        return SVJG_E_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    for (auto &ev : c->ev) hipEventCreate(&ev);
+    if (hipMalloc(&c->d_st, sizeof(DevStatus)) != hipSuccess || hipMalloc(&c->d_maxn, sizeof(unsigned int)) != hipSuccess) {
+        g_init_error = "hipMalloc failed";
+        delete c;
+        return SVJG_E_NOMEM;
+    }
+    hipFuncSetAttribute((const void *)k_classify_main, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = c;
+    return 0;
+}
+
+static void free_graph(svjg_ctx *c) {
+    hipFree(c->d_nodes); hipFree(c->d_edges); hipFree(c->d_hits); hipFree(c->d_cnames); hipFree(c->d_coff);
+    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap);
+    c->d_nodes = nullptr; c->d_edges = nullptr; c->d_hits = nullptr; c->d_cnames = nullptr; c->d_coff = nullptr;
+    c->d_clo = nullptr; c->d_chash = nullptr; c->d_counts = nullptr; c->d_snap = nullptr;
+    c->have_graph = false; c->have_counts = false;
+}
+
+extern "C" void svjg_destroy(svjg_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    free_graph(c);
+    hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
+    hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows);
+    for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+template <class T>
+static int upload(svjg_ctx *c, T **dst, const T *src, uint64_t n, uint64_t extra = 0) {
+    HIPCHK(c, hipMalloc((void **)dst, (n + extra + 1) * sizeof(T)));
+    if (n) HIPCHK(c, hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+static int reset_status(svjg_ctx *c, bool all) {
+    DevStatus s = c->h_st;
+    if (all) { memset(&s, 0, sizeof s); c->total_deferred = 0; }
+    s.n_deferred = 0; s.overflow = 0;
+    if (all) s.err = ~0ull;
+    c->h_st = s;
+    HIPCHK(c, hipMemcpyAsync(c->d_st, &c->h_st, sizeof s, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
+    if (!c || !g || !g->nodes || !g->chrom_off || !g->chrom_node_lo) return SVJG_E_ARG;
+    if (g->n_nodes >= 0x7FFFFFFFull || g->n_edges >= 0x7FFFFFFFull || g->n_chrom >= 65535) { c->err = "graph too large"; return SVJG_E_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    free_graph(c);
+    int rc;
+    if ((rc = upload(c, &c->d_nodes, g->nodes, g->n_nodes + 1))) return rc;
+    if ((rc = upload(c, &c->d_edges, g->edges, g->n_edges))) return rc;
+    if ((rc = upload(c, &c->d_hits, g->hits, g->n_hits))) return rc;
+    c->names_len = g->chrom_off[g->n_chrom];
+    if ((rc = upload(c, &c->d_cnames, (const uint8_t *)g->chrom_names, c->names_len, 8))) return rc;
+    if ((rc = upload(c, &c->d_coff, g->chrom_off, g->n_chrom + 1))) return rc;
+    if ((rc = upload(c, &c->d_clo, g->chrom_node_lo, g->n_chrom + 1))) return rc;
+    std::vector<uint32_t> hash = build_chrom_hash(*g);
+    if ((rc = upload(c, &c->d_chash, hash.data(), hash.size()))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // `hash` is a local
+    c->gv.nodes = c->d_nodes; c->gv.n_nodes = (uint32_t)g->n_nodes; c->gv.edges = c->d_edges; c->gv.hits = c->d_hits;
+    c->gv.chrom_names = c->d_cnames; c->gv.chrom_off = c->d_coff; c->gv.chrom_lo = c->d_clo; c->gv.chrom_hash = c->d_chash;
+    c->gv.n_chrom = g->n_chrom; c->gv.hash_mask = (uint32_t)hash.size() - 1; c->gv.d_over = g->d_over;
+    c->dict_bytes = ((c->names_len + 3) & ~3u) + 4 * (2 * (g->n_chrom + 1) + (uint32_t)hash.size());
+    c->dict_in_lds = c->dict_bytes <= DICT_LDS_MAX;
+    c->gflags = g->flags;
+    c->n_slots = g->n_slots;
+    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)g->n_slots + 1) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)g->n_slots + 1) * 8));
+    c->have_graph = true; c->have_counts = true;
+    return svjg_reset_counts(c);
+}
+
+extern "C" int svjg_alloc_counts(svjg_ctx *c, uint32_t n_slots) {
+    if (!c) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    free_graph(c);
+    c->n_slots = n_slots;
+    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)n_slots + 1) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)n_slots + 1) * 8));
+    c->have_counts = true;
+    return svjg_reset_counts(c);
+}
+
+extern "C" int svjg_reset_counts(svjg_ctx *c) {
+    if (!c || !c->have_counts) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, ((uint64_t)c->n_slots + 1) * 8, c->stream));
+    int rc = reset_status(c, true);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int svjg_gaf_upload(svjg_ctx *c, const char *gaf, uint64_t n) {
+    if (!c || (n && !gaf)) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t need = ((n + 15) & ~15ull) + TEXT + 64;
+    if (need > c->gaf_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_gaf); c->d_gaf = nullptr; c->gaf_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_gaf, need));
+        c->gaf_cap = need;
+    }
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_gaf, gaf, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_gaf + n, 0, need - n, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->gaf_bytes = n;
+    c->have_gaf = true;
+    return 0;
+}
+
+static int ensure(svjg_ctx *c, void **p, uint64_t *cap, uint64_t want, size_t elem, bool keep) {
+    if (want <= *cap) return 0;
+    void *q = nullptr;
+    HIPCHK(c, hipMalloc(&q, want * elem));
+    if (keep && *p && *cap) HIPCHK(c, hipMemcpyAsync(q, *p, *cap * elem, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(*p);
+    *p = q; *cap = want;
+    return 0;
+}
+
+extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int want_hits) {
+    if (!c || !c->have_graph || !c->have_gaf) { if (c) c->err = "classify needs a graph and an uploaded GAF"; return SVJG_E_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = c->gaf_bytes;
+    if (n == 0) return 0;
+    const bool all_slow = (c->gflags & SVJG_GRAPH_ALL_SLOW) != 0;
+    uint64_t def_want = all_slow ? n / 24 + 64 : (n / 4096 + 65536);
+    uint64_t rec_want = want_hits ? c->h_st.n_recs + n / 64 + 65536 : 0;
+    int rc;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if ((rc = ensure(c, (void **)&c->d_deferred, &c->deferred_cap, def_want, sizeof(uint64_t), false))) return rc;
+        if (want_hits && (rc = ensure(c, (void **)&c->d_recs, &c->rec_cap, rec_want, sizeof(svjg_hitrec), true))) return rc;
+        // snapshot so that an overflowed attempt can be rolled back
+        HIPCHK(c, hipMemcpyAsync(c->d_snap, c->d_counts, ((uint64_t)c->n_slots + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+        DevStatus before = c->h_st;
+        if ((rc = reset_status(c, false))) return rc;
+        ClassifyArgs a{};
+        a.gaf = c->d_gaf; a.n_bytes = n; a.base_offset = base_offset; a.g = c->gv;
+        a.dict_names_len = c->names_len; a.dict_in_lds = c->dict_in_lds; a.all_slow = all_slow; a.want_hits = want_hits != 0;
+        a.n_chunks = (uint32_t)((n + CHUNK - 1) / CHUNK);
+        a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
+        a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st;
+        size_t lds = TEXT + 16 + ((MAXSTARTS + 8) * 2 + 15) / 16 * 16 + HMAX * WG * sizeof(Pending) + 64 + (c->dict_in_lds ? c->dict_bytes : 0);
+        uint32_t grid = a.n_chunks < (uint32_t)c->n_cu * 2 ? a.n_chunks : (uint32_t)c->n_cu * 2;
+        HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        uint64_t n_def = c->h_st.n_deferred;
+        c->ms_slow = 0;
+        if (n_def && !(c->h_st.overflow & 1u)) {
+            HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+            hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)((n_def + WG - 1) / WG)), dim3(WG), 0, c->stream, a, n_def);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipEventElapsedTime(&c->ms_slow, c->ev[2], c->ev[3]));
+        }
+        HIPCHK(c, hipEventElapsedTime(&c->ms_main, c->ev[0], c->ev[1]));
+        if (!c->h_st.overflow) { c->total_deferred += n_def; break; }
+        // roll back and retry with worst-case buffers
+        if (attempt == 2) { c->err = "output buffers overflowed repeatedly"; return SVJG_E_NOMEM; }
+        if (c->h_st.overflow & 1u) def_want = n / 24 + 64;
+        if (c->h_st.overflow & 2u) rec_want = before.n_recs + (c->h_st.n_recs - before.n_recs) * 2 + n / 24 + 64;
+        HIPCHK(c, hipMemcpyAsync(c->d_counts, c->d_snap, ((uint64_t)c->n_slots + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+        uint64_t keep_err = before.err;
+        c->h_st = before; c->h_st.err = keep_err;
+    }
+    if (c->h_st.err != ~0ull) return SVJG_E_INPUT;
+    return 0;
+}
+
+extern "C" int svjg_classify(svjg_ctx *c, const char *gaf, uint64_t n, uint64_t base_offset, int want_hits) {
+    int rc = svjg_gaf_upload(c, gaf, n);
+    if (rc) return rc;
+    return svjg_classify_resident(c, base_offset, want_hits);
+}
+
+extern "C" int svjg_get_stats(svjg_ctx *c, svjg_stats *out) {
+    if (!c || !out) return SVJG_E_ARG;
+    out->n_lines = c->h_st.n_lines; out->n_deferred = c->total_deferred; out->n_hitrecs = c->h_st.n_recs; out->non_ascii = c->h_st.non_ascii;
+    return 0;
+}
+
+extern "C" int svjg_input_error(svjg_ctx *c, int *cls, uint64_t *off) {
+    if (!c || !cls || !off) return SVJG_E_ARG;
+    if (c->h_st.err == ~0ull) { *cls = SVJG_EXC_NONE; *off = 0; }
+    else { *cls = (int)(c->h_st.err & 7); *off = c->h_st.err >> 3; }
+    return 0;
+}
+
+extern "C" int svjg_get_counts(svjg_ctx *c, uint32_t *out, uint32_t n_slots) {
+    if (!c || !c->have_counts || !out || n_slots != c->n_slots) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<unsigned long long> tmp(n_slots);
+    if (n_slots) HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_counts, (uint64_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n_slots; ++i) { out[2 * i] = (uint32_t)tmp[i]; out[2 * i + 1] = (uint32_t)(tmp[i] >> 32); }
+    return 0;
+}
+
+extern "C" int svjg_set_counts(svjg_ctx *c, const uint32_t *in, uint32_t n_slots) {
+    if (!c || !c->have_counts || !in || n_slots != c->n_slots) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<unsigned long long> tmp(n_slots);
+    for (uint32_t i = 0; i < n_slots; ++i) tmp[i] = (unsigned long long)in[2 * i] | ((unsigned long long)in[2 * i + 1] << 32);
+    if (n_slots) HIPCHK(c, hipMemcpyAsync(c->d_counts, tmp.data(), (uint64_t)n_slots * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int svjg_get_hits(svjg_ctx *c, svjg_hitrec *out, uint64_t cap, uint64_t *n) {
+    if (!c || !n) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t have = c->h_st.n_recs < cap ? c->h_st.n_recs : cap;
+    if (have && !out) return SVJG_E_ARG;
+    if (have) HIPCHK(c, hipMemcpyAsync(out, c->d_recs, have * sizeof(svjg_hitrec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n = have;
+    return 0;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------------
+
+extern "C" int svjg_comm_unique_id(char *out128) {
+    if (!out128) return SVJG_E_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return SVJG_E_RCCL;
+    memcpy(out128, &id, 128);
+    return 0;
+}
+
+extern "C" int svjg_comm_init(svjg_ctx *c, const char *id128, int n_ranks, int rank) {
+    if (!c || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, id, rank);
+    if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); c->comm = nullptr; return SVJG_E_RCCL; }
+    return 0;
+}
+
+// the path's only collective: sum of the per-SV count vector (packed ref | alt << 32 as one u64 each)
+extern "C" int svjg_allreduce_counts(svjg_ctx *c) {
+    if (!c || !c->have_counts) return SVJG_E_ARG;
+    if (!c->comm) { c->err = "svjg_comm_init has not been called"; return SVJG_E_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclResult_t r = ncclAllReduce(c->d_counts, c->d_counts, c->n_slots, ncclUint64, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return SVJG_E_RCCL; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- genotypes -----------------------------------------------------------------------------------------
+
+extern "C" int svjg_genotype(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
+                             uint32_t min_support, double err, uint8_t *gt, int64_t *pl, uint32_t *raw, uint8_t *genotyped) {
+    if (!c || !c->have_counts) return SVJG_E_ARG;
+    if (n_rows == 0) return 0;
+    if (!sv_type || !slot || !ok || !gt || !pl || !raw || !genotyped) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (uint64_t r = 0; r < n_rows; ++r)
+        if (slot[r] != NONE32 && slot[r] >= c->n_slots) { c->err = "slot out of range"; return SVJG_E_ARG; }
+    // one device block: in = type[1] ok[1] slot[4] ; out = gt[1] done[1] raw[8] pl[24]
+    const uint64_t per_row = 1 + 1 + 4 + 1 + 1 + 8 + 24;
+    int rc = ensure(c, &c->d_rows, &c->rows_cap, n_rows * per_row + 256, 1, false);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)c->d_rows;
+    int64_t *d_pl = (int64_t *)base;                       base += n_rows * 24;
+    uint32_t *d_raw = (uint32_t *)base;                    base += n_rows * 8;
+    uint32_t *d_slot = (uint32_t *)base;                   base += n_rows * 4;
+    uint8_t *d_type = base;                                base += n_rows;
+    uint8_t *d_ok = base;                                  base += n_rows;
+    uint8_t *d_gt = base;                                  base += n_rows;
+    uint8_t *d_done = base;
+    HIPCHK(c, hipMemcpyAsync(d_slot, slot, n_rows * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_type, sv_type, n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_ok, ok, n_rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_maxn, 0, sizeof(unsigned int), c->stream));
+    GenoArgs a{};
+    a.counts = c->d_counts; a.sv_type = d_type; a.slot = d_slot; a.ok = d_ok; a.n_rows = n_rows; a.min_support = min_support;
+    a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
+    a.gt = d_gt; a.pl = d_pl; a.raw = d_raw; a.genotyped = d_done; a.max_n = c->d_maxn;
+    const uint32_t grid = (uint32_t)((n_rows + WG - 1) / WG);
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    hipLaunchKernelGGL(k_geno_maxn, dim3(grid), dim3(WG), 0, c->stream, a);
+    unsigned int max_n = 0;
+    HIPCHK(c, hipMemcpyAsync(&max_n, c->d_maxn, sizeof max_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (max_n + 1 > c->logfact_n) {
+        uint32_t want = max_n + 1 + 1024;
+        want = (want + LF_BLOCK - 1) / LF_BLOCK * LF_BLOCK;
+        hipFree(c->d_logfact); hipFree(c->d_bsum); c->d_logfact = nullptr; c->d_bsum = nullptr; c->logfact_n = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_logfact, (uint64_t)want * sizeof(dd)));
+        HIPCHK(c, hipMalloc((void **)&c->d_bsum, (uint64_t)(want / LF_BLOCK) * sizeof(dd)));
+        hipLaunchKernelGGL(k_logfact_local, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
+        hipLaunchKernelGGL(k_logfact_bsum, dim3(1), dim3(64), 0, c->stream, c->d_bsum, want / LF_BLOCK);
+        hipLaunchKernelGGL(k_logfact_add, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
+        HIPCHK(c, hipGetLastError());
+        c->logfact_n = want;
+    }
+    a.logfact = c->d_logfact; a.logfact_n = c->logfact_n;
+    hipLaunchKernelGGL(k_genotype, dim3(grid), dim3(WG), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(c, hipMemcpyAsync(pl, d_pl, n_rows * 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(raw, d_raw, n_rows * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(gt, d_gt, n_rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(genotyped, d_done, n_rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventElapsedTime(&c->ms_geno, c->ev[4], c->ev[5]));
+    return 0;
+}
+
+extern "C" int svjg_last_kernel_ms(svjg_ctx *c, float *m, float *s, float *g) {
+    if (!c) return SVJG_E_ARG;
+    if (m) *m = c->ms_main;
+    if (s) *s = c->ms_slow;
+    if (g) *g = c->ms_geno;
+    return 0;
+}
+
+extern "C" int svjg_sync(svjg_ctx *c) {
+    if (!c) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}

@@ -134,8 +134,8 @@ SVJG_HD bool col_skip(P t, uint32_t &p, uint32_t e) {
 // Order of work: columns 1-5, then a light scan to the end of the path column so that Tlen/Ts/Te (columns
 // 7-9) are known before the path is walked; every link's overlap test is then decided on the spot and the
 // per-lane list only ever holds final, merged entries.
-template <class P>
-SVJG_HD int fast_line(const GraphView &g, P t, uint32_t s, uint32_t e, Pending *out, uint32_t out_cap, uint32_t *n_out) {
+template <class P, class O>
+SVJG_HD int fast_line(const GraphView &g, P t, uint32_t s, uint32_t e, O out, uint32_t out_cap, uint32_t *n_out) {
     *n_out = 0;
     while (e > s && py_space(t[e - 1])) --e;
     uint32_t p = s;

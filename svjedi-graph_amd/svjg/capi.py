@@ -58,6 +58,7 @@ _SIGS = {
     "svjg_input_error": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
     "svjg_get_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
     "svjg_set_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "svjg_alloc_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32]),
     "svjg_get_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "svjg_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "svjg_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
@@ -128,8 +129,14 @@ class Context:
 
     def load_graph(self, g):
         self.graph = g
+        self.n_slots = g.n_slots
         cg = cgraph_of(g)
         self._chk(self.lib.svjg_load_graph(self.h, ctypes.byref(cg)))
+
+    def alloc_counts(self, n_slots):
+        self.graph = None
+        self.n_slots = n_slots
+        self._chk(self.lib.svjg_alloc_counts(self.h, n_slots))
 
     def upload(self, gaf):
         a = _as_u8(gaf)
@@ -151,14 +158,14 @@ class Context:
         return {"n_lines": s.n_lines, "n_deferred": s.n_deferred, "n_hitrecs": s.n_hitrecs, "non_ascii": s.non_ascii}
 
     def counts(self):
-        out = np.zeros((self.graph.n_slots, 2), dtype=np.uint32)
-        self._chk(self.lib.svjg_get_counts(self.h, out.ctypes.data, self.graph.n_slots))
+        out = np.zeros((self.n_slots, 2), dtype=np.uint32)
+        self._chk(self.lib.svjg_get_counts(self.h, out.ctypes.data, self.n_slots))
         return out
 
     def set_counts(self, c):
         c = np.ascontiguousarray(c, dtype=np.uint32)
-        assert c.shape == (self.graph.n_slots, 2)
-        self._chk(self.lib.svjg_set_counts(self.h, c.ctypes.data, self.graph.n_slots))
+        assert c.shape == (self.n_slots, 2)
+        self._chk(self.lib.svjg_set_counts(self.h, c.ctypes.data, self.n_slots))
 
     def hits(self):
         n = self.stats()["n_hitrecs"]

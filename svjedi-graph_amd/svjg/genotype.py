@@ -1,0 +1,139 @@
+"""Host side of the genotyper: VCF rows -> count slots, svjg_genotype (HIP) -> VCF text.
+
+Mirrors predict-genotype.py's decision_vcf (:89-279) for everything that is file format; the likelihood
+(:281-338) and the presence gate (:216) run on the GPU.
+"""
+import json
+
+import numpy as np
+
+NONE = 0xFFFFFFFF
+TYPE_CODE = {"DEL": 0, "INS": 1, "INV": 2, "BND": 3}
+GT_TEXT = ("0/0", "0/1", "1/1", "./.")
+
+FORMAT_HEADER = (
+    '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n'
+    '##FORMAT=<ID=DP,Number=1,Type=Float,Description="Total number of informative read alignments across all alleles (after normalization for unbalanced SVs)">\n'
+    '##FORMAT=<ID=AD,Number=2,Type=Float,Description="Number of informative read alignments supporting each allele (after normalization by breakpoint number for unbalanced SVs)">\n'
+    '##FORMAT=<ID=PL,Number=3,Type=Integer,Description="Phred-scaled likelihood for each genotype">\n'
+    "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n"
+)
+
+
+def _info(info, label):
+    """predict-genotype.py:77-87 (IndexError when the label is absent, like the reference)."""
+    fields = info.split(";")
+    if fields[0].startswith(label + "="):
+        return info.split(label + "=")[1].split(";")[0]
+    if fields[-1].startswith(label + "="):
+        return info.split(";" + label + "=")[1]
+    return info.split(";" + label + "=")[1].split(";")[0]
+
+
+def row_key(chrom, pos, alt, info, ins_seen):
+    """(svtype, sv_id, length) of one VCF row — predict-genotype.py:118-211."""
+    svtype = ""
+    if "SVTYPE" in info:
+        svtype = info.split("SVTYPE=")[1]
+        if not info.split(";")[-1].startswith("SVTYPE="):
+            svtype = svtype.split(";")[0]
+    end = _info(info, "END") if svtype not in ("BND", "INS") else None
+    if svtype in ("DEL", "INV"):
+        return svtype, "%s:%s-%s-%s" % (chrom, svtype, pos, end), int(end) - int(pos)
+    if svtype == "INS":
+        n = ins_seen[pos] = ins_seen.get(pos, 0) + 1        # keyed by POS only, shared by all chromosomes
+        return svtype, "%s:INS-%s-%d" % (chrom, pos, n), len(alt)
+    if svtype == "BND":
+        for br in ("[", "]"):
+            if br in alt:
+                parts = [x for x in alt.split(br) if x]
+                if ":" in parts[1]:
+                    return svtype, "%s:BND-%s%s%s%s" % (chrom, pos, br, parts[1], br), 50
+                return svtype, "%s:BND-%s%s%s%s" % (chrom, br, parts[0], br, pos), 50
+        return svtype, "wrong_format", 50
+    return svtype, "unsupported_type", 0
+
+
+class VcfRows:
+    """Input VCF split into header output lines and data rows with their count slot."""
+
+    def __init__(self, vcf_path, slot_of, slot_is_presence=False):
+        self.items = []          # ("h", text) or ("r", row index)
+        self.prefix = []         # text before "\tGT:DP:AD:PL" for each data row
+        types, slots, oks = [], [], []
+        ins_seen = {}
+        with open(vcf_path) as fh:
+            for line in fh:
+                if line.startswith("##FORMAT"):
+                    continue
+                if line.startswith("##"):
+                    self.items.append(("h", line))
+                    continue
+                if line.startswith("#C"):
+                    self.items.append(("h", FORMAT_HEADER))
+                    continue
+                chrom, pos, _id, _ref, alt, _q, _f, info, *_rest = line.rstrip("\n").split("\t")
+                svtype, key, length = row_key(chrom, pos, alt, info, ins_seen)
+                code = TYPE_CODE.get(svtype)
+                types.append(code if code is not None else 0)
+                oks.append((3 if slot_is_presence else 1) if (code is not None and abs(length) >= 50) else 0)
+                slots.append(slot_of.get(key, NONE))
+                raw = line.split("\t")
+                self.prefix.append(line.rstrip("\n") if len(raw) <= 8 else "\t".join(raw[:8]))
+                self.items.append(("r", len(types) - 1))
+        self.sv_type = np.array(types, dtype=np.uint8)
+        self.slot = np.array(slots, dtype=np.uint32)
+        self.ok = np.array(oks, dtype=np.uint8)
+
+
+def _fmt_counts(svtype_code, ref, alt):
+    """AD and DP text after the in-place normalisation of predict-genotype.py:327-338 (Python formatting)."""
+    c = [ref, alt]
+    if svtype_code == 0 and ref > 0:
+        c[0] = round(ref / 2, 1)
+    elif svtype_code == 1 and alt > 0:
+        c[1] = round(alt / 2, 1)
+    return str(round(sum(c), 3)), "%s,%s" % (c[0], c[1])
+
+
+def write_vcf(out_path, rows, gt, pl, raw, done):
+    n_done = 0
+    with open(out_path, "w") as out:
+        for kind, v in rows.items:
+            if kind == "h":
+                out.write(v)
+                continue
+            if done[v]:
+                n_done += 1
+                dp, ad = _fmt_counts(int(rows.sv_type[v]), int(raw[v, 0]), int(raw[v, 1]))
+                tail = "%s:%s:%s:%d,%d,%d" % (GT_TEXT[gt[v]], dp, ad, pl[v, 0], pl[v, 1], pl[v, 2])
+            else:
+                tail = "./.:0:0,0:.,.,."
+            out.write(rows.prefix[v] + "\tGT:DP:AD:PL\t" + tail + "\n")
+    return n_done
+
+
+def genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support=3, err=0.00005, slot_is_presence=False):
+    """Counts already live in the context (fused path, or set_counts): parse, run the kernel, write."""
+    rows = VcfRows(vcf_path, slot_of, slot_is_presence)
+    gt, pl, raw, done = ctx.genotype(rows.sv_type, rows.slot, rows.ok, min_support, err)
+    return write_vcf(out_path, rows, gt, pl, raw, done)
+
+
+def run(json_path, vcf_path, out_path, min_support=3, err=0.00005, device=0):
+    """predict-genotype.py main(): counts come from the informative-alignment JSON."""
+    from . import capi
+    with open(json_path, "r") as fh:
+        d = json.load(fh)
+    keys = list(d)
+    slot_of = {k: i for i, k in enumerate(keys)}
+    counts = np.array([[len(d[k][0]), len(d[k][1])] for k in keys], dtype=np.uint32).reshape(len(keys), 2)
+    ctx = capi.Context(device)
+    try:
+        ctx.alloc_counts(len(keys))
+        ctx.set_counts(counts)
+        n = genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support, err, slot_is_presence=True)
+    finally:
+        ctx.close()
+    print("Genotyped svs: " + str(n))
+    return n

@@ -1,0 +1,233 @@
+"""Parity of the HIP path (through the C ABI, svjedi-graph_amd/svjg/capi.py) with the reference:
+golden vectors produced by the reference itself, and the CPU oracle on seeded synthetic inputs.
+Bit-exact for counts, genotypes, PL integers and output files.  Needs an MI355X: run with -m gpu."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_c as OC      # noqa: E402
+from oracle import oracle_py as O      # noqa: E402
+
+QUIRKS = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "quirks"))
+                if f.endswith(".gaf"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from svjg import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _counts_dict(graph, counts):
+    return {graph.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(graph.n_slots) if counts[i].sum()}
+
+
+@pytest.mark.parametrize("all_slow", [False, True])
+@pytest.mark.parametrize("name", QUIRKS)
+def test_quirks(ctx, golden, name, all_slow):
+    from svjg import filter as flt
+    from svjg.graph import Graph
+    q = f"{golden}/quirks"
+    man = json.load(open(f"{q}/manifest.json"))[name]
+    g = Graph.from_files(f"{q}/q_svs_edges.json", f"{q}/q.gfa", all_slow=all_slow)
+    if man["rc"] == 0:
+        counts, recs, data = flt.classify_file(ctx, g, f"{q}/{name}.gaf")
+        ref_text = open(f"{q}/{name}.ref.json").read()
+        ref = json.loads(ref_text)
+        assert _counts_dict(g, counts) == {k: [len(v[0]), len(v[1])] for k, v in ref.items()}
+        got = json.dumps(flt.informative_dict(g, recs, data.tobytes()), sort_keys=True, indent=4)
+        assert got == ref_text
+    else:
+        with pytest.raises(Exception) as ei:
+            flt.classify_file(ctx, g, f"{q}/{name}.gaf")
+        assert type(ei.value).__name__ == man["error"]
+
+
+def test_testdir_files(ctx, golden, tmp_path):
+    """BASELINE configs[0] plumbing: the reference's own test graph, a GAF whose counts reproduce the 40
+    expected rows, through the drop-in filter + genotyper: both output files byte-identical."""
+    import shutil
+    import subprocess
+    import sys
+    t = f"{golden}/testdir"
+    for f in ("test.gaf", "test.gfa", "test_svs_edges.json", "test.vcf"):
+        shutil.copy(f"{t}/{f}", tmp_path / f)
+    amd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svjedi-graph_amd")
+    pre = str(tmp_path / "test")
+    p = subprocess.run([sys.executable, f"{amd}/filter-alignments.py", "-a", pre + ".gaf", "-g", pre + ".gfa", "-p", pre],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(pre + "_informative_aln.json").read() == open(f"{t}/ref_informative_aln.json").read()
+    p = subprocess.run([sys.executable, f"{amd}/predict-genotype.py", "-d", pre + "_informative_aln.json", "-v", pre + ".vcf",
+                        "--minsupport", "3", "-o", pre + "_genotype.vcf"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == open(f"{t}/ref_stdout.txt").read()
+    assert open(pre + "_genotype.vcf").read() == open(f"{t}/ref_genotype.vcf").read()
+    exp = [l for l in open(f"{t}/expected_genotype.vcf") if not l.startswith("#")]
+    assert [l for l in open(pre + "_genotype.vcf") if not l.startswith("#")] == exp
+
+
+def test_cli_error_exit_code(golden, tmp_path):
+    import shutil
+    import subprocess
+    import sys
+    q = f"{golden}/quirks"
+    shutil.copy(f"{q}/q_svs_edges.json", tmp_path / "q_svs_edges.json")
+    amd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svjedi-graph_amd")
+    p = subprocess.run([sys.executable, f"{amd}/filter-alignments.py", "-a", f"{q}/err_nonint.gaf", "-g", f"{q}/q.gfa",
+                        "-p", str(tmp_path / "q")], capture_output=True, text=True)
+    assert p.returncode == 1 and "ValueError" in p.stderr
+    assert not os.path.exists(tmp_path / "q_informative_aln.json")
+
+
+@pytest.mark.parametrize("tag", ["g6_mixed", "g6_del"])
+def test_synth_g6(ctx, golden, tag, tmp_path):
+    import synth
+    from svjg import filter as flt, genotype
+    from svjg.graph import Graph
+    g6 = json.load(open(f"{golden}/synth/g6.json"))[tag]
+    pre = str(tmp_path / "s")
+    synth.generate(prefix=pre, **g6["args"])
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    counts, recs, data = flt.classify_file(ctx, g, pre + ".gaf")
+    assert _counts_dict(g, counts) == g6["counts"]
+    st = ctx.stats()
+    assert st["n_lines"] == g6["args"]["n_aln"]
+    assert 0 < st["n_deferred"] < st["n_lines"] // 100
+    js = json.dumps(flt.informative_dict(g, recs, data.tobytes()), sort_keys=True, indent=4)
+    assert hashlib.sha256(js.encode()).hexdigest() == g6["sha256_json"]
+    n = genotype.genotype_with_counts(ctx, pre + ".vcf", g.slot_of, pre + "_genotype.vcf")
+    assert f"Genotyped svs: {n}\n" == g6["stdout"]
+    assert open(pre + "_genotype.vcf").read() == open(f"{golden}/synth/{tag}.ref_genotype.vcf").read()
+
+
+def test_likelihood_known_answers(ctx, golden):
+    """All known answers of the reference's likelihood(): GT and the three PL integers, exactly."""
+    z = np.load(f"{golden}/lik/lik_kat.npz")
+    cases, errs = z["cases"], z["err"]
+    for ms in np.unique(cases[:, 3]):
+        for e in np.unique(errs):
+            sel = np.where((cases[:, 3] == ms) & (errs == e))[0]
+            if len(sel) == 0:
+                continue
+            c = cases[sel]
+            ctx.alloc_counts(len(sel))
+            ctx.set_counts(c[:, 1:3].astype(np.uint32))
+            gt, pl, raw, done = ctx.genotype(c[:, 0].astype(np.uint8), np.arange(len(sel), dtype=np.uint32),
+                                             np.full(len(sel), 3, dtype=np.uint8), int(ms), float(e))
+            assert done.all()
+            assert np.array_equal(raw, c[:, 1:3].astype(np.uint32))
+            bad = np.where((gt != c[:, 4]) | (pl != c[:, 5:8]).any(axis=1))[0]
+            assert len(bad) == 0, (c[bad[:5]], gt[bad[:5]], pl[bad[:5]])
+
+
+@pytest.mark.parametrize("tag,ms,err", [("ms3", 3, None), ("ms1", 1, None), ("ms0", 0, None), ("ms3_e1e-3", 3, 0.001)])
+def test_vcf_cases(golden, tmp_path, tag, ms, err):
+    import subprocess
+    import sys
+    v = f"{golden}/vcf"
+    amd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svjedi-graph_amd")
+    cmd = [sys.executable, f"{amd}/predict-genotype.py", "-d", f"{v}/cases_informative_aln.json", "-v", f"{v}/cases.vcf",
+           "-o", str(tmp_path / "o.vcf"), "-ms", str(ms)]
+    if err is not None:
+        cmd += ["-e", str(err)]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(tmp_path / "o.vcf").read() == open(f"{v}/ref_{tag}.vcf").read()
+    assert p.stdout == open(f"{v}/ref_{tag}.stdout").read()
+
+
+def test_vcf_crash_exit_code(golden, tmp_path):
+    import subprocess
+    import sys
+    v = f"{golden}/vcf"
+    amd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svjedi-graph_amd")
+    p = subprocess.run([sys.executable, f"{amd}/predict-genotype.py", "-d", f"{v}/cases_informative_aln.json",
+                        "-v", f"{v}/err_no_end.vcf", "-o", str(tmp_path / "o.vcf")], capture_output=True, text=True)
+    assert p.returncode == 1 and "IndexError" in p.stderr
+
+
+def _synth_case(tmp_path, n_aln, n_sv, n_chrom, mix, seed):
+    import synth
+    from svjg.graph import Graph
+    pre = str(tmp_path / "c")
+    inf = synth.generate(pre, n_aln, n_sv, n_chrom, mix, seed, write_gaf=False, return_gaf=True)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    return pre, inf["gaf"], g, orc
+
+
+def _oracle_dict(orc, c):
+    return {sv: [int(c[i, 0]), int(c[i, 1])] for i, sv in enumerate(orc.sv_ids) if c[i].sum()}
+
+
+def test_stripe_boundaries_and_terminators(ctx, tmp_path):
+    """Lines straddling the 44 KB stripes at every phase, CRLF / lone CR terminators, an over-long line
+    (exact path), no final newline: counts equal the oracle's."""
+    pre, gaf, g, orc = _synth_case(tmp_path, 6000, 300, 2, "mixed", 99)
+    raw = gaf.tobytes()
+    lines = raw.split(b"\n")[:-1]
+    long_line = lines[5].replace(b"read5\t", b"read5" + b"x" * 6000 + b"\t")
+    variants = {
+        "plain": raw,
+        "crlf": b"\r\n".join(lines) + b"\r\n",
+        "lone_cr": b"\r".join(lines) + b"\r",
+        "mixed_terms": b"".join(l + (b"\n", b"\r\n", b"\r")[i % 3] for i, l in enumerate(lines)),
+        "no_final_newline": raw[:-1],
+        "long_line": b"\n".join(lines[:5] + [long_line] + lines[6:]) + b"\n",
+        "shifted": b"\n".join(lines[3:]) + b"\n",
+    }
+    for name, data in variants.items():
+        want, _, n_lines = orc.filter(data, want_hits=False)
+        ctx.load_graph(g)
+        ctx.classify(np.frombuffer(data, dtype=np.uint8))
+        assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want), name
+        assert ctx.stats()["n_lines"] == n_lines, name
+
+
+def test_empty_and_tiny_inputs(ctx, tmp_path):
+    pre, gaf, g, orc = _synth_case(tmp_path, 10, 50, 1, "del", 5)
+    ctx.load_graph(g)
+    ctx.classify(np.zeros(0, dtype=np.uint8))
+    assert ctx.counts().sum() == 0 and ctx.stats()["n_lines"] == 0
+    one = gaf.tobytes().split(b"\n")[0] + b"\n"
+    ctx.classify(np.frombuffer(one, dtype=np.uint8))
+    want, _, _ = orc.filter(one, want_hits=False)
+    assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
+
+
+def test_c2_full_size(ctx, tmp_path):
+    """BASELINE configs[1] at full size (1 M alignments x 10 k DEL): counts equal the C oracle's, the two
+    halves of the file add up to the whole (what the multi-GPU all-reduce relies on), genotypes equal the
+    Python oracle's on a sample of rows."""
+    import synth
+    n_aln, n_sv, n_chrom, mix, seed = synth.CONFIGS["c2"]
+    pre, gaf, g, orc = _synth_case(tmp_path, n_aln, n_sv, n_chrom, mix, seed)
+    want, _, n_lines = orc.filter(gaf, want_hits=False)
+    assert n_lines == n_aln
+    ctx.load_graph(g)
+    ctx.upload(gaf)
+    ctx.classify_resident()
+    whole = ctx.counts()
+    assert _counts_dict(g, whole) == _oracle_dict(orc, want)
+    cut = int(np.where(gaf[: gaf.size // 2] == 10)[0][-1]) + 1
+    ctx.reset_counts()
+    ctx.classify(gaf[:cut])
+    ctx.classify(gaf[cut:])
+    assert np.array_equal(ctx.counts(), whole)
+    # genotypes
+    from svjg import genotype
+    ctx.set_counts(whole)
+    n = genotype.genotype_with_counts(ctx, pre + ".vcf", g.slot_of, pre + "_genotype.vcf")
+    D = {sv: [["x"] * a, ["y"] * b] for sv, (a, b) in _counts_dict(g, whole).items()}
+    head = [l for l in open(pre + ".vcf")]
+    text, n_ref = O.genotype_vcf(head[:2000], D)
+    assert open(pre + "_genotype.vcf").read().startswith(text)
+    assert n >= n_ref
