@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -22,7 +23,7 @@ struct svjg_ctx {
     // graph
     bool have_graph = false, have_counts = false;
     svjg_node *d_nodes = nullptr;  svjg_edge *d_edges = nullptr;  uint32_t *d_hits = nullptr;
-    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr;
+    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr, *d_bbase = nullptr, *d_bkt = nullptr, *d_w4 = nullptr, *d_wtab = nullptr;
     GraphView gv{};
     uint32_t names_len = 0, dict_bytes = 0, dict_in_lds = 0, gflags = 0, n_slots = 0;
     unsigned long long *d_counts = nullptr, *d_snap = nullptr;
@@ -32,6 +33,7 @@ struct svjg_ctx {
     uint64_t *d_deferred = nullptr;  uint64_t deferred_cap = 0;
     svjg_hitrec *d_recs = nullptr;   uint64_t rec_cap = 0;
     DevStatus *d_st = nullptr;
+    unsigned long long *d_dbg = nullptr;
     DevStatus h_st{};
     uint64_t total_deferred = 0;
     // genotype scratch
@@ -83,7 +85,7 @@ extern "C" int svjg_init(int device, svjg_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     for (auto &ev : c->ev) hipEventCreate(&ev);
-    if (hipMalloc(&c->d_st, sizeof(DevStatus)) != hipSuccess || hipMalloc(&c->d_maxn, sizeof(unsigned int)) != hipSuccess) {
+    if (hipMalloc(&c->d_dbg, 16 * 8) != hipSuccess || hipMalloc(&c->d_st, sizeof(DevStatus)) != hipSuccess || hipMalloc(&c->d_maxn, sizeof(unsigned int)) != hipSuccess) {
         g_init_error = "hipMalloc failed";
         delete c;
         return SVJG_E_NOMEM;
@@ -95,7 +97,8 @@ extern "C" int svjg_init(int device, svjg_ctx **out) {
 
 static void free_graph(svjg_ctx *c) {
     hipFree(c->d_nodes); hipFree(c->d_edges); hipFree(c->d_hits); hipFree(c->d_cnames); hipFree(c->d_coff);
-    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap);
+    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap); hipFree(c->d_bbase); hipFree(c->d_bkt); hipFree(c->d_w4); hipFree(c->d_wtab);
+    c->d_bbase = nullptr; c->d_bkt = nullptr; c->d_w4 = nullptr; c->d_wtab = nullptr;
     c->d_nodes = nullptr; c->d_edges = nullptr; c->d_hits = nullptr; c->d_cnames = nullptr; c->d_coff = nullptr;
     c->d_clo = nullptr; c->d_chash = nullptr; c->d_counts = nullptr; c->d_snap = nullptr;
     c->have_graph = false; c->have_counts = false;
@@ -146,11 +149,19 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     if ((rc = upload(c, &c->d_clo, g->chrom_node_lo, g->n_chrom + 1))) return rc;
     std::vector<uint32_t> hash = build_chrom_hash(*g);
     if ((rc = upload(c, &c->d_chash, hash.data(), hash.size()))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));           // `hash` is a local
+    BucketTable bt = build_buckets(*g);
+    if ((rc = upload(c, &c->d_bbase, bt.base.data(), bt.base.size()))) return rc;
+    if ((rc = upload(c, &c->d_bkt, bt.table.data(), bt.table.size()))) return rc;
+    ChromWords cw = build_chrom_words(*g);
+    if ((rc = upload(c, &c->d_w4, cw.w4.data(), cw.w4.size()))) return rc;
+    if ((rc = upload(c, &c->d_wtab, cw.table.data(), cw.table.size()))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // `hash`, `bt`, `cw` are locals
+    c->gv.chrom_w4 = c->d_w4; c->gv.chrom_wtab = c->d_wtab; c->gv.wtab_mask = (uint32_t)cw.table.size() - 1;
+    c->gv.bkt_base = c->d_bbase; c->gv.bkt = c->d_bkt; c->gv.bkt_shift = bt.shift;
     c->gv.nodes = c->d_nodes; c->gv.n_nodes = (uint32_t)g->n_nodes; c->gv.edges = c->d_edges; c->gv.hits = c->d_hits;
     c->gv.chrom_names = c->d_cnames; c->gv.chrom_off = c->d_coff; c->gv.chrom_lo = c->d_clo; c->gv.chrom_hash = c->d_chash;
     c->gv.n_chrom = g->n_chrom; c->gv.hash_mask = (uint32_t)hash.size() - 1; c->gv.d_over = g->d_over;
-    c->dict_bytes = ((c->names_len + 3) & ~3u) + 4 * (2 * (g->n_chrom + 1) + (uint32_t)hash.size());
+    c->dict_bytes = 4 * (2 * (g->n_chrom + 1) + 4 * g->n_chrom + (uint32_t)cw.table.size());   // off | bkt_base | w4 | wtab
     c->dict_in_lds = c->dict_bytes <= DICT_LDS_MAX;
     c->gflags = g->flags;
     c->n_slots = g->n_slots;
@@ -230,10 +241,12 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         a.gaf = c->d_gaf; a.n_bytes = n; a.base_offset = base_offset; a.g = c->gv;
         a.dict_names_len = c->names_len; a.dict_in_lds = c->dict_in_lds; a.all_slow = all_slow; a.want_hits = want_hits != 0;
         a.n_chunks = (uint32_t)((n + CHUNK - 1) / CHUNK);
+        { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob for profiling only
         a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
-        a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st;
-        size_t lds = TEXT + 16 + ((MAXSTARTS + 8) * 2 + 15) / 16 * 16 + HMAX * WG * sizeof(Pending) + 64 + (c->dict_in_lds ? c->dict_bytes : 0);
+        a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
+        size_t lds = LDS_MAIN + (c->dict_in_lds ? c->dict_bytes : 0);
         uint32_t grid = a.n_chunks < (uint32_t)c->n_cu * 2 ? a.n_chunks : (uint32_t)c->n_cu * 2;
+        if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
         HIPCHK(c, hipGetLastError());
@@ -241,10 +254,15 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         uint64_t n_def = c->h_st.n_deferred;
+        if (a.diag & 16u) {
+            unsigned long long d[8];
+            HIPCHK(c, hipMemcpy(d, c->d_dbg, sizeof d, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[svjg diag] workgroup cycles  A %llu  B %llu  R1 %llu  R2 %llu  R3 %llu  R4 %llu  R5 %llu  R6 %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        }
         c->ms_slow = 0;
         if (n_def && !(c->h_st.overflow & 1u)) {
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-            hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)((n_def + WG - 1) / WG)), dim3(WG), 0, c->stream, a, n_def);
+            hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)((n_def + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, a, n_def);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
             HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
@@ -377,9 +395,9 @@ extern "C" int svjg_genotype(svjg_ctx *c, const uint8_t *sv_type, const uint32_t
     a.counts = c->d_counts; a.sv_type = d_type; a.slot = d_slot; a.ok = d_ok; a.n_rows = n_rows; a.min_support = min_support;
     a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
     a.gt = d_gt; a.pl = d_pl; a.raw = d_raw; a.genotyped = d_done; a.max_n = c->d_maxn;
-    const uint32_t grid = (uint32_t)((n_rows + WG - 1) / WG);
+    const uint32_t grid = (uint32_t)((n_rows + TPB - 1) / TPB);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    hipLaunchKernelGGL(k_geno_maxn, dim3(grid), dim3(WG), 0, c->stream, a);
+    hipLaunchKernelGGL(k_geno_maxn, dim3(grid), dim3(TPB), 0, c->stream, a);
     unsigned int max_n = 0;
     HIPCHK(c, hipMemcpyAsync(&max_n, c->d_maxn, sizeof max_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -396,7 +414,7 @@ extern "C" int svjg_genotype(svjg_ctx *c, const uint8_t *sv_type, const uint32_t
         c->logfact_n = want;
     }
     a.logfact = c->d_logfact; a.logfact_n = c->logfact_n;
-    hipLaunchKernelGGL(k_genotype, dim3(grid), dim3(WG), 0, c->stream, a);
+    hipLaunchKernelGGL(k_genotype, dim3(grid), dim3(TPB), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     HIPCHK(c, hipMemcpyAsync(pl, d_pl, n_rows * 24, hipMemcpyDeviceToHost, c->stream));

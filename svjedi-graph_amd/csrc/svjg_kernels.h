@@ -18,15 +18,39 @@
 
 namespace svjg {
 
-constexpr uint32_t WG = 256;
-constexpr uint32_t CHUNK = 44 * 1024;            // bytes of text owned by one workgroup iteration
-constexpr uint32_t LOOK = 4 * 1024;              // look-ahead so that lines starting in the chunk are complete
-constexpr uint32_t TEXT = CHUNK + LOOK;          // 48 KB staged in LDS
-constexpr uint32_t SPAN = TEXT / WG;             // 192 B of terminator scan per lane
-constexpr uint32_t PIECES = SPAN / 16;           // 12
+constexpr uint32_t WG = 192;                     // classify kernel: 3 waves; two workgroups per CU (LDS-bound)
+constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
+constexpr uint32_t PIECES = 13;                  // 16-byte pieces of text per lane and stripe
+constexpr uint32_t SPAN = PIECES * 16;           // 208 B of byte classification per lane
+constexpr uint32_t TEXT = SPAN * WG;             // 39 KB staged in LDS
+constexpr uint32_t LOOK = 4 * 1024;              // look-ahead so that lines starting in the stripe are complete
+constexpr uint32_t CHUNK = TEXT - LOOK;          // bytes of text owned by one workgroup iteration (a "stripe")
 constexpr uint32_t MAXSTARTS = TEXT / 24 + 8;    // a valid line has >= 24 bytes incl. its terminator
-constexpr uint32_t HMAX = 12;                    // informative SVs per alignment kept by the fast path
-constexpr uint32_t DICT_LDS_MAX = 8 * 1024;      // chromosome dictionary is copied to LDS when it fits
+constexpr uint32_t KMAX = 16;                    // path nodes per alignment handled by the main kernel
+constexpr uint32_t NMAX = 1280;                  // path nodes per round of WG lines
+constexpr uint32_t DICT_LDS_MAX = 1024;          // chromosome dictionary is copied to LDS when it fits
+
+// LDS carve-up of k_classify_main (bytes)
+constexpr uint32_t L_TEXT = 0;
+constexpr uint32_t L_TABBM = L_TEXT + TEXT + 16;                           // u16[TEXT/16] one bit per byte: '\t'
+constexpr uint32_t L_ORIBM = L_TABBM + TEXT / 8;                           // u16[TEXT/16] one bit per byte: '<' or '>'
+constexpr uint32_t L_STARTS = L_ORIBM + TEXT / 8 + 16;                     // u16[MAXSTARTS + 8]
+constexpr uint32_t L_TS = (L_STARTS + (MAXSTARTS + 8) * 2 + 15) / 16 * 16; // u32[WG]  path start column
+constexpr uint32_t L_TE = L_TS + WG * 4;                                   // u32[WG]
+constexpr uint32_t L_TLEN = L_TE + WG * 4;                                 // u32[WG]
+constexpr uint32_t L_TOT = L_TLEN + WG * 4;                                // u32[WG]  sum of node lengths
+constexpr uint32_t L_META = L_TOT + WG * 4;                                // u32[WG]  nbase | k << 16 | status << 24
+constexpr uint32_t L_LSTART = L_META + WG * 4;                             // u16[WG]  line start
+constexpr uint32_t L_PBEG = L_LSTART + WG * 2;                             // u16[WG]  tab before the path column
+constexpr uint32_t L_PEND = L_PBEG + WG * 2;                               // u16[WG]  tab after the path column
+constexpr uint32_t L_NPOS = L_PEND + WG * 2;                               // u16[NMAX]  name start (orientation mark + 1)
+constexpr uint32_t L_NLINE = L_NPOS + NMAX * 2;                            // u16[NMAX]  line in round | orientation << 15
+constexpr uint32_t L_NFIRST = L_NLINE + NMAX * 2;                          // u16[NMAX]  first node of the line with the same name
+constexpr uint32_t L_NID = L_NFIRST + NMAX * 2;                            // u32[NMAX]
+constexpr uint32_t L_NPRE = L_NID + NMAX * 4;                              // u32[NMAX]  length, then inclusive prefix
+constexpr uint32_t L_MISC = L_NPRE + NMAX * 4;                             // u32[16]
+constexpr uint32_t L_DICT = L_MISC + 64;
+constexpr uint32_t LDS_MAIN = L_DICT;                                      // + dictionary bytes when staged
 
 // status words (device)
 struct DevStatus {
@@ -48,21 +72,21 @@ struct ClassifyArgs {
     uint32_t all_slow;
     uint32_t want_hits;
     uint32_t n_chunks;
+    uint32_t diag;                       // measurement only (SVJG_DIAG): 1 stop after B, 2 stop after R2, 4 no node lookup, 8 no atomics
     unsigned long long *counts;          // [n_slots] ref | alt << 32
     uint64_t *deferred;  uint64_t deferred_cap;
     svjg_hitrec *recs;   uint64_t rec_cap;
     DevStatus *st;
+    unsigned long long *dbg;             // measurement only (SVJG_DIAG & 16): per-phase cycle sums of lane 0 of every workgroup
 };
 
-struct LaneList {                        // per-lane list laid out [entry][lane]: conflict-free ds_write_b64
-    Pending *base;
-    __device__ Pending &operator[](uint32_t j) const { return base[j * WG]; }
-};
-
-__device__ inline uint32_t eq_mask4(uint32_t x, uint32_t pat) {        // 4-bit mask of bytes equal to pat's byte
-    uint32_t t = x ^ pat;
-    uint32_t m = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);   // 0x80 where the byte is zero
-    return (((m >> 7) * 0x00204081u) >> 21) & 0xFu;
+__device__ inline uint32_t zero_bytes(uint32_t t) {                    // 0x80 in every byte of t that is zero (exact)
+    return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+}
+__device__ inline uint32_t movemask4(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
+__device__ inline uint32_t eq_mask16(uint4 v, uint32_t pat) {          // 16-bit mask of bytes equal to pat's byte
+    return movemask4(zero_bytes(v.x ^ pat)) | (movemask4(zero_bytes(v.y ^ pat)) << 4) |
+           (movemask4(zero_bytes(v.z ^ pat)) << 8) | (movemask4(zero_bytes(v.w ^ pat)) << 12);
 }
 
 __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
@@ -77,72 +101,214 @@ __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
     return x - v;
 }
 
-__global__ __launch_bounds__(WG) void k_classify_main(ClassifyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *text = lds;                                               // TEXT + 16
-    uint16_t *starts = (uint16_t *)(lds + TEXT + 16);                  // MAXSTARTS + 8 (u16)
-    Pending *lists = (Pending *)(lds + TEXT + 16 + ((MAXSTARTS + 8) * 2 + 15) / 16 * 16);   // HMAX * WG
-    uint32_t *misc = (uint32_t *)((uint8_t *)lists + HMAX * WG * sizeof(Pending));           // 16 words
-    uint8_t *dict = (uint8_t *)(misc + 16);
+// block-wide exclusive scan; `slot` = WG/64 words of LDS; two barriers inside
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *slot, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t wtot, ex = wave_excl_scan(v, wtot);
+    __syncthreads();
+    if (lane == 63) slot[wave] = wtot;
+    __syncthreads();
+    uint32_t base = 0; total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < WG / 64; ++w) { uint32_t x = slot[w]; if (w < wave) base += x; total += x; }
+    return base + ex;
+}
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round
+
+// plain decimal column text[a, b): 1..9 digits and nothing else -> value.  Straight-line SWAR: three aligned
+// LDS words, digits checked and folded pairwise (no per-digit loop, no divergence).
+__device__ inline bool field_dec(const uint8_t *text, uint32_t a, uint32_t b, uint32_t &v) {
+    const uint32_t n = b - a;
+    const uint32_t *w = (const uint32_t *)(text + (a & ~3u));
+    const uint32_t sh = a & 3u, d0 = w[0], d1 = w[1], d2 = w[2];
+    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh) ^ 0x30303030u;    // chars a .. a+3 as digits
+    uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh) ^ 0x30303030u;    // chars a+4 .. a+7
+    const uint32_t n8 = n < 8 ? n : 8;
+    // keep the first n8 bytes, then shift them to the top of the 64-bit (hi:lo) so that leading bytes are zero digits
+    const uint32_t klo = n8 >= 4 ? 0xFFFFFFFFu : ((1u << ((8 * n8) & 31u)) - 1u);
+    const uint32_t khi = n8 >= 8 ? 0xFFFFFFFFu : (n8 > 4 ? ((1u << ((8 * (n8 - 4)) & 31u)) - 1u) : 0u);
+    lo &= klo; hi &= khi;
+    bool ok = (((lo + 0x76767676u) | lo | (hi + 0x76767676u) | hi) & 0x80808080u) == 0;     // every kept byte is 0..9
+    const unsigned long long x = (((unsigned long long)hi << 32) | lo) << ((8 * (8 - n8)) & 63u);
+    lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
+    uint32_t pl = (lo * 10u + (lo >> 8)) & 0x00FF00FFu, ph = (hi * 10u + (hi >> 8)) & 0x00FF00FFu;
+    uint32_t r = ((pl & 0xFFu) * 100u + (pl >> 16)) * 10000u + (ph & 0xFFu) * 100u + (ph >> 16);
+    if (n == 9) { uint32_t d = (uint32_t)text[a + 8] - '0'; ok &= d <= 9; r = r * 10u + d; }
+    v = r;
+    return ok & (n - 1u <= 8u);
+}
+
+// next set bit of a bitmap, scanning upwards from the cursor (word index wi, remaining bits `cur`); `lim` = end position
+struct BitCursor {
+    const uint32_t *bm; uint32_t wi, cur, lim;
+    __device__ uint32_t next() {                                         // position of the next set bit, or lim
+        while (cur == 0) { ++wi; if ((wi << 5) >= lim) return lim; cur = bm[wi]; }
+        uint32_t b = __builtin_ctz(cur); cur &= cur - 1;
+        uint32_t p = (wi << 5) + b;
+        return p < lim ? p : lim;
+    }
+};
+
+// Node name text[a0, a0+L) = chrom ':' A ('-' | '.') B with canonical decimals and a chromosome of the dictionary
+// -> (cidx, A, B, kind).  Straight-line: the 32 name bytes are classified digit / non-digit with SWAR, the two
+// separators are the two highest non-digits, A and B go through field_dec, the chromosome is matched as four words.
+__device__ inline bool parse_name(const GraphView &g, const uint8_t *text, uint32_t a0, uint32_t L,
+                                  uint32_t &cidx, uint32_t &v1, uint32_t &v2, uint32_t &kind) {
+    const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
+    const uint32_t sh = a0 & 3u;
+    uint32_t d[8], M = 0;
+    uint32_t prev = w[0];
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        const uint32_t nx = w[i + 1];
+        d[i] = __builtin_amdgcn_alignbyte(nx, prev, sh);
+        prev = nx;
+        const uint32_t t = d[i] ^ 0x30303030u;
+        M |= movemask4(((t + 0x76767676u) | t) & 0x80808080u) << (4 * i);      // bit = byte is not a digit
+    }
+    bool ok = L - 3u <= 29u;                                                     // 3 <= L <= 32
+    const uint32_t Mv = M & (L >= 32 ? 0xFFFFFFFFu : ((1u << (L & 31u)) - 1u));
+    ok &= Mv != 0;
+    const uint32_t ps = 31u - (uint32_t)__builtin_clz(Mv | 1u);                  // B's separator: highest non-digit
+    const uint32_t Mc = Mv & ((1u << ps) - 1u);
+    ok &= Mc != 0;
+    const uint32_t pc = 31u - (uint32_t)__builtin_clz(Mc | 1u);                  // the ':' before A
+    const uint32_t sepc = text[a0 + ps], colc = text[a0 + pc];
+    kind = sepc == '.';
+    ok &= (sepc == '-' || sepc == '.') && colc == ':';
+    const uint32_t nd1 = ps - pc - 1u, nd2 = L - ps - 1u;
+    ok &= field_dec(text, a0 + pc + 1, a0 + ps, v1) & field_dec(text, a0 + ps + 1, a0 + L, v2);
+    // canonical spelling (no leading zeros): an n-digit number is >= 10^(n-1)
+    const uint32_t p10a = nd1 > 1 ? (nd1 == 2 ? 10u : nd1 == 3 ? 100u : nd1 == 4 ? 1000u : nd1 == 5 ? 10000u : nd1 == 6 ? 100000u : nd1 == 7 ? 1000000u : nd1 == 8 ? 10000000u : 100000000u) : 0u;
+    const uint32_t p10b = nd2 > 1 ? (nd2 == 2 ? 10u : nd2 == 3 ? 100u : nd2 == 4 ? 1000u : nd2 == 5 ? 10000u : nd2 == 6 ? 100000u : nd2 == 7 ? 1000000u : nd2 == 8 ? 10000000u : 100000000u) : 0u;
+    ok &= v1 >= p10a && v2 >= p10b;
+    const uint32_t clen = pc;
+    ok &= clen - 1u <= 15u;                                                      // 1..16 bytes (longer names: exact path)
+    uint32_t c[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint32_t nb = clen > 4 * i ? clen - 4 * i : 0u;
+        c[i] = d[i] & (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
+    }
+    cidx = NONE32;
+    if (ok) cidx = chrom_lookup_words(g, c[0], c[1], c[2], c[3], clen);
+    return ok && cidx != NONE32 && !(kind && v2 >= 32768);
+}
+
+#ifndef SVJG_UBN
+#define SVJG_UBN 3
+#endif
+#ifndef SVJG_UBL
+#define SVJG_UBL 2
+#endif
+constexpr uint32_t UB = SVJG_UBN;                // path nodes handled per lane at a time (independent loads in flight)
+constexpr uint32_t UL = SVJG_UBL;                // path steps handled per lane at a time
+
+// The classify kernel.  One workgroup walks stripes of the GAF text; the next stripe's HBM loads are issued into
+// registers before the current one is processed, so the only HBM read of the text overlaps the parse.  Per stripe:
+//   A  registers -> LDS (16 B per lane, coalesced on the HBM side)
+//   B  one 208-byte SPAN per lane, branch-free SWAR classification of every byte: line terminators -> sorted
+//      line-start list (block prefix sum); tab and orientation-mark ('<' '>') bitmaps -> LDS
+//   then, in rounds of WG lines:
+//   R1 one LINE per lane: the twelve column boundaries by bit-scanning the tab bitmap, the nine decimal columns by
+//      SWAR, path geometry; block prefix sum hands every line a contiguous range of node slots
+//   R2 one LINE per lane: node slots filled from the orientation bitmap (name position, line, orientation)
+//   R3 one path NODE per lane: name -> (chromosome, coordinates) -> node id through the position buckets of the
+//      sorted node table (L2 / Infinity Cache resident), length
+//   R4 one LINE per lane: running path length, first occurrence of every name (the reference's list.index /
+//      str.split quirks), validation
+//   R5 one path STEP (link) per lane: overlap test on the prefix sums, link lookup in the node's CSR row, one 64-bit
+//      atomic (ref | alt << 32) per hit, optional hit records
+//   R6 deferred-line offsets, one aggregated atomic per wave
+__global__ __launch_bounds__(WG, 2) void k_classify_main(ClassifyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *text = lds + L_TEXT;
+    uint16_t *tabbm16 = (uint16_t *)(lds + L_TABBM), *oribm16 = (uint16_t *)(lds + L_ORIBM);
+    const uint32_t *tabbm = (const uint32_t *)(lds + L_TABBM), *oribm = (const uint32_t *)(lds + L_ORIBM);
+    uint16_t *starts = (uint16_t *)(lds + L_STARTS);
+    uint32_t *l_ts = (uint32_t *)(lds + L_TS), *l_te = (uint32_t *)(lds + L_TE), *l_tlen = (uint32_t *)(lds + L_TLEN);
+    uint32_t *l_tot = (uint32_t *)(lds + L_TOT), *l_meta = (uint32_t *)(lds + L_META);
+    uint16_t *l_start = (uint16_t *)(lds + L_LSTART), *l_pbeg = (uint16_t *)(lds + L_PBEG), *l_pend = (uint16_t *)(lds + L_PEND);
+    uint16_t *n_pos = (uint16_t *)(lds + L_NPOS), *n_line = (uint16_t *)(lds + L_NLINE), *n_first = (uint16_t *)(lds + L_NFIRST);
+    uint32_t *n_id = (uint32_t *)(lds + L_NID), *n_pre = (uint32_t *)(lds + L_NPRE);
+    uint32_t *misc = (uint32_t *)(lds + L_MISC);
+    uint8_t *dict = lds + L_DICT;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
 
     GraphView g = a.g;
     if (a.dict_in_lds) {
-        // names | off[n+1] | lo[n+1] | hash[mask+1]   (names padded to 4 B)
-        uint32_t nb = (a.dict_names_len + 3) & ~3u, n1 = g.n_chrom + 1, hs = g.hash_mask + 1;
-        uint32_t *d_off = (uint32_t *)(dict + nb), *d_lo = d_off + n1, *d_hash = d_lo + n1;
-        for (uint32_t i = tid; i < a.dict_names_len; i += WG) dict[i] = g.chrom_names[i];
-        for (uint32_t i = tid; i < n1; i += WG) { d_off[i] = g.chrom_off[i]; d_lo[i] = g.chrom_lo[i]; }
-        for (uint32_t i = tid; i < hs; i += WG) d_hash[i] = g.chrom_hash[i];
-        g.chrom_names = dict; g.chrom_off = d_off; g.chrom_lo = d_lo; g.chrom_hash = d_hash;
+        // off[n+1] | bkt_base[n+1] | w4[4n] | wtab[mask+1]
+        const uint32_t n1 = g.n_chrom + 1, ws = g.wtab_mask + 1;
+        uint32_t *d_off = (uint32_t *)dict, *d_bb = d_off + n1, *d_w4 = d_bb + n1, *d_wt = d_w4 + 4 * g.n_chrom;
+        for (uint32_t i = tid; i < n1; i += WG) { d_off[i] = g.chrom_off[i]; d_bb[i] = g.bkt_base[i]; }
+        for (uint32_t i = tid; i < 4 * g.n_chrom; i += WG) d_w4[i] = g.chrom_w4[i];
+        for (uint32_t i = tid; i < ws; i += WG) d_wt[i] = g.chrom_wtab[i];
+        g.chrom_off = d_off; g.bkt_base = d_bb; g.chrom_w4 = d_w4; g.chrom_wtab = d_wt;
     }
 
-    const uint64_t padded = (a.n_bytes + 15) & ~15ull;
     unsigned long long wg_lines = 0;
+    unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool stamp = (a.diag & 16u) != 0;
+#define SVJG_STAMP(i) do { if (stamp) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
+    if (stamp) tprev = __builtin_amdgcn_s_memtime();
+
+    // stripe prefetch registers
+    uint4 pf[PIECES];
+    auto prefetch = [&](uint32_t chunk) {                            // no bounds tests: the buffer is zero padded by TEXT + 64 bytes
+        const uint64_t c0 = (uint64_t)(chunk < a.n_chunks ? chunk : a.n_chunks - 1) * CHUNK;
+        const uint4 *src = (const uint4 *)(a.gaf + c0) + tid;
+#pragma unroll
+        for (uint32_t i = 0; i < PIECES; ++i) pf[i] = src[i * WG];
+    };
+    prefetch(blockIdx.x);
 
     for (uint32_t chunk = blockIdx.x; chunk < a.n_chunks; chunk += gridDim.x) {
         const uint64_t c0 = (uint64_t)chunk * CHUNK;
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (uint64_t)TEXT) ? (a.n_bytes - c0) : (uint64_t)TEXT);   // valid bytes staged
 
-        // ---- A: HBM -> LDS ---------------------------------------------------------------------
+        // ---- A: registers -> LDS, then start the next stripe's HBM loads ---------------------------------
         uint32_t hi_bits = 0;
-#pragma unroll 4
-        for (uint32_t i = tid; i < TEXT / 16; i += WG) {
-            uint64_t off = c0 + (uint64_t)i * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (off < padded) v = *(const uint4 *)(a.gaf + off);
-            hi_bits |= v.x | v.y | v.z | v.w;
-            *(uint4 *)(text + i * 16) = v;
+#pragma unroll
+        for (uint32_t i = 0; i < PIECES; ++i) {
+            hi_bits |= pf[i].x | pf[i].y | pf[i].z | pf[i].w;
+            *(uint4 *)(text + (i * WG + tid) * 16) = pf[i];
         }
-        if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+        if (tid == 0) misc[0] = 0;
         if (hi_bits & 0x80808080u) a.st->non_ascii = 1;
         __syncthreads();
+        prefetch(chunk + gridDim.x);
+        SVJG_STAMP(0);
 
-        // ---- B: terminators -> line starts ----------------------------------------------------------
+        // ---- B: byte classes ----------------------------------------------------------------------------
         // terminator = '\n', or a '\r' not followed by '\n' (Python universal newlines)
-        uint32_t mask[PIECES / 2];                                       // two 16-bit masks per word
+        uint32_t mask[(PIECES + 1) / 2];                                 // two 16-bit terminator masks per word
         uint32_t cnt = 0;
         const uint32_t sp = tid * SPAN;
 #pragma unroll
         for (uint32_t pc = 0; pc < PIECES; ++pc) {
-            uint4 v = *(const uint4 *)(text + sp + pc * 16);
-            uint32_t nl = eq_mask4(v.x, 0x0A0A0A0Au) | (eq_mask4(v.y, 0x0A0A0A0Au) << 4) | (eq_mask4(v.z, 0x0A0A0A0Au) << 8) | (eq_mask4(v.w, 0x0A0A0A0Au) << 12);
-            uint32_t cr = eq_mask4(v.x, 0x0D0D0D0Du) | (eq_mask4(v.y, 0x0D0D0D0Du) << 4) | (eq_mask4(v.z, 0x0D0D0D0Du) << 8) | (eq_mask4(v.w, 0x0D0D0D0Du) << 12);
-            while (cr) {                                                 // rare
-                uint32_t b = __builtin_ctz(cr); cr &= cr - 1;
-                uint32_t q = sp + pc * 16 + b;
-                uint8_t nx = (q + 1 < TEXT) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
-                if (nx != '\n') nl |= 1u << b;
+            const uint4 v = *(const uint4 *)(text + sp + pc * 16);
+            uint32_t nl = eq_mask16(v, 0x0A0A0A0Au);
+            tabbm16[tid * PIECES + pc] = (uint16_t)eq_mask16(v, 0x09090909u);
+            oribm16[tid * PIECES + pc] = (uint16_t)eq_mask16(make_uint4(v.x | 0x02020202u, v.y | 0x02020202u, v.z | 0x02020202u, v.w | 0x02020202u), 0x3E3E3E3Eu);
+            // carriage returns: cheap any-test first (no text file has them in practice)
+            const uint32_t crq = zero_bytes(v.x ^ 0x0D0D0D0Du) | zero_bytes(v.y ^ 0x0D0D0D0Du) | zero_bytes(v.z ^ 0x0D0D0D0Du) | zero_bytes(v.w ^ 0x0D0D0D0Du);
+            if (crq) {
+                uint32_t cr = eq_mask16(v, 0x0D0D0D0Du);
+                while (cr) {
+                    uint32_t b = __builtin_ctz(cr); cr &= cr - 1;
+                    uint32_t q = sp + pc * 16 + b;
+                    uint8_t nx = (q + 1 < TEXT) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
+                    if (nx != '\n') nl |= 1u << b;
+                }
             }
-            // ignore anything at or beyond the valid length
-            uint32_t base = sp + pc * 16;
-            if (base >= V) nl = 0; else if (base + 16 > V) nl &= (1u << (V - base)) - 1u;
+            uint32_t pb = sp + pc * 16;                                  // ignore anything at or beyond the valid length
+            if (pb >= V) nl = 0; else if (pb + 16 > V) nl &= (1u << (V - pb)) - 1u;
             if (pc & 1) mask[pc >> 1] |= nl << 16; else mask[pc >> 1] = nl;
             cnt += __builtin_popcount(nl);
         }
-        // does the chunk begin at a line start?  (file start, or a terminator right before it)
-        uint32_t head = 0;
+        uint32_t head = 0;                                               // does the stripe begin at a line start?
         if (tid == 0) {
             if (c0 == 0) head = 1;
             else {
@@ -150,14 +316,8 @@ __global__ __launch_bounds__(WG) void k_classify_main(ClassifyArgs a) {
                 head = (pb == '\n') || (pb == '\r' && text[0] != '\n');
             }
         }
-        uint32_t mine = cnt + head;
-        uint32_t wtot, excl = wave_excl_scan(mine, wtot);
-        if (lane == 63) misc[4 + wave] = wtot;
-        __syncthreads();
-        uint32_t wbase = 0, total = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < WG / 64; ++w) { uint32_t x = misc[4 + w]; if (w < wave) wbase += x; total += x; }
-        uint32_t o = wbase + excl;
+        uint32_t total;
+        uint32_t o = block_excl_scan(cnt + head, misc + 4, total);
         uint32_t owned = 0;
         const bool too_dense = total > MAXSTARTS;
         if (!too_dense) {
@@ -177,71 +337,247 @@ __global__ __launch_bounds__(WG) void k_classify_main(ClassifyArgs a) {
         __syncthreads();
         const uint32_t n_owned = misc[0];
         if (too_dense) {
-            // > CHUNK/24 lines in the stripe: some line is shorter than 12 columns -> the reference raises ValueError
+            // more than TEXT/24 lines in the stripe: some line has fewer than 12 columns -> ValueError in the reference
             if (tid == 0) atomicMin(&a.st->err, ((a.base_offset + c0) << 3) | SVJG_EXC_VALUE_ERROR);
             __syncthreads();
             continue;
         }
         const bool at_eof = c0 + V == a.n_bytes;
+        SVJG_STAMP(1);
+        if (a.diag & 1u) { if (tid == 0) wg_lines += n_owned; __syncthreads(); continue; }
 
-        // ---- C + D: one line per lane, wave-level commit ----------------------------------------------
         for (uint32_t base = 0; base < n_owned; base += WG) {           // uniform trip count across the block
-            uint32_t li = base + tid;
-            int status = 1;                                              // 1 = no line
-            uint32_t m = 0, s = 0;
-            LaneList out{lists + tid};
+            // ---- R1: one line per lane --------------------------------------------------------------
+            if (tid == 0) misc[3] = 0;                                   // node slots in use this round
+            const uint32_t li = base + tid;
+            uint32_t status = ST_NONE, k = 0, s = 0;
             if (li < n_owned) {
                 s = starts[li];
-                uint32_t e;
+                uint32_t e = V;
                 bool complete = true;
                 if (li + 1 < total) e = (uint32_t)starts[li + 1] - 1;
-                else if (at_eof) e = V;
-                else { complete = false; e = V; }
-                if (!complete || a.all_slow) status = -30;
-                else status = fast_line(g, (const uint8_t *)text, s, e, out, HMAX, &m);
-            }
-            const bool have = li < n_owned;
-            const bool defer = have && status < 0;
-            // deferred lines: one atomic per wave
-            unsigned long long db = __ballot(defer);
-            if (db) {
-                uint32_t nd = __popcll(db);
-                unsigned long long dbase = 0;
-                if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)nd);
-                dbase = __shfl(dbase, 0);
-                if (defer) {
-                    unsigned long long idx = dbase + __popcll(db & ((1ull << lane) - 1ull));
-                    if (idx < a.deferred_cap) a.deferred[idx] = c0 + s; else atomicOr(&a.st->overflow, 1u);
+                else if (!at_eof) complete = false;
+                status = ST_DEFER;
+                if (complete && !a.all_slow) {
+                    while (e > s && py_space(text[e - 1])) --e;         // line.rstrip()
+                    BitCursor tc{tabbm, s >> 5, 0, e};
+                    tc.cur = tabbm[s >> 5] & (0xFFFFFFFFu << (s & 31));
+                    const uint32_t t0 = tc.next(), t1 = tc.next(), t2 = tc.next(), t3 = tc.next(), t4 = tc.next(), t5 = tc.next();
+                    const uint32_t t6 = tc.next(), t7 = tc.next(), t8 = tc.next(), t9 = tc.next(), t10 = tc.next(), t11 = tc.next();
+                    bool ok = t10 < e;                                   // twelve columns
+                    uint32_t qlen, qs, qe, tlen, ts, te, am, alen, aq;
+                    ok &= field_dec(text, t0 + 1, t1, qlen) & field_dec(text, t1 + 1, t2, qs) & field_dec(text, t2 + 1, t3, qe);
+                    ok &= field_dec(text, t5 + 1, t6, tlen) & field_dec(text, t6 + 1, t7, ts) & field_dec(text, t7 + 1, t8, te);
+                    ok &= field_dec(text, t8 + 1, t9, am) & field_dec(text, t9 + 1, t10, alen) & field_dec(text, t10 + 1, t11, aq);
+                    ok &= alen != 0;                                     // ZeroDivisionError unless an id:f: tag exists: exact path decides
+                    // path column (t4, t5): starts with an orientation mark; count the marks
+                    const uint32_t pa = t4 + 1, pbnd = t5;
+                    if (ok && pa < pbnd) {
+                        const uint32_t w0 = pa >> 5, w1 = (pbnd - 1) >> 5;
+                        for (uint32_t w = w0; w <= w1; ++w) {
+                            uint32_t m = oribm[w];
+                            if (w == w0) m &= 0xFFFFFFFFu << (pa & 31);
+                            if (w == w1 && ((pbnd & 31) != 0)) m &= (1u << (pbnd & 31)) - 1u;
+                            k += __builtin_popcount(m);
+                        }
+                        ok &= ((oribm[w0] >> (pa & 31)) & 1u) != 0;
+                    } else ok = false;
+                    ok &= k >= 1 && k <= KMAX;
+                    if (ok) {
+                        status = k >= 2 ? ST_OK : ST_NOHIT;
+                        l_ts[tid] = ts; l_te[tid] = te; l_tlen[tid] = tlen; l_pbeg[tid] = (uint16_t)t4; l_pend[tid] = (uint16_t)t5;
+                    }
                 }
+                l_start[tid] = (uint16_t)s;
             }
-            if (defer) m = 0;
-            // counts: packed (ref | alt << 32) adds; neighbouring SVs of one alignment share cache lines
-            for (uint32_t j = 0; j < m; ++j) {
-                Pending h = out[j];
-                atomicAdd(&a.counts[h.hit], (unsigned long long)(h.pre & 0xFFFFu) | ((unsigned long long)(h.pre >> 16) << 32));
+            if (status != ST_OK) k = 0;
+            uint32_t ntot;
+            uint32_t nbase = block_excl_scan(k, misc + 8, ntot);
+            (void)ntot;
+            if (status == ST_OK && nbase + k > NMAX) { status = ST_DEFER; k = 0; }     // node slots exhausted (very long paths)
+            if (k) atomicMax(&misc[3], nbase + k);
+            SVJG_STAMP(2);
+            // ---- R2: node slots from the orientation bitmap; every name must be non-empty ------------------------
+            if (k) {
+                const uint32_t pa = (uint32_t)l_pbeg[tid] + 1, pbnd = l_pend[tid];
+                BitCursor oc{oribm, pa >> 5, 0, pbnd};
+                oc.cur = oribm[pa >> 5] & (0xFFFFFFFFu << (pa & 31));
+                uint32_t prev = pa - 1;
+                bool ok = true;
+                for (uint32_t j = 0; j < k; ++j) {
+                    const uint32_t q = oc.next();
+                    ok &= (j == 0) | (q > prev + 1);
+                    prev = q;
+                    n_pos[nbase + j] = (uint16_t)(q + 1);
+                    n_line[nbase + j] = (uint16_t)tid;                  // orientation bit added by the node's lane (R3)
+                }
+                ok &= pbnd > prev + 1;
+                if (!ok) status = ST_DEFER;
             }
-            if (a.want_hits) {
-                uint32_t tot, ex = wave_excl_scan(m, tot);
-                if (tot) {
-                    unsigned long long rb = 0;
-                    if (lane == 0) rb = atomicAdd(&a.st->n_recs, (unsigned long long)tot);
-                    rb = __shfl(rb, 0);
-                    for (uint32_t j = 0; j < m; ++j) {
-                        unsigned long long idx = rb + ex + j;
-                        if (idx < a.rec_cap) {
-                            Pending h = out[j];
-                            svjg_hitrec r; r.line_start = a.base_offset + c0 + s; r.slot = h.hit;
-                            r.n_ref = (uint16_t)(h.pre & 0xFFFFu); r.n_alt = (uint16_t)(h.pre >> 16);
-                            a.recs[idx] = r;
-                        } else atomicOr(&a.st->overflow, 2u);
+            l_meta[tid] = nbase | (k << 16) | (status << 24);
+            __syncthreads();
+            SVJG_STAMP(3);
+            const uint32_t n_nodes = (a.diag & 2u) ? 0u : misc[3];
+            // ---- R3: one node per lane, UB nodes in flight per lane ------------------------------------------------
+            for (uint32_t nb = 0; nb < n_nodes; nb += UB * WG) {
+                uint32_t nn[UB], lnv[UB], cidx[UB], v1[UB], v2[UB], kind[UB], lo[UB], hi[UB], end[UB];
+                unsigned long long key[UB];
+                bool live[UB], good[UB];
+#pragma unroll
+                for (uint32_t u = 0; u < UB; ++u) {
+                    nn[u] = nb + u * WG + tid;
+                    live[u] = false; good[u] = false; lo[u] = hi[u] = end[u] = 0; key[u] = 0; lnv[u] = 0;
+                    cidx[u] = NONE32; v1[u] = v2[u] = kind[u] = 0;
+                    if (nn[u] < n_nodes) {
+                        lnv[u] = n_line[nn[u]] & 0x7FFFu;
+                        const uint32_t meta = l_meta[lnv[u]];
+                        if ((meta >> 24) == ST_OK) {
+                            live[u] = true;
+                            const uint32_t a0 = n_pos[nn[u]];
+                            const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
+                            const uint32_t b0 = (nn[u] + 1 < lnb + lk) ? (uint32_t)n_pos[nn[u] + 1] - 1u : (uint32_t)l_pend[lnv[u]];
+                            if (text[a0 - 1] == '<') n_line[nn[u]] = (uint16_t)(lnv[u] | 0x8000u);
+                            good[u] = parse_name(g, text, a0, b0 - a0, cidx[u], v1[u], v2[u], kind[u]);
+                        }
+                    }
+                }
+                // position buckets -> candidate range in the sorted node table
+#pragma unroll
+                for (uint32_t u = 0; u < UB; ++u) {
+                    if (good[u]) {
+                        key[u] = node_key(cidx[u], v1[u], kind[u], kind[u] ? v2[u] : 0);
+                        const uint32_t b0 = g.bkt_base[cidx[u]], nbk = g.bkt_base[cidx[u] + 1] - b0 - 1, b = v1[u] >> g.bkt_shift;
+                        if (b < nbk && !(a.diag & 4u)) { lo[u] = g.bkt[b0 + b]; end[u] = hi[u] = g.bkt[b0 + b + 1]; }
+                    }
+                }
+                for (;;) {                                               // joint binary search, loads of the UB nodes overlap
+                    unsigned long long kk[UB]; uint32_t mid[UB]; bool any = false;
+#pragma unroll
+                    for (uint32_t u = 0; u < UB; ++u) { mid[u] = (lo[u] + hi[u]) >> 1; kk[u] = 0; if (lo[u] < hi[u]) { kk[u] = g.nodes[mid[u]].key; any = true; } }
+                    if (!any) break;
+#pragma unroll
+                    for (uint32_t u = 0; u < UB; ++u) if (lo[u] < hi[u]) { if (kk[u] < key[u]) lo[u] = mid[u] + 1; else hi[u] = mid[u]; }
+                }
+                svjg_node nd[UB];
+#pragma unroll
+                for (uint32_t u = 0; u < UB; ++u) { nd[u].key = 0; nd[u].aux = 0; nd[u].row = 0; if (good[u] && lo[u] < end[u]) nd[u] = g.nodes[lo[u]]; }
+#pragma unroll
+                for (uint32_t u = 0; u < UB; ++u) {
+                    if (live[u]) {
+                        uint32_t id = NONE32, len = 0;
+                        if (good[u] && lo[u] < end[u] && nd[u].key == key[u] && !(nd[u].row & 0x80000000u)) {   // hazard-prone names: exact path
+                            if (kind[u]) { if (nd[u].aux != SVJG_LEN_UNKNOWN) { id = lo[u]; len = nd[u].aux; } }
+                            else if (nd[u].aux == v2[u]) { id = lo[u]; len = v2[u] - v1[u] + 1; }
+                        }
+                        if ((a.diag & 4u) && good[u]) { id = 0; len = v2[u] - v1[u] + 1; }
+                        n_id[nn[u]] = id; n_pre[nn[u]] = len;
+                        if (id == NONE32) atomicOr(&l_meta[lnv[u]], ST_DEFER << 24);              // ST_OK | ST_DEFER == ST_DEFER
                     }
                 }
             }
+            __syncthreads();
+            SVJG_STAMP(4);
+            // ---- R4: one line per lane: prefix sums, first occurrences --------------------------------------
+            {
+                const uint32_t meta = l_meta[tid];
+                if ((meta >> 24) == ST_OK) {
+                    const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
+                    unsigned long long run = 0, seen1 = 0, seen2 = 0;
+                    for (uint32_t j = 0; j < lk; ++j) {
+                        const uint32_t idj = n_id[lnb + j];
+                        run += n_pre[lnb + j];
+                        n_pre[lnb + j] = (uint32_t)run;
+                        uint32_t f = j;
+                        // two-hash filter: only a possible revisit pays for the search of the first occurrence
+                        const unsigned long long b1 = 1ull << (idj & 63), b2 = 1ull << ((idj * 0x9E3779B1u) >> 26);
+                        if ((seen1 & b1) && (seen2 & b2))
+                            for (uint32_t jj = 0; jj < j; ++jj) if (n_id[lnb + jj] == idj) { f = jj; break; }
+                        seen1 |= b1; seen2 |= b2;
+                        n_first[lnb + j] = (uint16_t)(lnb + f);
+                    }
+                    l_tot[tid] = (uint32_t)run;
+                    if (run > 0xFFFFFFFFull) l_meta[tid] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
+                }
+            }
+            __syncthreads();
+            SVJG_STAMP(5);
+            // ---- R5: one path step per lane, UL steps in flight per lane ------------------------------------------------
+            for (uint32_t nb = 0; nb < n_nodes; nb += UL * WG) {
+                uint32_t lnv[UL], idl[UL], idr[UL], want[UL], ra[UL], rb[UL], hit_e[UL];
+                bool go[UL];
+#pragma unroll
+                for (uint32_t u = 0; u < UL; ++u) {
+                    const uint32_t n = nb + u * WG + tid;
+                    go[u] = false; lnv[u] = 0; idl[u] = idr[u] = 0; want[u] = 0; ra[u] = rb[u] = 0; hit_e[u] = NONE32;
+                    if (n + 1 < n_nodes) {
+                        const uint32_t ln = n_line[n] & 0x7FFFu;
+                        const uint32_t meta = l_meta[ln];
+                        const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
+                        if ((meta >> 24) == ST_OK && n + 1 < lnb + lk) {
+                            // the reference evaluates the link (name, strand) of the FIRST occurrence of each name
+                            // (str.split / list.index, filter-alignments.py:206, :269-271)
+                            const uint32_t fl = n_first[n], fr = n_first[n + 1];
+                            const long long left = (long long)n_pre[fl] - (long long)l_ts[ln];
+                            const long long pre_excl_r = fr > lnb ? (long long)n_pre[fr - 1] : 0;
+                            const long long right = (long long)l_tot[ln] - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
+                            if (left >= (long long)g.d_over && right >= (long long)g.d_over) {
+                                go[u] = true; lnv[u] = ln; idl[u] = n_id[n]; idr[u] = n_id[n + 1];
+                                want[u] = (uint32_t)(n_line[fl] >> 15) | ((uint32_t)(n_line[fr] >> 15) << 1);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < UL; ++u) if (go[u]) { ra[u] = g.nodes[idl[u]].row & 0x7FFFFFFFu; rb[u] = g.nodes[idl[u] + 1].row & 0x7FFFFFFFu; }
+                for (uint32_t e = 0;; ++e) {                             // CSR rows are a handful of entries; the UL rows are walked together
+                    svjg_edge ed[UL]; bool any = false;
+#pragma unroll
+                    for (uint32_t u = 0; u < UL; ++u) { ed[u].right = NONE32; ed[u].meta = 0; ed[u].h0 = ed[u].h1 = 0; if (go[u] && hit_e[u] == NONE32 && ra[u] + e < rb[u]) { ed[u] = g.edges[ra[u] + e]; any = true; } }
+                    if (!any) break;
+#pragma unroll
+                    for (uint32_t u = 0; u < UL; ++u) {
+                        if (go[u] && hit_e[u] == NONE32 && ra[u] + e < rb[u] && ed[u].right == idr[u] && (ed[u].meta & 3u) == want[u]) {
+                            hit_e[u] = ra[u] + e;
+                            const uint32_t nh = ed[u].meta >> 2;
+                            for (uint32_t j = 0; j < nh; ++j) {
+                                const uint32_t hv = edge_hit(g, ed[u], j);
+                                if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
+                                if (a.want_hits) {
+                                    unsigned long long idx = atomicAdd(&a.st->n_recs, 1ull);
+                                    if (idx < a.rec_cap) {
+                                        svjg_hitrec r; r.line_start = a.base_offset + c0 + l_start[lnv[u]]; r.slot = hv >> 1;
+                                        r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
+                                        a.recs[idx] = r;
+                                    } else atomicOr(&a.st->overflow, 2u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            SVJG_STAMP(6);
+            // ---- R6: lines for the exact path ------------------------------------------------------------------
+            {
+                const bool defer = li < n_owned && (l_meta[tid] >> 24) == ST_DEFER;
+                unsigned long long db = __ballot(defer);
+                if (db) {
+                    unsigned long long dbase = 0;
+                    if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)__popcll(db));
+                    dbase = __shfl(dbase, 0);
+                    if (defer) {
+                        unsigned long long idx = dbase + __popcll(db & ((1ull << lane) - 1ull));
+                        if (idx < a.deferred_cap) a.deferred[idx] = c0 + s; else atomicOr(&a.st->overflow, 1u);
+                    }
+                }
+            }
+            __syncthreads();                                             // round state is reused
+            SVJG_STAMP(7);
         }
         if (tid == 0) wg_lines += n_owned;
-        __syncthreads();                                                 // LDS is reused by the next stripe
     }
     if (tid == 0 && wg_lines) atomicAdd(&a.st->n_lines, wg_lines);
+    if (stamp && tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], ph[i]);
+#undef SVJG_STAMP
 }
 
 struct SlowEmit {
@@ -259,8 +595,8 @@ struct SlowEmit {
     }
 };
 
-__global__ __launch_bounds__(WG) void k_classify_slow(ClassifyArgs a, uint64_t n_def) {
-    uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x;
+__global__ __launch_bounds__(TPB) void k_classify_slow(ClassifyArgs a, uint64_t n_def) {
+    uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= n_def) return;
     uint64_t s = a.deferred[i], e = s;
     while (e < a.n_bytes && a.gaf[e] != '\n' && a.gaf[e] != '\r') ++e;
@@ -350,8 +686,8 @@ __device__ inline bool geno_gate(const GenoArgs &a, uint64_t r, uint32_t &ref, u
     return (ok & 2u) || (ref | alt) != 0;
 }
 
-__global__ __launch_bounds__(WG) void k_geno_maxn(GenoArgs a) {
-    uint64_t r = (uint64_t)blockIdx.x * WG + threadIdx.x;
+__global__ __launch_bounds__(TPB) void k_geno_maxn(GenoArgs a) {
+    uint64_t r = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     uint32_t n = 0;
     if (r < a.n_rows) {
         uint32_t ref, alt;
@@ -370,8 +706,8 @@ __device__ inline int64_t trunc_dd(dd v) {               // int(Decimal): toward
     return (int64_t)t;
 }
 
-__global__ __launch_bounds__(WG) void k_genotype(GenoArgs a) {
-    uint64_t r = (uint64_t)blockIdx.x * WG + threadIdx.x;
+__global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
+    uint64_t r = (uint64_t)blockIdx.x * TPB + threadIdx.x;
     if (r >= a.n_rows) return;
     uint32_t ref, alt;
     bool go = geno_gate(a, r, ref, alt);

@@ -1,19 +1,15 @@
-// Per-alignment classification routines of the HIP path (one GAF line per lane).
+// Graph-table lookups shared by the classify kernels, and the EXACT per-line routine (slow_line) that
+// evaluates a deferred GAF line straight from HBM with the reference's string semantics, including the
+// exception it would raise.  The main kernel (svjg_kernels.h, k_classify_main) handles the regular case —
+// canonical node names that exist in the graph, plain decimal columns — and defers anything else; nothing
+// is ever guessed.
 //
-// Two tiers, both run on the GPU:
-//   fast_line  - streaming parse of a line staged in LDS.  Handles the regular case (canonical node names
-//                that exist in the graph, no repeated node, no name that is a substring of another, path
-//                length column consistent with the node names, plain decimal columns).  Anything else is
-//                DEFERRED, never guessed.
-//   slow_line  - exact string-level evaluation straight from HBM for the deferred lines, following the
-//                reference's semantics to the letter, including the exception it would raise.
-//
-// What they replace in the reference (/root/reference/filter-alignments.py):
+// What this replaces in the reference (/root/reference/filter-alignments.py):
 //   read_gaf_line :184-198, extract_nodes :351-373, get_aln_links :200-219, reverse_link :221-225,
 //   the d_link_sv probes :141-153, check_bkpt_overlap :258-273, get_node_start/end/len :328-349.
 //
-// The functions are plain C++ on raw pointers so that tests/hostsim can also compile them with g++ and
-// run them against the oracle without a GPU (test harness only; the shipped library has no CPU path).
+// Plain C++ on raw pointers so that tests/hostsim can also compile slow_line with g++ and run it against the
+// oracle without a GPU (test harness only; the shipped library has no CPU path).
 #pragma once
 #include <stdint.h>
 #include "../../include/svjg.h"
@@ -40,14 +36,31 @@ struct GraphView {
     uint32_t n_chrom;
     uint32_t hash_mask;
     uint32_t d_over;
+    const uint32_t *bkt_base;    // n_chrom + 1 : first position bucket of each chromosome (svjg_host_tables.h)
+    const uint32_t *bkt;         // bucket -> first node at or after the bucket's first position
+    uint32_t bkt_shift;
+    const uint32_t *chrom_w4;    // n_chrom x 4 words: names of <= 16 bytes, zero padded (main kernel dictionary)
+    const uint32_t *chrom_wtab;  // open addressing on chrom_word_hash, value = chrom index + 1
+    uint32_t wtab_mask;
 };
 
-struct Pending {                 // a hit whose breakpoint-overlap test is still open
-    uint32_t hit;                // slot << 1 | allele       (after fast_line: slot)
-    uint32_t pre;                // path length through the link's left node   (after fast_line: n_ref | n_alt << 16)
-};
+SVJG_HD uint32_t chrom_word_hash(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t len) {
+    uint32_t h = (c0 * 0x9E3779B1u) ^ (c1 * 0x85EBCA77u) ^ (c2 * 0xC2B2AE3Du) ^ (c3 * 0x27D4EB2Fu) ^ (len * 0x165667B1u);
+    return h ^ (h >> 15);
+}
 
-enum { LINE_OK = 0, LINE_DEFER = -1 };   // fast_line returns LINE_OK or a negative defer-site number (diagnostics)
+// chromosome of a name given as four zero-padded words + length (<= 16), or NONE32
+SVJG_HD uint32_t chrom_lookup_words(const GraphView &g, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t len) {
+    uint32_t i = chrom_word_hash(c0, c1, c2, c3, len) & g.wtab_mask;
+    for (;;) {
+        const uint32_t v = g.chrom_wtab[i];
+        if (v == 0) return NONE32;
+        const uint32_t c = v - 1;
+        const uint32_t *w = g.chrom_w4 + 4 * c;
+        if (w[0] == c0 && w[1] == c1 && w[2] == c2 && w[3] == c3 && g.chrom_off[c + 1] - g.chrom_off[c] == len) return c;
+        i = (i + 1) & g.wtab_mask;
+    }
+}
 
 SVJG_HD bool py_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 
@@ -85,6 +98,20 @@ SVJG_HD uint32_t node_search(const GraphView &g, uint32_t cidx, uint64_t key) {
     return (lo < g.chrom_lo[cidx + 1] && g.nodes[lo].key == key) ? lo : NONE32;
 }
 
+// same result through the position buckets: two dependent loads in the common case
+SVJG_HD uint32_t node_lookup(const GraphView &g, uint32_t cidx, uint32_t pos, uint64_t key) {
+    const uint32_t b0 = g.bkt_base[cidx], nb = g.bkt_base[cidx + 1] - b0 - 1, b = pos >> g.bkt_shift;
+    if (b >= nb) return NONE32;
+    uint32_t lo = g.bkt[b0 + b];
+    const uint32_t end = g.bkt[b0 + b + 1];
+    uint32_t hi = end;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (g.nodes[mid].key < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < end && g.nodes[lo].key == key) ? lo : NONE32;
+}
+
 // entry of the directed link (l, sl) -> (r, sr), or NONE32
 SVJG_HD uint32_t edge_find(const GraphView &g, uint32_t l, uint32_t sl, uint32_t r, uint32_t sr) {
     uint32_t a = g.nodes[l].row & 0x7FFFFFFFu, b = g.nodes[l + 1].row & 0x7FFFFFFFu;
@@ -98,144 +125,6 @@ SVJG_HD uint32_t edge_hit(const GraphView &g, const svjg_edge &e, uint32_t j) {
     uint32_t nh = e.meta >> 2;
     if (nh <= 2) return j == 0 ? e.h0 : e.h1;
     return g.hits[e.h0 + j];
-}
-
-// ---------------------------------------------------------------------------------------------------
-// fast path
-// ---------------------------------------------------------------------------------------------------
-
-// plain unsigned decimal column followed by a tab (or the end of the line when `last_ok`)
-template <class P>
-SVJG_HD bool col_uint(P t, uint32_t &p, uint32_t e, uint64_t &v, bool last_ok) {
-    uint32_t nd = 0;
-    v = 0;
-    while (p < e) {
-        uint32_t d = (uint32_t)t[p] - '0';
-        if (d > 9) break;
-        v = v * 10 + d;
-        ++nd; ++p;
-    }
-    if (nd == 0 || nd > 18) return false;
-    if (p < e) { if (t[p] != '\t') return false; ++p; return true; }
-    return last_ok;
-}
-
-template <class P>
-SVJG_HD bool col_skip(P t, uint32_t &p, uint32_t e) {
-    while (p < e && t[p] != '\t') ++p;
-    if (p >= e) return false;
-    ++p;
-    return true;
-}
-
-// One line, text in [s, e) of `t` (terminator excluded).  On LINE_OK, out[0..*n_out) holds the line's
-// informative SVs as (hit = slot, pre = n_ref | n_alt << 16).
-//
-// Order of work: columns 1-5, then a light scan to the end of the path column so that Tlen/Ts/Te (columns
-// 7-9) are known before the path is walked; every link's overlap test is then decided on the spot and the
-// per-lane list only ever holds final, merged entries.
-template <class P, class O>
-SVJG_HD int fast_line(const GraphView &g, P t, uint32_t s, uint32_t e, O out, uint32_t out_cap, uint32_t *n_out) {
-    *n_out = 0;
-    while (e > s && py_space(t[e - 1])) --e;
-    uint32_t p = s;
-    uint64_t tmp;
-    if (!col_skip(t, p, e)) return -1;
-    if (!col_uint(t, p, e, tmp, false) || !col_uint(t, p, e, tmp, false) || !col_uint(t, p, e, tmp, false)) return -2;
-    if (!col_skip(t, p, e)) return -3;
-    uint32_t ps = p;
-    if (!col_skip(t, p, e)) return -14;
-    uint32_t pe = p - 1;                                                      // the tab that ends the path column
-    uint64_t Tlen, Ts, Te, am, alen, aq;
-    if (!col_uint(t, p, e, Tlen, false) || !col_uint(t, p, e, Ts, false) || !col_uint(t, p, e, Te, false)) return -15;
-    if (!col_uint(t, p, e, am, false) || !col_uint(t, p, e, alen, false) || !col_uint(t, p, e, aq, true)) return -16;
-    if (alen == 0) return -17;                                                // ZeroDivisionError unless an id:f: tag exists
-    // a link passes iff  pre_L - Ts >= d_over  and  (Tlen - pre_L) - (Tlen - Te - 1) >= d_over   (pre_L = path
-    // length through its left node; needs sum(node lengths) == Tlen, verified below)
-    const uint64_t lo_ok = Ts + g.d_over;
-
-    uint64_t pre = 0, seen1 = 0, seen2 = 0;
-    uint32_t m = 0, k = 0, prev_id = NONE32, prev_or = 0;
-    uint32_t prev_cidx = NONE32, prev_ch = 0, prev_cl = 0;
-    p = ps;
-    while (p < pe && (t[p] == '>' || t[p] == '<')) {
-        uint32_t orient = t[p] == '<';
-        ++p;
-        uint32_t ns = p, colon = NONE32, nd1 = 0, nd2 = 0, sep = 0, bad = 0, h = FNV_INIT, hc = 0;
-        uint64_t v1 = 0, v2 = 0;
-        while (p < pe) {
-            uint32_t c = t[p];
-            if (c == '>' || c == '<') break;
-            if (c == ':') { colon = p; hc = h; v1 = v2 = 0; nd1 = nd2 = sep = bad = 0; }
-            else if (colon != NONE32) {
-                uint32_t d = c - '0';
-                if (d <= 9) {
-                    if (!sep) { bad |= (nd1 == 1 && v1 == 0); v1 = v1 * 10 + d; ++nd1; }
-                    else      { bad |= (nd2 == 1 && v2 == 0); v2 = v2 * 10 + d; ++nd2; }
-                } else if ((c == '-' || c == '.') && !sep && nd1) sep = c;
-                else bad = 1;
-            }
-            h = (h ^ c) * FNV_PRIME;
-            ++p;
-        }
-        if (colon == NONE32 || !sep || !nd1 || !nd2 || bad || nd1 > 10 || nd2 > 10 || v1 > 0xFFFFFFFFull || v2 > 0xFFFFFFFFull)
-            return -4;
-        uint32_t clen = colon - ns, cidx;
-        if (prev_cidx != NONE32 && hc == prev_ch && clen == prev_cl) {
-            uint32_t o = g.chrom_off[prev_cidx], j = 0;
-            while (j < clen && g.chrom_names[o + j] == t[ns + j]) ++j;
-            cidx = (j == clen) ? prev_cidx : chrom_lookup(g, t, ns, clen, hc);
-        } else cidx = chrom_lookup(g, t, ns, clen, hc);
-        if (cidx == NONE32) return -5;
-        prev_cidx = cidx; prev_ch = hc; prev_cl = clen;
-        uint32_t kind = sep == '.';
-        if (kind && v2 >= 32768) return -6;
-        uint64_t key = node_key(cidx, (uint32_t)v1, kind, kind ? (uint32_t)v2 : 0);
-        uint32_t id = NONE32;
-        if (prev_id != NONE32) {
-            if (g.nodes[prev_id + 1].key == key) id = prev_id + 1;            // sentinel key never matches
-            else if (prev_id > 0 && g.nodes[prev_id - 1].key == key) id = prev_id - 1;
-            else if (prev_id + 2 <= g.n_nodes && g.nodes[prev_id + 2].key == key) id = prev_id + 2;
-            else if (prev_id > 1 && g.nodes[prev_id - 2].key == key) id = prev_id - 2;
-        }
-        if (id == NONE32) id = node_search(g, cidx, key);
-        if (id == NONE32) return -7;
-        svjg_node nd = g.nodes[id];
-        if (nd.row & 0x80000000u) return -8;
-        uint64_t len;
-        if (kind) { if (nd.aux == SVJG_LEN_UNKNOWN) return -9; len = nd.aux; }
-        else { if (nd.aux != (uint32_t)v2) return -10; len = v2 - v1 + 1; }
-        // two-hash filter for "this node was already on the path" (exactness is the deferred path's job)
-        uint64_t b1 = 1ull << (id & 63), b2 = 1ull << ((id * 0x9E3779B1u) >> 26);
-        if ((seen1 & b1) && (seen2 & b2)) return -11;
-        seen1 |= b1; seen2 |= b2;
-        if (k && pre >= lo_ok && pre + (g.d_over - 1) <= Te) {
-            uint32_t ei = edge_find(g, prev_id, prev_or, id, orient);
-            if (ei != NONE32) {
-                svjg_edge ed = g.edges[ei];
-                uint32_t nh = ed.meta >> 2;
-                for (uint32_t j = 0; j < nh; ++j) {
-                    uint32_t hv = edge_hit(g, ed, j), slot = hv >> 1, add = (hv & 1) ? 0x10000u : 1u, q = 0;
-                    while (q < m && out[q].hit != slot) ++q;
-                    if (q == m) {
-                        if (m == out_cap) return -12;
-                        out[m].hit = slot; out[m].pre = add; ++m;
-                    } else {
-                        out[q].pre += add;
-                        if ((out[q].pre & 0xFFFFu) == 0xFFFFu || (out[q].pre >> 16) == 0xFFFFu) return -12;
-                    }
-                }
-            }
-        }
-        pre += len;
-        if (pre > 0xFFFFFFFFull) return -13;
-        prev_id = id; prev_or = orient; ++k;
-    }
-    if (k == 0 || p != pe) return -14;
-    if (k < 2) return LINE_OK;
-    if (pre != Tlen) return -18;
-    *n_out = m;
-    return LINE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

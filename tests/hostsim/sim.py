@@ -20,20 +20,32 @@ def build():
     return SO
 
 
-def classify(graph, gaf, force_slow=False, pend_cap=12):
+def _lib():
     from svjg import capi
     lib = ctypes.CDLL(build())
     lib.hostsim_classify.restype = ctypes.c_int
-    lib.hostsim_classify.argtypes = [ctypes.POINTER(capi.CGraph), ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int,
-                                     ctypes.c_uint32, ctypes.c_void_p] + [ctypes.c_void_p] * 4
+    lib.hostsim_classify.argtypes = [ctypes.POINTER(capi.CGraph), ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p] + [ctypes.c_void_p] * 3
+    lib.hostsim_check_lookup.restype = ctypes.c_uint64
+    lib.hostsim_check_lookup.argtypes = [ctypes.POINTER(capi.CGraph)]
+    return lib, capi
+
+
+def classify(graph, gaf):
+    """Every line through svjg::slow_line (the exact path the kernels defer to)."""
+    lib, capi = _lib()
     cg = capi.cgraph_of(graph)
     buf = np.frombuffer(gaf, dtype=np.uint8) if not isinstance(gaf, np.ndarray) else gaf
     counts = np.zeros((max(graph.n_slots, 1), 2), dtype=np.uint32)
-    nl, nd, eo = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    nl, eo = ctypes.c_uint64(0), ctypes.c_uint64(0)
     ex = ctypes.c_int(0)
-    rc = lib.hostsim_classify(ctypes.byref(cg), buf.ctypes.data if buf.size else None, buf.size, int(force_slow), pend_cap,
-                              counts.ctypes.data, ctypes.addressof(nl), ctypes.addressof(nd), ctypes.addressof(ex),
-                              ctypes.addressof(eo))
+    rc = lib.hostsim_classify(ctypes.byref(cg), buf.ctypes.data if buf.size else None, buf.size, counts.ctypes.data,
+                              ctypes.addressof(nl), ctypes.addressof(ex), ctypes.addressof(eo))
     if rc:
         raise EXC[ex.value](f"offset {eo.value}")
-    return counts[: graph.n_slots], nl.value, nd.value
+    return counts[: graph.n_slots], nl.value
+
+
+def check_lookup(graph):
+    lib, capi = _lib()
+    cg = capi.cgraph_of(graph)
+    return lib.hostsim_check_lookup(ctypes.byref(cg))

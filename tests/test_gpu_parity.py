@@ -100,7 +100,7 @@ def test_synth_g6(ctx, golden, tag, tmp_path):
     assert _counts_dict(g, counts) == g6["counts"]
     st = ctx.stats()
     assert st["n_lines"] == g6["args"]["n_aln"]
-    assert 0 < st["n_deferred"] < st["n_lines"] // 100
+    assert st["n_deferred"] == 0          # revisited nodes are handled in the main kernel; nothing needs the exact path
     js = json.dumps(flt.informative_dict(g, recs, data.tobytes()), sort_keys=True, indent=4)
     assert hashlib.sha256(js.encode()).hexdigest() == g6["sha256_json"]
     n = genotype.genotype_with_counts(ctx, pre + ".vcf", g.slot_of, pre + "_genotype.vcf")
