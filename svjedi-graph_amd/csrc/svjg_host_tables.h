@@ -1,6 +1,7 @@
 // Host-side helper shared by the library's graph upload and the host test harness: builds the
 // open-addressing chromosome-name hash table that svjg::chrom_lookup probes.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <vector>
 #include "../../include/svjg.h"
