@@ -23,9 +23,9 @@ struct svjg_ctx {
     // graph
     bool have_graph = false, have_counts = false;
     svjg_node *d_nodes = nullptr;  svjg_edge *d_edges = nullptr;  uint32_t *d_hits = nullptr;
-    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr, *d_bbase = nullptr, *d_bkt = nullptr, *d_w4 = nullptr, *d_wtab = nullptr;
+    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr, *d_names = nullptr, *d_links = nullptr;
     GraphView gv{};
-    uint32_t names_len = 0, dict_bytes = 0, dict_in_lds = 0, gflags = 0, n_slots = 0;
+    uint32_t names_len = 0, gflags = 0, n_slots = 0;
     unsigned long long *d_counts = nullptr, *d_snap = nullptr;
     // text
     uint8_t *d_gaf = nullptr;  uint64_t gaf_cap = 0, gaf_bytes = 0;  bool have_gaf = false;
@@ -97,8 +97,8 @@ extern "C" int svjg_init(int device, svjg_ctx **out) {
 
 static void free_graph(svjg_ctx *c) {
     hipFree(c->d_nodes); hipFree(c->d_edges); hipFree(c->d_hits); hipFree(c->d_cnames); hipFree(c->d_coff);
-    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap); hipFree(c->d_bbase); hipFree(c->d_bkt); hipFree(c->d_w4); hipFree(c->d_wtab);
-    c->d_bbase = nullptr; c->d_bkt = nullptr; c->d_w4 = nullptr; c->d_wtab = nullptr;
+    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap); hipFree(c->d_names); hipFree(c->d_links);
+    c->d_names = nullptr; c->d_links = nullptr;
     c->d_nodes = nullptr; c->d_edges = nullptr; c->d_hits = nullptr; c->d_cnames = nullptr; c->d_coff = nullptr;
     c->d_clo = nullptr; c->d_chash = nullptr; c->d_counts = nullptr; c->d_snap = nullptr;
     c->have_graph = false; c->have_counts = false;
@@ -149,20 +149,14 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     if ((rc = upload(c, &c->d_clo, g->chrom_node_lo, g->n_chrom + 1))) return rc;
     std::vector<uint32_t> hash = build_chrom_hash(*g);
     if ((rc = upload(c, &c->d_chash, hash.data(), hash.size()))) return rc;
-    BucketTable bt = build_buckets(*g);
-    if ((rc = upload(c, &c->d_bbase, bt.base.data(), bt.base.size()))) return rc;
-    if ((rc = upload(c, &c->d_bkt, bt.table.data(), bt.table.size()))) return rc;
-    ChromWords cw = build_chrom_words(*g);
-    if ((rc = upload(c, &c->d_w4, cw.w4.data(), cw.w4.size()))) return rc;
-    if ((rc = upload(c, &c->d_wtab, cw.table.data(), cw.table.size()))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));           // `hash`, `bt`, `cw` are locals
-    c->gv.chrom_w4 = c->d_w4; c->gv.chrom_wtab = c->d_wtab; c->gv.wtab_mask = (uint32_t)cw.table.size() - 1;
-    c->gv.bkt_base = c->d_bbase; c->gv.bkt = c->d_bkt; c->gv.bkt_shift = bt.shift;
+    KernelTables kt = build_kernel_tables(*g);
+    if ((rc = upload(c, &c->d_names, kt.names.data(), kt.names.size()))) return rc;
+    if ((rc = upload(c, &c->d_links, kt.links.data(), kt.links.size()))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // `hash` and `kt` are locals
     c->gv.nodes = c->d_nodes; c->gv.n_nodes = (uint32_t)g->n_nodes; c->gv.edges = c->d_edges; c->gv.hits = c->d_hits;
     c->gv.chrom_names = c->d_cnames; c->gv.chrom_off = c->d_coff; c->gv.chrom_lo = c->d_clo; c->gv.chrom_hash = c->d_chash;
     c->gv.n_chrom = g->n_chrom; c->gv.hash_mask = (uint32_t)hash.size() - 1; c->gv.d_over = g->d_over;
-    c->dict_bytes = 4 * (2 * (g->n_chrom + 1) + 4 * g->n_chrom + (uint32_t)cw.table.size());   // off | bkt_base | w4 | wtab
-    c->dict_in_lds = c->dict_bytes <= DICT_LDS_MAX;
+    c->gv.name_tab = c->d_names; c->gv.name_mask = kt.name_mask; c->gv.link_tab = c->d_links; c->gv.link_mask = kt.link_mask;
     c->gflags = g->flags;
     c->n_slots = g->n_slots;
     HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)g->n_slots + 1) * 8));
@@ -239,12 +233,12 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         if ((rc = reset_status(c, false))) return rc;
         ClassifyArgs a{};
         a.gaf = c->d_gaf; a.n_bytes = n; a.base_offset = base_offset; a.g = c->gv;
-        a.dict_names_len = c->names_len; a.dict_in_lds = c->dict_in_lds; a.all_slow = all_slow; a.want_hits = want_hits != 0;
+        a.all_slow = all_slow; a.want_hits = want_hits != 0;
         a.n_chunks = (uint32_t)((n + CHUNK - 1) / CHUNK);
         { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob for profiling only
         a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
         a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
-        size_t lds = LDS_MAIN + (c->dict_in_lds ? c->dict_bytes : 0);
+        size_t lds = LDS_MAIN;
         uint32_t grid = a.n_chunks < (uint32_t)c->n_cu * 2 ? a.n_chunks : (uint32_t)c->n_cu * 2;
         if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));

@@ -1,5 +1,6 @@
-// Host-side helper shared by the library's graph upload and the host test harness: builds the
-// open-addressing chromosome-name hash table that svjg::chrom_lookup probes.
+// Host-side table builders shared by the library's graph upload and the host test harness:
+// the open-addressing chromosome-name hash table that svjg::chrom_lookup probes (exact path) and the
+// name / link hash tables of the main kernel.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -30,83 +31,78 @@ inline std::vector<uint32_t> build_chrom_hash(const svjg_graph &g) {
 
 }  // namespace svjg
 
-namespace svjg {
-
-// Position buckets for the node lookup: for chromosome c, bucket b covers positions [b << shift, (b+1) << shift);
-// table[base[c] + b] = index of the first node of c whose pos >= b << shift, with one closing entry per chromosome,
-// so a node with position p lives in [table[base+b], table[base+b+1]) for b = p >> shift.
-struct BucketTable {
-    uint32_t shift = 0;
-    std::vector<uint32_t> base;      // n_chrom + 1 (base[c+1] - base[c] - 1 = number of buckets of c)
-    std::vector<uint32_t> table;
-};
-
-inline BucketTable build_buckets(const svjg_graph &g) {
-    BucketTable bt;
-    auto pos_of = [&](uint64_t i) { return (uint32_t)((g.nodes[i].key >> 16) & 0xFFFFFFFFull); };
-    uint64_t want = 2 * g.n_nodes + 1024;
-    for (bt.shift = 0; bt.shift < 32; ++bt.shift) {
-        uint64_t tot = 0;
-        for (uint32_t c = 0; c < g.n_chrom; ++c) {
-            uint32_t lo = g.chrom_node_lo[c], hi = g.chrom_node_lo[c + 1];
-            tot += (hi > lo ? ((uint64_t)pos_of(hi - 1) >> bt.shift) + 1 : 0) + 1;
-        }
-        if (tot <= want) break;
-    }
-    bt.base.assign(g.n_chrom + 1, 0);
-    for (uint32_t c = 0; c < g.n_chrom; ++c) {
-        uint32_t lo = g.chrom_node_lo[c], hi = g.chrom_node_lo[c + 1];
-        uint32_t nb = hi > lo ? (pos_of(hi - 1) >> bt.shift) + 1 : 0;
-        bt.base[c + 1] = bt.base[c] + nb + 1;
-    }
-    bt.table.assign(bt.base[g.n_chrom] + 1, 0);
-    for (uint32_t c = 0; c < g.n_chrom; ++c) {
-        uint32_t lo = g.chrom_node_lo[c], hi = g.chrom_node_lo[c + 1];
-        uint32_t nb = bt.base[c + 1] - bt.base[c] - 1, i = lo;
-        for (uint32_t b = 0; b <= nb; ++b) {
-            while (i < hi && (pos_of(i) >> bt.shift) < b) ++i;
-            bt.table[bt.base[c] + b] = i;
-        }
-    }
-    return bt;
-}
-
-}  // namespace svjg
+#include <string>
 
 namespace svjg {
 
-// Word-based chromosome dictionary for the main kernel: names of up to 16 bytes as four little-endian words
-// (zero padded) + length, found through an open-addressing table keyed by chrom_word_hash (same function on
-// the device, svjg_line.h).  Longer names are left out: alignments that use them take the exact path.
-struct ChromWords {
-    std::vector<uint32_t> w4;        // n_chrom * 4
-    std::vector<uint32_t> table;     // value = chrom index + 1, 0 = empty
-};
+// ---- hash tables of the main kernel --------------------------------------------------------------------
+// NAME TABLE: canonical node name (<= 32 bytes, zero padded to eight words) -> node.  The kernel hashes the raw
+// bytes of a path segment and compares them with the stored spelling: no number parsing on the device, and
+// only names spelled exactly like the graph's can match (anything else goes to the exact path).
+//   entry = 16 words: [0..7] name, [8] byte length | flags << 8 (bit 0 hazard-prone, bit 1 length unknown),
+//                     [9] node id, [10] node length in bp, [11..15] unused.   byte length 0 = empty slot.
+// LINK TABLE: (left id, left strand, right id, right strand) -> hits, same content as the CSR rows.
+//   entry = 8 words: [0] key low, [1] key high, [2] n_hits, [3] h0, [4] h1 (n_hits > 2: h0 = index into hits[]).
+//   key = left << 33 | left strand << 32 | right << 1 | right strand ; all ones = empty slot.
+constexpr uint32_t NAME_ENT_WORDS = 16, LINK_ENT_WORDS = 8;
 
-inline uint32_t chrom_word_hash_host(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t len) {
-    uint32_t h = (c0 * 0x9E3779B1u) ^ (c1 * 0x85EBCA77u) ^ (c2 * 0xC2B2AE3Du) ^ (c3 * 0x27D4EB2Fu) ^ (len * 0x165667B1u);
-    return h ^ (h >> 15);
+inline uint32_t name_hash_host(const uint32_t *d, uint32_t len) {
+    static const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+    uint32_t h = len * 0x7FEB352Du;
+    for (int i = 0; i < 8; ++i) h += d[i] * C[i];
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
 }
 
-inline ChromWords build_chrom_words(const svjg_graph &g) {
-    ChromWords cw;
-    uint32_t sz = 8;
-    while (sz < 2 * g.n_chrom + 2) sz *= 2;
-    cw.table.assign(sz, 0);
-    cw.w4.assign((size_t)g.n_chrom * 4 + 4, 0);
-    for (uint32_t c = 0; c < g.n_chrom; ++c) {
-        uint32_t o = g.chrom_off[c], n = g.chrom_off[c + 1] - o;
-        if (n == 0 || n > 16) { cw.w4[c * 4] = 0xFFFFFFFFu; continue; }          // never matches a masked name
-        uint8_t b[16] = {0};
-        for (uint32_t i = 0; i < n; ++i) b[i] = (uint8_t)g.chrom_names[o + i];
-        uint32_t w[4];
-        for (int i = 0; i < 4; ++i) w[i] = b[4 * i] | (b[4 * i + 1] << 8) | (b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
-        for (int i = 0; i < 4; ++i) cw.w4[c * 4 + i] = w[i];
-        uint32_t j = chrom_word_hash_host(w[0], w[1], w[2], w[3], n) & (sz - 1);
-        while (cw.table[j]) j = (j + 1) & (sz - 1);
-        cw.table[j] = c + 1;
+inline uint32_t link_hash_host(uint64_t key) {
+    uint32_t x = (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    return x;
+}
+
+struct KernelTables {
+    std::vector<uint32_t> names; uint32_t name_mask = 0;
+    std::vector<uint32_t> links; uint32_t link_mask = 0;
+};
+
+inline KernelTables build_kernel_tables(const svjg_graph &g) {
+    KernelTables kt;
+    uint64_t nsz = 16;
+    while (nsz < 2 * g.n_nodes + 2) nsz *= 2;
+    kt.names.assign(nsz * NAME_ENT_WORDS, 0);
+    kt.name_mask = (uint32_t)nsz - 1;
+    for (uint64_t i = 0; i < g.n_nodes; ++i) {
+        const svjg_node &nd = g.nodes[i];
+        uint32_t c = (uint32_t)(nd.key >> 48), pos = (uint32_t)(nd.key >> 16), kind = (uint32_t)(nd.key >> 15) & 1u, cnt = (uint32_t)nd.key & 0x7FFFu;
+        std::string nm(g.chrom_names + g.chrom_off[c], g.chrom_off[c + 1] - g.chrom_off[c]);
+        nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
+        if (nm.size() > 32) continue;                       // such a name can only be handled by the exact path
+        uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t b = 0; b < nm.size(); ++b) d[b >> 2] |= (uint32_t)(uint8_t)nm[b] << (8 * (b & 3));
+        uint32_t flags = ((nd.row & 0x80000000u) ? 1u : 0u) | ((kind && nd.aux == SVJG_LEN_UNKNOWN) ? 2u : 0u);
+        uint32_t len_bp = kind ? nd.aux : nd.aux - pos + 1;
+        uint64_t j = name_hash_host(d, (uint32_t)nm.size()) & kt.name_mask;
+        while (kt.names[j * NAME_ENT_WORDS + 8] & 0xFFu) j = (j + 1) & kt.name_mask;
+        uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
+        for (int w = 0; w < 8; ++w) e[w] = d[w];
+        e[8] = (uint32_t)nm.size() | (flags << 8); e[9] = (uint32_t)i; e[10] = len_bp;
     }
-    return cw;
+    uint64_t lsz = 16;
+    while (lsz < 2 * g.n_edges + 2) lsz *= 2;
+    kt.links.assign(lsz * LINK_ENT_WORDS, 0xFFFFFFFFu);
+    kt.link_mask = (uint32_t)lsz - 1;
+    for (uint64_t n = 0; n < g.n_nodes; ++n) {
+        uint32_t a = g.nodes[n].row & 0x7FFFFFFFu, b = g.nodes[n + 1].row & 0x7FFFFFFFu;
+        for (uint32_t i = a; i < b; ++i) {
+            const svjg_edge &ed = g.edges[i];
+            uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
+            uint64_t j = link_hash_host(key) & kt.link_mask;
+            while (kt.links[j * LINK_ENT_WORDS] != 0xFFFFFFFFu || kt.links[j * LINK_ENT_WORDS + 1] != 0xFFFFFFFFu) j = (j + 1) & kt.link_mask;
+            uint32_t *e = &kt.links[j * LINK_ENT_WORDS];
+            e[0] = (uint32_t)key; e[1] = (uint32_t)(key >> 32); e[2] = ed.meta >> 2; e[3] = ed.h0; e[4] = ed.h1;
+        }
+    }
+    return kt;
 }
 
 }  // namespace svjg

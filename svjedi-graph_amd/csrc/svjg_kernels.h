@@ -18,17 +18,21 @@
 
 namespace svjg {
 
-constexpr uint32_t WG = 192;                     // classify kernel: 3 waves; two workgroups per CU (LDS-bound)
+#ifndef SVJG_WG
+#define SVJG_WG 256
+#define SVJG_PIECES 10
+#define SVJG_NMAX 1152
+#endif
+constexpr uint32_t WG = SVJG_WG;                   // classify kernel: 3 waves; two workgroups per CU (LDS-bound)
 constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
-constexpr uint32_t PIECES = 13;                  // 16-byte pieces of text per lane and stripe
+constexpr uint32_t PIECES = SVJG_PIECES;                 // 16-byte pieces of text per lane and stripe
 constexpr uint32_t SPAN = PIECES * 16;           // 208 B of byte classification per lane
 constexpr uint32_t TEXT = SPAN * WG;             // 39 KB staged in LDS
 constexpr uint32_t LOOK = 4 * 1024;              // look-ahead so that lines starting in the stripe are complete
 constexpr uint32_t CHUNK = TEXT - LOOK;          // bytes of text owned by one workgroup iteration (a "stripe")
 constexpr uint32_t MAXSTARTS = TEXT / 24 + 8;    // a valid line has >= 24 bytes incl. its terminator
 constexpr uint32_t KMAX = 16;                    // path nodes per alignment handled by the main kernel
-constexpr uint32_t NMAX = 1280;                  // path nodes per round of WG lines
-constexpr uint32_t DICT_LDS_MAX = 1024;          // chromosome dictionary is copied to LDS when it fits
+constexpr uint32_t NMAX = SVJG_NMAX;                 // path nodes per round of WG lines
 
 // LDS carve-up of k_classify_main (bytes)
 constexpr uint32_t L_TEXT = 0;
@@ -49,8 +53,7 @@ constexpr uint32_t L_NFIRST = L_NLINE + NMAX * 2;                          // u1
 constexpr uint32_t L_NID = L_NFIRST + NMAX * 2;                            // u32[NMAX]
 constexpr uint32_t L_NPRE = L_NID + NMAX * 4;                              // u32[NMAX]  length, then inclusive prefix
 constexpr uint32_t L_MISC = L_NPRE + NMAX * 4;                             // u32[16]
-constexpr uint32_t L_DICT = L_MISC + 64;
-constexpr uint32_t LDS_MAIN = L_DICT;                                      // + dictionary bytes when staged
+constexpr uint32_t LDS_MAIN = L_MISC + 64;
 
 // status words (device)
 struct DevStatus {
@@ -67,8 +70,6 @@ struct ClassifyArgs {
     uint64_t n_bytes;
     uint64_t base_offset;
     GraphView g;                         // global-memory views
-    uint32_t dict_names_len;             // bytes of chromosome names
-    uint32_t dict_in_lds;
     uint32_t all_slow;
     uint32_t want_hits;
     uint32_t n_chunks;
@@ -150,60 +151,52 @@ struct BitCursor {
     }
 };
 
-// Node name text[a0, a0+L) = chrom ':' A ('-' | '.') B with canonical decimals and a chromosome of the dictionary
-// -> (cidx, A, B, kind).  Straight-line: the 32 name bytes are classified digit / non-digit with SWAR, the two
-// separators are the two highest non-digits, A and B go through field_dec, the chromosome is matched as four words.
-__device__ inline bool parse_name(const GraphView &g, const uint8_t *text, uint32_t a0, uint32_t L,
-                                  uint32_t &cidx, uint32_t &v1, uint32_t &v2, uint32_t &kind) {
+// Path segment text[a0, a0+L) -> its entry in the node-name hash table (svjg_host_tables.h), or nullptr.  The raw
+// bytes are hashed and compared with the stored spelling: only names written exactly like the graph's match.
+__device__ inline const uint32_t *name_probe(const GraphView &g, const uint8_t *text, uint32_t a0, uint32_t L) {
+    if (L - 1u > 31u) return nullptr;                                  // 1 .. 32 bytes
     const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
     const uint32_t sh = a0 & 3u;
-    uint32_t d[8], M = 0;
+    uint32_t d[8];
     uint32_t prev = w[0];
+    uint32_t h = L * 0x7FEB352Du;
+    const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
 #pragma unroll
     for (uint32_t i = 0; i < 8; ++i) {
         const uint32_t nx = w[i + 1];
-        d[i] = __builtin_amdgcn_alignbyte(nx, prev, sh);
+        const uint32_t nb = L > 4 * i ? L - 4 * i : 0u;                 // bytes of the name in this word
+        d[i] = __builtin_amdgcn_alignbyte(nx, prev, sh) & (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
         prev = nx;
-        const uint32_t t = d[i] ^ 0x30303030u;
-        M |= movemask4(((t + 0x76767676u) | t) & 0x80808080u) << (4 * i);      // bit = byte is not a digit
+        h += d[i] * C[i];
     }
-    bool ok = L - 3u <= 29u;                                                     // 3 <= L <= 32
-    const uint32_t Mv = M & (L >= 32 ? 0xFFFFFFFFu : ((1u << (L & 31u)) - 1u));
-    ok &= Mv != 0;
-    const uint32_t ps = 31u - (uint32_t)__builtin_clz(Mv | 1u);                  // B's separator: highest non-digit
-    const uint32_t Mc = Mv & ((1u << ps) - 1u);
-    ok &= Mc != 0;
-    const uint32_t pc = 31u - (uint32_t)__builtin_clz(Mc | 1u);                  // the ':' before A
-    const uint32_t sepc = text[a0 + ps], colc = text[a0 + pc];
-    kind = sepc == '.';
-    ok &= (sepc == '-' || sepc == '.') && colc == ':';
-    const uint32_t nd1 = ps - pc - 1u, nd2 = L - ps - 1u;
-    ok &= field_dec(text, a0 + pc + 1, a0 + ps, v1) & field_dec(text, a0 + ps + 1, a0 + L, v2);
-    // canonical spelling (no leading zeros): an n-digit number is >= 10^(n-1)
-    const uint32_t p10a = nd1 > 1 ? (nd1 == 2 ? 10u : nd1 == 3 ? 100u : nd1 == 4 ? 1000u : nd1 == 5 ? 10000u : nd1 == 6 ? 100000u : nd1 == 7 ? 1000000u : nd1 == 8 ? 10000000u : 100000000u) : 0u;
-    const uint32_t p10b = nd2 > 1 ? (nd2 == 2 ? 10u : nd2 == 3 ? 100u : nd2 == 4 ? 1000u : nd2 == 5 ? 10000u : nd2 == 6 ? 100000u : nd2 == 7 ? 1000000u : nd2 == 8 ? 10000000u : 100000000u) : 0u;
-    ok &= v1 >= p10a && v2 >= p10b;
-    const uint32_t clen = pc;
-    ok &= clen - 1u <= 15u;                                                      // 1..16 bytes (longer names: exact path)
-    uint32_t c[4];
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-        const uint32_t nb = clen > 4 * i ? clen - 4 * i : 0u;
-        c[i] = d[i] & (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    for (uint32_t slot = h & g.name_mask;; slot = (slot + 1) & g.name_mask) {
+        const uint4 *e = (const uint4 *)(g.name_tab + (size_t)slot * 16);
+        const uint4 e2 = e[2];
+        if ((e2.x & 0xFFu) == 0) return nullptr;
+        const uint4 e0 = e[0], e1 = e[1];
+        if ((e2.x & 0xFFu) == L && e0.x == d[0] && e0.y == d[1] && e0.z == d[2] && e0.w == d[3] &&
+            e1.x == d[4] && e1.y == d[5] && e1.z == d[6] && e1.w == d[7]) return (const uint32_t *)e;
     }
-    cidx = NONE32;
-    if (ok) cidx = chrom_lookup_words(g, c[0], c[1], c[2], c[3], clen);
-    return ok && cidx != NONE32 && !(kind && v2 >= 32768);
+}
+
+// (left, left strand, right, right strand) -> entry of the link hash table, or nullptr
+__device__ inline const uint32_t *link_probe(const GraphView &g, uint32_t l, uint32_t sl, uint32_t r, uint32_t sr) {
+    const uint32_t klo = (r << 1) | sr, khi = (l << 1) | sl | (r >> 31);
+    uint32_t x = klo ^ (khi * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
+    for (uint32_t slot = x & g.link_mask;; slot = (slot + 1) & g.link_mask) {
+        const uint32_t *e = g.link_tab + (size_t)slot * 8;
+        const uint2 k = *(const uint2 *)e;
+        if (k.x == klo && k.y == khi) return e;
+        if ((k.x & k.y) == 0xFFFFFFFFu) return nullptr;
+    }
 }
 
 #ifndef SVJG_UBN
 #define SVJG_UBN 3
 #endif
-#ifndef SVJG_UBL
-#define SVJG_UBL 2
-#endif
 constexpr uint32_t UB = SVJG_UBN;                // path nodes handled per lane at a time (independent loads in flight)
-constexpr uint32_t UL = SVJG_UBL;                // path steps handled per lane at a time
 
 // The classify kernel.  One workgroup walks stripes of the GAF text; the next stripe's HBM loads are issued into
 // registers before the current one is processed, so the only HBM read of the text overlaps the parse.  Per stripe:
@@ -221,7 +214,7 @@ constexpr uint32_t UL = SVJG_UBL;                // path steps handled per lane 
 //   R5 one path STEP (link) per lane: overlap test on the prefix sums, link lookup in the node's CSR row, one 64-bit
 //      atomic (ref | alt << 32) per hit, optional hit records
 //   R6 deferred-line offsets, one aggregated atomic per wave
-__global__ __launch_bounds__(WG, 2) void k_classify_main(ClassifyArgs a) {
+__global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify_main(ClassifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *text = lds + L_TEXT;
     uint16_t *tabbm16 = (uint16_t *)(lds + L_TABBM), *oribm16 = (uint16_t *)(lds + L_ORIBM);
@@ -233,20 +226,10 @@ __global__ __launch_bounds__(WG, 2) void k_classify_main(ClassifyArgs a) {
     uint16_t *n_pos = (uint16_t *)(lds + L_NPOS), *n_line = (uint16_t *)(lds + L_NLINE), *n_first = (uint16_t *)(lds + L_NFIRST);
     uint32_t *n_id = (uint32_t *)(lds + L_NID), *n_pre = (uint32_t *)(lds + L_NPRE);
     uint32_t *misc = (uint32_t *)(lds + L_MISC);
-    uint8_t *dict = lds + L_DICT;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
 
-    GraphView g = a.g;
-    if (a.dict_in_lds) {
-        // off[n+1] | bkt_base[n+1] | w4[4n] | wtab[mask+1]
-        const uint32_t n1 = g.n_chrom + 1, ws = g.wtab_mask + 1;
-        uint32_t *d_off = (uint32_t *)dict, *d_bb = d_off + n1, *d_w4 = d_bb + n1, *d_wt = d_w4 + 4 * g.n_chrom;
-        for (uint32_t i = tid; i < n1; i += WG) { d_off[i] = g.chrom_off[i]; d_bb[i] = g.bkt_base[i]; }
-        for (uint32_t i = tid; i < 4 * g.n_chrom; i += WG) d_w4[i] = g.chrom_w4[i];
-        for (uint32_t i = tid; i < ws; i += WG) d_wt[i] = g.chrom_wtab[i];
-        g.chrom_off = d_off; g.bkt_base = d_bb; g.chrom_w4 = d_w4; g.chrom_wtab = d_wt;
-    }
+    const GraphView g = a.g;
 
     unsigned long long wg_lines = 0;
     unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -418,16 +401,15 @@ __global__ __launch_bounds__(WG, 2) void k_classify_main(ClassifyArgs a) {
             __syncthreads();
             SVJG_STAMP(3);
             const uint32_t n_nodes = (a.diag & 2u) ? 0u : misc[3];
-            // ---- R3: one node per lane, UB nodes in flight per lane ------------------------------------------------
+            // ---- R3: one node per lane (UB per lane, so that their table probes overlap) ------------------------------
             for (uint32_t nb = 0; nb < n_nodes; nb += UB * WG) {
-                uint32_t nn[UB], lnv[UB], cidx[UB], v1[UB], v2[UB], kind[UB], lo[UB], hi[UB], end[UB];
-                unsigned long long key[UB];
-                bool live[UB], good[UB];
+                uint32_t nn[UB], lnv[UB];
+                const uint32_t *ent[UB];
+                bool live[UB];
 #pragma unroll
                 for (uint32_t u = 0; u < UB; ++u) {
                     nn[u] = nb + u * WG + tid;
-                    live[u] = false; good[u] = false; lo[u] = hi[u] = end[u] = 0; key[u] = 0; lnv[u] = 0;
-                    cidx[u] = NONE32; v1[u] = v2[u] = kind[u] = 0;
+                    live[u] = false; ent[u] = nullptr; lnv[u] = 0;
                     if (nn[u] < n_nodes) {
                         lnv[u] = n_line[nn[u]] & 0x7FFFu;
                         const uint32_t meta = l_meta[lnv[u]];
@@ -437,39 +419,19 @@ __global__ __launch_bounds__(WG, 2) void k_classify_main(ClassifyArgs a) {
                             const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
                             const uint32_t b0 = (nn[u] + 1 < lnb + lk) ? (uint32_t)n_pos[nn[u] + 1] - 1u : (uint32_t)l_pend[lnv[u]];
                             if (text[a0 - 1] == '<') n_line[nn[u]] = (uint16_t)(lnv[u] | 0x8000u);
-                            good[u] = parse_name(g, text, a0, b0 - a0, cidx[u], v1[u], v2[u], kind[u]);
+                            if (!(a.diag & 4u)) ent[u] = name_probe(g, text, a0, b0 - a0);
                         }
                     }
                 }
-                // position buckets -> candidate range in the sorted node table
-#pragma unroll
-                for (uint32_t u = 0; u < UB; ++u) {
-                    if (good[u]) {
-                        key[u] = node_key(cidx[u], v1[u], kind[u], kind[u] ? v2[u] : 0);
-                        const uint32_t b0 = g.bkt_base[cidx[u]], nbk = g.bkt_base[cidx[u] + 1] - b0 - 1, b = v1[u] >> g.bkt_shift;
-                        if (b < nbk && !(a.diag & 4u)) { lo[u] = g.bkt[b0 + b]; end[u] = hi[u] = g.bkt[b0 + b + 1]; }
-                    }
-                }
-                for (;;) {                                               // joint binary search, loads of the UB nodes overlap
-                    unsigned long long kk[UB]; uint32_t mid[UB]; bool any = false;
-#pragma unroll
-                    for (uint32_t u = 0; u < UB; ++u) { mid[u] = (lo[u] + hi[u]) >> 1; kk[u] = 0; if (lo[u] < hi[u]) { kk[u] = g.nodes[mid[u]].key; any = true; } }
-                    if (!any) break;
-#pragma unroll
-                    for (uint32_t u = 0; u < UB; ++u) if (lo[u] < hi[u]) { if (kk[u] < key[u]) lo[u] = mid[u] + 1; else hi[u] = mid[u]; }
-                }
-                svjg_node nd[UB];
-#pragma unroll
-                for (uint32_t u = 0; u < UB; ++u) { nd[u].key = 0; nd[u].aux = 0; nd[u].row = 0; if (good[u] && lo[u] < end[u]) nd[u] = g.nodes[lo[u]]; }
 #pragma unroll
                 for (uint32_t u = 0; u < UB; ++u) {
                     if (live[u]) {
                         uint32_t id = NONE32, len = 0;
-                        if (good[u] && lo[u] < end[u] && nd[u].key == key[u] && !(nd[u].row & 0x80000000u)) {   // hazard-prone names: exact path
-                            if (kind[u]) { if (nd[u].aux != SVJG_LEN_UNKNOWN) { id = lo[u]; len = nd[u].aux; } }
-                            else if (nd[u].aux == v2[u]) { id = lo[u]; len = v2[u] - v1[u] + 1; }
+                        if (ent[u]) {
+                            const uint4 e2 = ((const uint4 *)ent[u])[2];     // byte length | flags << 8, node id, length in bp
+                            if (!(e2.x & 0x300u)) { id = e2.y; len = e2.z; }  // hazard-prone name / unknown alt length: exact path
                         }
-                        if ((a.diag & 4u) && good[u]) { id = 0; len = v2[u] - v1[u] + 1; }
+                        if (a.diag & 4u) { id = 0; len = 100; }
                         n_id[nn[u]] = id; n_pre[nn[u]] = len;
                         if (id == NONE32) atomicOr(&l_meta[lnv[u]], ST_DEFER << 24);              // ST_OK | ST_DEFER == ST_DEFER
                     }
@@ -501,54 +463,35 @@ __global__ __launch_bounds__(WG, 2) void k_classify_main(ClassifyArgs a) {
             }
             __syncthreads();
             SVJG_STAMP(5);
-            // ---- R5: one path step per lane, UL steps in flight per lane ------------------------------------------------
-            for (uint32_t nb = 0; nb < n_nodes; nb += UL * WG) {
-                uint32_t lnv[UL], idl[UL], idr[UL], want[UL], ra[UL], rb[UL], hit_e[UL];
-                bool go[UL];
-#pragma unroll
-                for (uint32_t u = 0; u < UL; ++u) {
-                    const uint32_t n = nb + u * WG + tid;
-                    go[u] = false; lnv[u] = 0; idl[u] = idr[u] = 0; want[u] = 0; ra[u] = rb[u] = 0; hit_e[u] = NONE32;
-                    if (n + 1 < n_nodes) {
-                        const uint32_t ln = n_line[n] & 0x7FFFu;
-                        const uint32_t meta = l_meta[ln];
-                        const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
-                        if ((meta >> 24) == ST_OK && n + 1 < lnb + lk) {
-                            // the reference evaluates the link (name, strand) of the FIRST occurrence of each name
-                            // (str.split / list.index, filter-alignments.py:206, :269-271)
-                            const uint32_t fl = n_first[n], fr = n_first[n + 1];
-                            const long long left = (long long)n_pre[fl] - (long long)l_ts[ln];
-                            const long long pre_excl_r = fr > lnb ? (long long)n_pre[fr - 1] : 0;
-                            const long long right = (long long)l_tot[ln] - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
-                            if (left >= (long long)g.d_over && right >= (long long)g.d_over) {
-                                go[u] = true; lnv[u] = ln; idl[u] = n_id[n]; idr[u] = n_id[n + 1];
-                                want[u] = (uint32_t)(n_line[fl] >> 15) | ((uint32_t)(n_line[fr] >> 15) << 1);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < UL; ++u) if (go[u]) { ra[u] = g.nodes[idl[u]].row & 0x7FFFFFFFu; rb[u] = g.nodes[idl[u] + 1].row & 0x7FFFFFFFu; }
-                for (uint32_t e = 0;; ++e) {                             // CSR rows are a handful of entries; the UL rows are walked together
-                    svjg_edge ed[UL]; bool any = false;
-#pragma unroll
-                    for (uint32_t u = 0; u < UL; ++u) { ed[u].right = NONE32; ed[u].meta = 0; ed[u].h0 = ed[u].h1 = 0; if (go[u] && hit_e[u] == NONE32 && ra[u] + e < rb[u]) { ed[u] = g.edges[ra[u] + e]; any = true; } }
-                    if (!any) break;
-#pragma unroll
-                    for (uint32_t u = 0; u < UL; ++u) {
-                        if (go[u] && hit_e[u] == NONE32 && ra[u] + e < rb[u] && ed[u].right == idr[u] && (ed[u].meta & 3u) == want[u]) {
-                            hit_e[u] = ra[u] + e;
-                            const uint32_t nh = ed[u].meta >> 2;
-                            for (uint32_t j = 0; j < nh; ++j) {
-                                const uint32_t hv = edge_hit(g, ed[u], j);
-                                if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
-                                if (a.want_hits) {
-                                    unsigned long long idx = atomicAdd(&a.st->n_recs, 1ull);
-                                    if (idx < a.rec_cap) {
-                                        svjg_hitrec r; r.line_start = a.base_offset + c0 + l_start[lnv[u]]; r.slot = hv >> 1;
-                                        r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
-                                        a.recs[idx] = r;
-                                    } else atomicOr(&a.st->overflow, 2u);
+            // ---- R5: one path step per lane --------------------------------------------------------------------------
+            for (uint32_t nb = 0; nb < n_nodes; nb += WG) {
+                const uint32_t n = nb + tid;
+                if (n + 1 < n_nodes) {
+                    const uint32_t ln = n_line[n] & 0x7FFFu;
+                    const uint32_t meta = l_meta[ln];
+                    const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
+                    if ((meta >> 24) == ST_OK && n + 1 < lnb + lk) {
+                        // the reference evaluates the link (name, strand) of the FIRST occurrence of each name
+                        // (str.split / list.index, filter-alignments.py:206, :269-271)
+                        const uint32_t fl = n_first[n], fr = n_first[n + 1];
+                        const long long left = (long long)n_pre[fl] - (long long)l_ts[ln];
+                        const long long pre_excl_r = fr > lnb ? (long long)n_pre[fr - 1] : 0;
+                        const long long right = (long long)l_tot[ln] - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
+                        if (left >= (long long)g.d_over && right >= (long long)g.d_over) {
+                            const uint32_t *e = link_probe(g, n_id[n], n_line[fl] >> 15, n_id[n + 1], n_line[fr] >> 15);
+                            if (e) {
+                                const uint32_t nh = e[2], h0 = e[3], h1 = e[4];
+                                for (uint32_t j = 0; j < nh; ++j) {
+                                    const uint32_t hv = nh <= 2 ? (j == 0 ? h0 : h1) : g.hits[h0 + j];
+                                    if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
+                                    if (a.want_hits) {
+                                        unsigned long long idx = atomicAdd(&a.st->n_recs, 1ull);
+                                        if (idx < a.rec_cap) {
+                                            svjg_hitrec r; r.line_start = a.base_offset + c0 + l_start[ln]; r.slot = hv >> 1;
+                                            r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
+                                            a.recs[idx] = r;
+                                        } else atomicOr(&a.st->overflow, 2u);
+                                    }
                                 }
                             }
                         }

@@ -36,31 +36,12 @@ struct GraphView {
     uint32_t n_chrom;
     uint32_t hash_mask;
     uint32_t d_over;
-    const uint32_t *bkt_base;    // n_chrom + 1 : first position bucket of each chromosome (svjg_host_tables.h)
-    const uint32_t *bkt;         // bucket -> first node at or after the bucket's first position
-    uint32_t bkt_shift;
-    const uint32_t *chrom_w4;    // n_chrom x 4 words: names of <= 16 bytes, zero padded (main kernel dictionary)
-    const uint32_t *chrom_wtab;  // open addressing on chrom_word_hash, value = chrom index + 1
-    uint32_t wtab_mask;
+    const uint32_t *name_tab;    // main kernel: canonical node name -> node (svjg_host_tables.h), 16 words per entry
+    uint32_t name_mask;
+    const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 8 words per entry
+    uint32_t link_mask;
 };
 
-SVJG_HD uint32_t chrom_word_hash(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t len) {
-    uint32_t h = (c0 * 0x9E3779B1u) ^ (c1 * 0x85EBCA77u) ^ (c2 * 0xC2B2AE3Du) ^ (c3 * 0x27D4EB2Fu) ^ (len * 0x165667B1u);
-    return h ^ (h >> 15);
-}
-
-// chromosome of a name given as four zero-padded words + length (<= 16), or NONE32
-SVJG_HD uint32_t chrom_lookup_words(const GraphView &g, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t len) {
-    uint32_t i = chrom_word_hash(c0, c1, c2, c3, len) & g.wtab_mask;
-    for (;;) {
-        const uint32_t v = g.chrom_wtab[i];
-        if (v == 0) return NONE32;
-        const uint32_t c = v - 1;
-        const uint32_t *w = g.chrom_w4 + 4 * c;
-        if (w[0] == c0 && w[1] == c1 && w[2] == c2 && w[3] == c3 && g.chrom_off[c + 1] - g.chrom_off[c] == len) return c;
-        i = (i + 1) & g.wtab_mask;
-    }
-}
 
 SVJG_HD bool py_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 
@@ -96,20 +77,6 @@ SVJG_HD uint32_t node_search(const GraphView &g, uint32_t cidx, uint64_t key) {
         if (k < key) lo = mid + 1; else hi = mid;
     }
     return (lo < g.chrom_lo[cidx + 1] && g.nodes[lo].key == key) ? lo : NONE32;
-}
-
-// same result through the position buckets: two dependent loads in the common case
-SVJG_HD uint32_t node_lookup(const GraphView &g, uint32_t cidx, uint32_t pos, uint64_t key) {
-    const uint32_t b0 = g.bkt_base[cidx], nb = g.bkt_base[cidx + 1] - b0 - 1, b = pos >> g.bkt_shift;
-    if (b >= nb) return NONE32;
-    uint32_t lo = g.bkt[b0 + b];
-    const uint32_t end = g.bkt[b0 + b + 1];
-    uint32_t hi = end;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (g.nodes[mid].key < key) lo = mid + 1; else hi = mid;
-    }
-    return (lo < end && g.nodes[lo].key == key) ? lo : NONE32;
 }
 
 // entry of the directed link (l, sl) -> (r, sr), or NONE32

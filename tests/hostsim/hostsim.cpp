@@ -15,13 +15,12 @@ struct CountEmit {
     void operator()(uint32_t slot, uint32_t allele) { counts[slot * 2 + allele]++; }
 };
 
-static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &hash, const BucketTable &bt) {
+static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &hash) {
     GraphView v;
     v.nodes = g->nodes; v.n_nodes = (uint32_t)g->n_nodes; v.edges = g->edges; v.hits = g->hits;
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
-    v.bkt_base = bt.base.data(); v.bkt = bt.table.data(); v.bkt_shift = bt.shift;
-    v.chrom_w4 = nullptr; v.chrom_wtab = nullptr; v.wtab_mask = 0;       // main-kernel dictionary: not used by the exact path
+    v.name_tab = nullptr; v.name_mask = 0; v.link_tab = nullptr; v.link_mask = 0;     // main-kernel tables: not used by the exact path
     return v;
 }
 
@@ -29,8 +28,7 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
                                 uint32_t *counts, uint64_t *n_lines, int *exc, uint64_t *err_off)
 {
     std::vector<uint32_t> hash = build_chrom_hash(*g);
-    BucketTable bt = build_buckets(*g);
-    GraphView v = make_view(g, hash, bt);
+    GraphView v = make_view(g, hash);
     const uint8_t *t = (const uint8_t *)gaf;
     *n_lines = 0; *exc = 0; *err_off = 0;
     uint64_t pos = 0;
@@ -47,22 +45,33 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
     return 0;
 }
 
-// every node must be found by both lookups; probes around every node must agree between the two
-extern "C" uint64_t hostsim_check_lookup(const svjg_graph *g) {
-    std::vector<uint32_t> hash = build_chrom_hash(*g);
-    BucketTable bt = build_buckets(*g);
-    GraphView v = make_view(g, hash, bt);
-    uint64_t bad = 0;
-    for (uint64_t i = 0; i < g->n_nodes; ++i) {
-        uint64_t key = g->nodes[i].key;
-        uint32_t c = (uint32_t)(key >> 48), pos = (uint32_t)(key >> 16);
-        if (node_search(v, c, key) != i || node_lookup(v, c, pos, key) != i) ++bad;
-        for (int d = -2; d <= 2; ++d) {
-            uint64_t k2 = key + ((int64_t)d << 16);
-            uint32_t p2 = (uint32_t)(k2 >> 16);
-            if ((uint32_t)(k2 >> 48) != c) continue;
-            if (node_search(v, c, k2) != node_lookup(v, c, p2, k2)) ++bad;
-        }
+// the main kernel's hash tables must agree with the sorted node table / CSR rows: every node name resolves to its
+// id, every CSR entry is found under its key with the same hits
+extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
+    KernelTables kt = build_kernel_tables(*g);
+    uint64_t bad = 0, found = 0;
+    for (uint64_t j = 0; j <= kt.name_mask; ++j) {
+        const uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
+        if (!(e[8] & 0xFFu)) continue;
+        ++found;
+        uint64_t q = name_hash_host(e, e[8] & 0xFFu) & kt.name_mask, steps = 0;
+        while (q != j && steps <= kt.name_mask) { if (!(kt.names[q * NAME_ENT_WORDS + 8] & 0xFFu)) { ++bad; break; } q = (q + 1) & kt.name_mask; ++steps; }
+        const svjg_node &nd = g->nodes[e[9]];
+        uint32_t kind = (uint32_t)(nd.key >> 15) & 1u, pos = (uint32_t)(nd.key >> 16);
+        if (e[10] != (kind ? nd.aux : nd.aux - pos + 1)) ++bad;
     }
+    if (found > g->n_nodes) ++bad;
+    for (uint64_t n = 0; n < g->n_nodes; ++n)
+        for (uint32_t i = g->nodes[n].row & 0x7FFFFFFFu; i < (g->nodes[n + 1].row & 0x7FFFFFFFu); ++i) {
+            const svjg_edge &ed = g->edges[i];
+            uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
+            uint64_t q = link_hash_host(key) & kt.link_mask;
+            for (;;) {
+                const uint32_t *e = &kt.links[q * LINK_ENT_WORDS];
+                if (e[0] == 0xFFFFFFFFu && e[1] == 0xFFFFFFFFu) { ++bad; break; }
+                if (e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32)) { if (e[2] != (ed.meta >> 2) || e[3] != ed.h0 || e[4] != ed.h1) ++bad; break; }
+                q = (q + 1) & kt.link_mask;
+            }
+        }
     return bad;
 }

@@ -25,8 +25,8 @@ def _lib():
     lib = ctypes.CDLL(build())
     lib.hostsim_classify.restype = ctypes.c_int
     lib.hostsim_classify.argtypes = [ctypes.POINTER(capi.CGraph), ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p] + [ctypes.c_void_p] * 3
-    lib.hostsim_check_lookup.restype = ctypes.c_uint64
-    lib.hostsim_check_lookup.argtypes = [ctypes.POINTER(capi.CGraph)]
+    lib.hostsim_check_tables.restype = ctypes.c_uint64
+    lib.hostsim_check_tables.argtypes = [ctypes.POINTER(capi.CGraph)]
     return lib, capi
 
 
@@ -45,7 +45,7 @@ def classify(graph, gaf):
     return counts[: graph.n_slots], nl.value
 
 
-def check_lookup(graph):
+def check_tables(graph):
     lib, capi = _lib()
     cg = capi.cgraph_of(graph)
-    return lib.hostsim_check_lookup(ctypes.byref(cg))
+    return lib.hostsim_check_tables(ctypes.byref(cg))

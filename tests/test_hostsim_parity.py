@@ -43,7 +43,7 @@ def test_testdir(golden):
     counts, n_lines = sim.classify(g, raw)
     ref = json.load(open(f"{t}/ref_informative_aln.json"))
     assert _as_dict(g, counts) == {k: [len(v[0]), len(v[1])] for k, v in ref.items()}
-    assert sim.check_lookup(g) == 0
+    assert sim.check_tables(g) == 0
 
 
 @pytest.mark.parametrize("tag", ["g6_mixed", "g6_del"])
@@ -53,7 +53,7 @@ def test_synth(golden, tag, tmp_path):
     pre = str(tmp_path / "s")
     synth.generate(prefix=pre, **g6["args"])
     g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
-    assert sim.check_lookup(g) == 0          # position-bucket lookup == binary search, for hits and misses
+    assert sim.check_tables(g) == 0          # the kernel's name / link hash tables agree with the node table and CSR rows
     raw = open(pre + ".gaf", "rb").read()
     cut = raw[: 3_000_000]
     cut = cut[: cut.rfind(b"\n") + 1]
