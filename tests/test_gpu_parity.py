@@ -231,3 +231,20 @@ def test_c2_full_size(ctx, tmp_path):
     text, n_ref = O.genotype_vcf(head[:2000], D)
     assert open(pre + "_genotype.vcf").read().startswith(text)
     assert n >= n_ref
+
+
+def test_rccl_single_rank_allreduce(ctx, tmp_path):
+    """The RCCL path of libsvjg_hip (svjg_comm_init / svjg_allreduce_counts) with a one-rank communicator: the count
+    vector must come back unchanged.  (Multi-rank sharding + reduction logic: tests/test_shard_gloo.py.)"""
+    from svjg import capi, shard
+    pre, gaf, g, orc = _synth_case(tmp_path, 5000, 200, 2, "mixed", 21)
+    c2 = capi.Context(0)
+    try:
+        c2.load_graph(g)
+        c2.classify(gaf)
+        before = c2.counts()
+        grp = shard.RcclGroup(c2, 1, 0, lambda uid: uid)
+        grp.allreduce_counts()
+        assert np.array_equal(c2.counts(), before) and before.sum() > 0
+    finally:
+        c2.close()
