@@ -156,6 +156,12 @@ int svjg_genotype(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, c
                   uint64_t n_rows, uint32_t min_support, double err,
                   uint8_t *gt, int64_t *pl, uint32_t *raw, uint8_t *genotyped);
 
+/* ---- host-side writer of <prefix>_informative_aln.json (libsvjg_host.so, no GPU involved) -----------------
+ * Byte-identical to json.dumps(dict_of_informative_aln, sort_keys=True, indent=4) (filter-alignments.py:174-175)
+ * from the hit records: sv_ids[slot] is the key of each count slot, `gaf` the same bytes that were classified. */
+int svjg_write_informative_json(const char *path, const char *gaf, uint64_t n_bytes, const svjg_hitrec *recs,
+                                uint64_t n_recs, const char *const *sv_ids, uint32_t n_slots, int n_threads);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the kernels of the last classify / genotype ---- */
 int svjg_last_kernel_ms(svjg_ctx *ctx, float *classify_main_ms, float *classify_slow_ms, float *genotype_ms);
 int svjg_sync(svjg_ctx *ctx);

@@ -1,0 +1,180 @@
+// libsvjg_host.so — host-side writer of <prefix>_informative_aln.json (no GPU code in this file).
+//
+// Reproduces, byte for byte, what the reference writes with
+//     json.dumps(dict_of_informative_aln, sort_keys=True, indent=4)        (filter-alignments.py:174-175)
+// from the device's hit records: for every SV key (sorted by code point = UTF-8 byte order) the two lists of
+// alignment texts in file order, where a text is the line as Python's text mode delivers it (terminator
+// translated to "\n", absent at EOF) cut before the first "cg:Z:" (filter-alignments.py:166), escaped like
+// json's ensure_ascii=True.  Multi-threaded by key ranges, streamed to the file in order.
+#include "../../include/svjg.h"
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Job {
+    const uint8_t *gaf; uint64_t n;
+    const svjg_hitrec *recs;                 // grouped by slot, each group sorted by line_start
+    const uint64_t *slot_begin;              // n_slots + 1
+    const char *const *sv_ids;
+    const uint32_t *order; uint64_t n_keys;  // slots with >= 1 record, sorted by key
+};
+
+inline void hex4(std::string &o, uint32_t v) {
+    static const char *H = "0123456789abcdef";
+    o += "\\u"; o += H[(v >> 12) & 15]; o += H[(v >> 8) & 15]; o += H[(v >> 4) & 15]; o += H[v & 15];
+}
+
+// JSON string body with ensure_ascii=True; returns false on malformed UTF-8
+bool escape(std::string &o, const uint8_t *s, size_t n) {
+    for (size_t i = 0; i < n;) {
+        uint8_t c = s[i];
+        if (c < 0x80) {
+            switch (c) {
+                case '"': o += "\\\""; break;
+                case '\\': o += "\\\\"; break;
+                case '\n': o += "\\n"; break;
+                case '\r': o += "\\r"; break;
+                case '\t': o += "\\t"; break;
+                case '\b': o += "\\b"; break;
+                case '\f': o += "\\f"; break;
+                default: if (c < 0x20 || c == 0x7F) hex4(o, c); else o += (char)c;   // json escapes everything outside ' '..'~'
+            }
+            ++i;
+            continue;
+        }
+        uint32_t cp; size_t len;
+        if ((c & 0xE0) == 0xC0) { cp = c & 0x1F; len = 2; }
+        else if ((c & 0xF0) == 0xE0) { cp = c & 0x0F; len = 3; }
+        else if ((c & 0xF8) == 0xF0) { cp = c & 0x07; len = 4; }
+        else return false;
+        if (i + len > n) return false;
+        for (size_t k = 1; k < len; ++k) { if ((s[i + k] & 0xC0) != 0x80) return false; cp = (cp << 6) | (s[i + k] & 0x3F); }
+        if ((len == 2 && cp < 0x80) || (len == 3 && cp < 0x800) || (len == 4 && cp < 0x10000) || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+        if (cp >= 0x10000) { cp -= 0x10000; hex4(o, 0xD800 + (cp >> 10)); hex4(o, 0xDC00 + (cp & 0x3FF)); }
+        else hex4(o, cp);
+        i += len;
+    }
+    return true;
+}
+
+// escaped text of the line starting at `start`
+bool line_text(const Job &j, uint64_t start, std::string &o) {
+    uint64_t e = start;
+    while (e < j.n && j.gaf[e] != '\n' && j.gaf[e] != '\r') ++e;
+    // cut before the first "cg:Z:" (searched in the translated text: the tag cannot span the terminator)
+    uint64_t cut = e; bool tag = false;
+    for (uint64_t q = start; q + 5 <= e; ++q)
+        if (j.gaf[q] == 'c' && j.gaf[q + 1] == 'g' && j.gaf[q + 2] == ':' && j.gaf[q + 3] == 'Z' && j.gaf[q + 4] == ':') { cut = q; tag = true; break; }
+    if (!escape(o, j.gaf + start, (size_t)(cut - start))) return false;
+    if (!tag && e < j.n) o += "\\n";
+    return true;
+}
+
+bool render_key(const Job &j, uint64_t ki, std::string &o, std::string &tmp) {
+    const uint32_t slot = j.order[ki];
+    o += ki ? ",\n    \"" : "\n    \"";
+    const char *id = j.sv_ids[slot];
+    if (!escape(o, (const uint8_t *)id, strlen(id))) return false;
+    o += "\": [";
+    for (int allele = 0; allele < 2; ++allele) {
+        uint64_t cnt = 0;
+        for (uint64_t r = j.slot_begin[slot]; r < j.slot_begin[slot + 1]; ++r) {
+            const uint32_t rep = allele ? j.recs[r].n_alt : j.recs[r].n_ref;
+            if (!rep) continue;
+            tmp.clear();
+            if (!line_text(j, j.recs[r].line_start, tmp)) return false;
+            for (uint32_t k = 0; k < rep; ++k) {
+                o += cnt ? ",\n            \"" : "\n        [\n            \"";
+                o += tmp; o += '"';
+                ++cnt;
+            }
+        }
+        if (cnt) o += "\n        ]"; else o += "\n        []";
+        if (!allele) o += ",";
+    }
+    o += "\n    ]";
+    return true;
+}
+
+}  // namespace
+
+// recs: n_recs hit records (any order; line_start relative to `gaf`); sv_ids[slot] = key string of each count slot.
+// Returns 0, SVJG_E_ARG, SVJG_E_NOMEM (cannot open / write) or SVJG_E_INPUT (text is not valid UTF-8).
+extern "C" int svjg_write_informative_json(const char *path, const char *gaf, uint64_t n_bytes, const svjg_hitrec *recs_in,
+                                           uint64_t n_recs, const char *const *sv_ids, uint32_t n_slots, int n_threads)
+{
+    if (!path || (n_bytes && !gaf) || (n_recs && !recs_in) || (n_slots && !sv_ids)) return SVJG_E_ARG;
+    // group by slot (counting sort), then file order inside each group
+    std::vector<uint64_t> begin((size_t)n_slots + 1, 0);
+    for (uint64_t i = 0; i < n_recs; ++i) { if (recs_in[i].slot >= n_slots) return SVJG_E_ARG; begin[recs_in[i].slot + 1]++; }
+    for (uint32_t s = 0; s < n_slots; ++s) begin[s + 1] += begin[s];
+    std::vector<svjg_hitrec> recs(n_recs);
+    { std::vector<uint64_t> cur(begin.begin(), begin.end() - 1);
+      for (uint64_t i = 0; i < n_recs; ++i) recs[cur[recs_in[i].slot]++] = recs_in[i]; }
+    std::vector<uint32_t> order;
+    for (uint32_t s = 0; s < n_slots; ++s) if (begin[s + 1] > begin[s]) order.push_back(s);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return strcmp(sv_ids[a], sv_ids[b]) < 0; });
+
+    Job job{(const uint8_t *)gaf, n_bytes, recs.data(), begin.data(), sv_ids, order.data(), order.size()};
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return SVJG_E_NOMEM;
+    if (order.empty()) { fputs("{}", fp); return fclose(fp) ? SVJG_E_NOMEM : 0; }
+
+    const uint64_t CH = 256;                                   // keys per task
+    const uint64_t n_tasks = (order.size() + CH - 1) / CH;
+    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (T < 1) T = 1;
+    if ((uint64_t)T > n_tasks) T = (int)n_tasks;
+    std::vector<std::string> out(n_tasks);
+    std::vector<char> done(n_tasks, 0);
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> bad{0};
+    std::mutex mu; std::condition_variable cv;
+    uint64_t written = 0;                                      // tasks flushed so far (guards memory: workers stay <= 4T ahead)
+    auto worker = [&]() {
+        std::string tmp;
+        for (;;) {
+            uint64_t t = next.fetch_add(1);
+            if (t >= n_tasks) return;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return t < written + 4 * (uint64_t)T || bad.load(); }); }
+            if (bad.load()) return;
+            // every line of every group sorted by file order
+            std::string s;
+            for (uint64_t ki = t * CH; ki < std::min<uint64_t>((t + 1) * CH, order.size()); ++ki) {
+                const uint32_t slot = order[ki];
+                std::sort(recs.begin() + begin[slot], recs.begin() + begin[slot + 1],
+                          [](const svjg_hitrec &a, const svjg_hitrec &b) { return a.line_start < b.line_start; });
+                if (!render_key(job, ki, s, tmp)) { bad.store(1); break; }
+            }
+            { std::lock_guard<std::mutex> lk(mu); out[t].swap(s); done[t] = 1; }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < T; ++i) th.emplace_back(worker);
+    int rc = 0;
+    fputc('{', fp);
+    for (uint64_t t = 0; t < n_tasks && !rc; ++t) {
+        std::string s;
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done[t] || bad.load(); });
+          if (!done[t]) { rc = SVJG_E_INPUT; break; }
+          s.swap(out[t]); }
+        if (fwrite(s.data(), 1, s.size(), fp) != s.size()) rc = SVJG_E_NOMEM;
+        { std::lock_guard<std::mutex> lk(mu); written = t + 1; }
+        cv.notify_all();
+    }
+    if (rc) { bad.store(1); cv.notify_all(); }
+    for (auto &x : th) x.join();
+    if (!rc && bad.load()) rc = SVJG_E_INPUT;
+    if (!rc) fputs("\n}", fp);
+    if (fclose(fp) && !rc) rc = SVJG_E_NOMEM;
+    return rc;
+}

@@ -59,7 +59,6 @@ def main():
     out_vcf = pre + "_genotype.vcf"
     if args.fused:
         print("Filtering alignment file...")
-        import json
         from svjg import capi, filter as flt, genotype
         from svjg.graph import Graph
         try:
@@ -67,8 +66,7 @@ def main():
             ctx = capi.Context(0)
             counts, recs, data = flt.classify_file(ctx, graph, gaf, want_hits=not args.no_json)
             if not args.no_json:
-                with open(out_json, "w") as fh:
-                    fh.write(json.dumps(flt.informative_dict(graph, recs, data.tobytes()), sort_keys=True, indent=4))
+                capi.write_informative_json(out_json, data, recs, graph.sv_ids)
         except Exception:
             import traceback
             traceback.print_exc()

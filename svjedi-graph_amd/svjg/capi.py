@@ -9,6 +9,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(HERE), "csrc", "libsvjg_hip.so")
+HOST_LIB_PATH = os.path.join(os.path.dirname(HERE), "csrc", "libsvjg_host.so")
 
 HITREC_DT = np.dtype([("line_start", "<u8"), ("slot", "<u4"), ("n_ref", "<u2"), ("n_alt", "<u2")])
 
@@ -71,8 +72,37 @@ _SIGS = {
     "svjg_sync": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
-EXPORTS = tuple(_SIGS)
+EXPORTS = tuple(_SIGS) + ("svjg_write_informative_json",)
 _lib = None
+_host_lib = None
+
+
+def load_host_library():
+    """libsvjg_host.so: the native JSON writer (plain C++, no GPU)."""
+    global _host_lib
+    if _host_lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise SvjgError(f"{HOST_LIB_PATH} not found: build it first (python __graft_entry__.py build)")
+        lib = ctypes.CDLL(HOST_LIB_PATH)
+        lib.svjg_write_informative_json.restype = ctypes.c_int
+        lib.svjg_write_informative_json.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                                    ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.c_int]
+        _host_lib = lib
+    return _host_lib
+
+
+def write_informative_json(path, gaf, recs, sv_ids, n_threads=0):
+    """<prefix>_informative_aln.json from hit records (filter-alignments.py:174-175)."""
+    lib = load_host_library()
+    a = _as_u8(gaf)
+    recs = np.ascontiguousarray(recs, dtype=HITREC_DT)
+    keys = (ctypes.c_char_p * max(1, len(sv_ids)))(*[s.encode("utf-8") for s in sv_ids])
+    rc = lib.svjg_write_informative_json(os.fsencode(path), a.ctypes.data if a.size else None, a.size,
+                                         recs.ctypes.data if len(recs) else None, len(recs), keys, len(sv_ids), n_threads)
+    if rc == -10:
+        raise UnicodeDecodeError("utf-8", b"", 0, 1, "invalid UTF-8 in an informative alignment line")
+    if rc:
+        raise SvjgError(f"svjg_write_informative_json failed ({rc}) for {path}")
 
 
 def load_library(path=None):

@@ -1,11 +1,11 @@
 """Host side of the alignment filter: the part of filter-alignments.py that is file handling.
 
-    GAF bytes --svjg_classify (HIP)--> per-SV (ref, alt) counts + hit records --> <prefix>_informative_aln.json
+    GAF bytes --svjg_classify (HIP)--> per-SV (ref, alt) counts + hit records
+              --svjg_write_informative_json (native, host)--> <prefix>_informative_aln.json
 
-The classification itself (filter-alignments.py:123-166) happens in libsvjg_hip.so; nothing in this module
-looks inside an alignment line except to copy its text into the JSON the reference would have written.
+The classification itself (filter-alignments.py:123-166) happens in libsvjg_hip.so and the JSON text is produced by
+libsvjg_host.so; nothing in this module looks inside an alignment line.
 """
-import json
 import os
 
 import numpy as np
@@ -35,38 +35,6 @@ def read_gaf(path):
     return np.fromfile(path, dtype=np.uint8)
 
 
-def line_text(raw, start):
-    """What the reference stores for the line starting at `start` (filter-alignments.py:166): the text-mode
-    line (terminator translated to \\n, absent at EOF) up to the first 'cg:Z:'."""
-    n = len(raw)
-    a = raw.find(b"\n", start)
-    b = raw.find(b"\r", start)
-    e = min(x for x in (a, b, n) if x >= 0)
-    s = raw[start:e].decode("utf-8") + ("\n" if e < n else "")
-    return s.split("cg:Z:")[0]
-
-
-def informative_dict(graph, recs, raw):
-    """dict_of_informative_aln rebuilt from the device hit records (filter-alignments.py:160-166)."""
-    out = {}
-    if len(recs) == 0:
-        return out
-    order = np.lexsort((recs["line_start"], recs["slot"]))
-    recs = recs[order]
-    texts = {}
-    for r in recs:
-        st = int(r["line_start"])
-        t = texts.get(st)
-        if t is None:
-            t = texts[st] = line_text(raw, st)
-        ent = out.setdefault(graph.sv_ids[int(r["slot"])], [[], []])
-        if r["n_ref"]:
-            ent[0].extend([t] * int(r["n_ref"]))
-        if r["n_alt"]:
-            ent[1].extend([t] * int(r["n_alt"]))
-    return out
-
-
 def classify_file(ctx, graph, gaf_path, want_hits=True):
     """-> (counts[n_slots, 2], hit records, raw bytes)"""
     data = read_gaf(gaf_path)
@@ -86,7 +54,5 @@ def run(gaf_path, gfa_path, prefix, output_dir=None, device=0):
         counts, recs, data = classify_file(ctx, graph, gaf_path, want_hits=True)
     finally:
         ctx.close()
-    d = informative_dict(graph, recs, data.tobytes())
-    with open(out_json, "w") as fh:
-        fh.write(json.dumps(d, sort_keys=True, indent=4))
+    capi.write_informative_json(out_json, data, recs, graph.sv_ids)
     return counts, graph

@@ -14,11 +14,11 @@ def _declared(root):
 
 def test_every_declared_symbol_is_exported(root):
     from svjg import capi
-    lib = capi.load_library()
+    lib, host = capi.load_library(), capi.load_host_library()
     names = _declared(root)
     assert len(names) >= 20
     for n in names:
-        assert hasattr(lib, n), f"libsvjg_hip.so does not export {n}"
+        assert hasattr(lib, n) or hasattr(host, n), f"neither libsvjg_hip.so nor libsvjg_host.so exports {n}"
     assert set(names) == set(capi.EXPORTS), "svjg/capi.py prototypes and include/svjg.h disagree"
     assert lib.svjg_abi_version() == 1
 

@@ -1,0 +1,69 @@
+"""The native _informative_aln.json writer (libsvjg_host.so, product code) against the reference's own JSON files.
+No GPU needed: the hit records fed to it here come from the CPU oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as OC
+from oracle import oracle_py as O
+from svjg import capi
+
+QUIRKS = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "quirks"))
+                if f.endswith(".gaf"))
+
+
+def _recs_from_oracle(hits):
+    recs = np.zeros(len(hits), dtype=capi.HITREC_DT)
+    recs["line_start"] = hits["line_start"]
+    recs["slot"] = hits["sv"]
+    recs["n_ref"] = (hits["allele"] == 0).astype(np.uint16)
+    recs["n_alt"] = (hits["allele"] == 1).astype(np.uint16)
+    return recs
+
+
+@pytest.mark.parametrize("name", QUIRKS)
+def test_quirks(golden, name, tmp_path):
+    q = f"{golden}/quirks"
+    if json.load(open(f"{q}/manifest.json"))[name]["rc"]:
+        pytest.skip("the reference dies on this input")
+    orc = OC.COracle(O.load_edges(f"{q}/q_svs_edges.json"), O.load_alt_node_len(f"{q}/q.gfa"))
+    raw = open(f"{q}/{name}.gaf", "rb").read()
+    _, hits, _ = orc.filter(raw)
+    out = str(tmp_path / "o.json")
+    rng = np.random.default_rng(1)
+    recs = _recs_from_oracle(hits)
+    capi.write_informative_json(out, np.frombuffer(raw, dtype=np.uint8), recs[rng.permutation(len(recs))], orc.sv_ids, n_threads=3)
+    assert open(out).read() == open(f"{q}/{name}.ref.json").read()
+
+
+def test_testdir(golden, tmp_path):
+    t = f"{golden}/testdir"
+    orc = OC.COracle(O.load_edges(f"{t}/test_svs_edges.json"), O.load_alt_node_len(f"{t}/test.gfa"))
+    raw = open(f"{t}/test.gaf", "rb").read()
+    _, hits, _ = orc.filter(raw)
+    out = str(tmp_path / "o.json")
+    capi.write_informative_json(out, np.frombuffer(raw, dtype=np.uint8), _recs_from_oracle(hits), orc.sv_ids)
+    assert open(out).read() == open(f"{t}/ref_informative_aln.json").read()
+
+
+def test_synth_sha(golden, tmp_path):
+    import synth
+    g6 = json.load(open(f"{golden}/synth/g6.json"))["g6_mixed"]
+    pre = str(tmp_path / "s")
+    synth.generate(prefix=pre, **g6["args"])
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    raw = np.fromfile(pre + ".gaf", dtype=np.uint8)
+    _, hits, _ = orc.filter(raw)
+    out = str(tmp_path / "o.json")
+    capi.write_informative_json(out, raw, _recs_from_oracle(hits), orc.sv_ids, n_threads=8)
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == g6["sha256_json"]
+
+
+def test_invalid_utf8(tmp_path):
+    recs = np.zeros(1, dtype=capi.HITREC_DT)
+    recs["n_ref"] = 1
+    with pytest.raises(UnicodeDecodeError):
+        capi.write_informative_json(str(tmp_path / "o.json"), np.frombuffer(b"r\xff\tx\n", dtype=np.uint8), recs, ["1:DEL-1-2"])
