@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--aln", type=int, default=0, help="override alignments per rank")
+    ap.add_argument("--svs", type=int, default=0, help="override the number of SVs (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -67,6 +68,9 @@ def main():
     n_aln, n_sv, n_chrom, mix, seed, desc = WORKLOADS[args.workload]
     if args.aln:
         n_aln = args.aln
+    if args.svs:
+        n_sv = args.svs
+        desc += f" [--svs {n_sv}]"
 
     # ---- inputs (untimed) --------------------------------------------------------------------------
     t0 = time.time()

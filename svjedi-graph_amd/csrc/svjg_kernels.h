@@ -86,8 +86,10 @@ __device__ inline uint32_t zero_bytes(uint32_t t) {                    // 0x80 i
 }
 __device__ inline uint32_t movemask4(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
 __device__ inline uint32_t eq_mask16(uint4 v, uint32_t pat) {          // 16-bit mask of bytes equal to pat's byte
-    return movemask4(zero_bytes(v.x ^ pat)) | (movemask4(zero_bytes(v.y ^ pat)) << 4) |
-           (movemask4(zero_bytes(v.z ^ pat)) << 8) | (movemask4(zero_bytes(v.w ^ pat)) << 12);
+    // byte flags (0x80 / 0x00) gathered with two chained v_dot4_u32_u8 per half: weights 1,2,4,8 / 16,32,64,128
+    const uint32_t lo = __builtin_amdgcn_udot4(zero_bytes(v.x ^ pat), 0x08040201u, __builtin_amdgcn_udot4(zero_bytes(v.y ^ pat), 0x80402010u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(zero_bytes(v.z ^ pat), 0x08040201u, __builtin_amdgcn_udot4(zero_bytes(v.w ^ pat), 0x80402010u, 0u, false), false);
+    return (lo | (hi << 8)) >> 7;
 }
 
 __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
@@ -151,13 +153,11 @@ struct BitCursor {
     }
 };
 
-// Path segment text[a0, a0+L) -> its entry in the node-name hash table (svjg_host_tables.h), or nullptr.  The raw
-// bytes are hashed and compared with the stored spelling: only names written exactly like the graph's match.
-__device__ inline const uint32_t *name_probe(const GraphView &g, const uint8_t *text, uint32_t a0, uint32_t L) {
-    if (L - 1u > 31u) return nullptr;                                  // 1 .. 32 bytes
+// Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the slot hash of the node-name table
+// (svjg_host_tables.h: name_hash_host).
+__device__ inline uint32_t name_words(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
     const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
     const uint32_t sh = a0 & 3u;
-    uint32_t d[8];
     uint32_t prev = w[0];
     uint32_t h = L * 0x7FEB352Du;
     const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
@@ -165,38 +165,26 @@ __device__ inline const uint32_t *name_probe(const GraphView &g, const uint8_t *
     for (uint32_t i = 0; i < 8; ++i) {
         const uint32_t nx = w[i + 1];
         const uint32_t nb = L > 4 * i ? L - 4 * i : 0u;                 // bytes of the name in this word
-        d[i] = __builtin_amdgcn_alignbyte(nx, prev, sh) & (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
+        d[i] = __builtin_amdgcn_alignbyte(nx, prev, sh) & (nb >= 4 ? 0xFFFFFFFFu : ((1u << ((8 * nb) & 31u)) - 1u));
         prev = nx;
         h += d[i] * C[i];
     }
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-    for (uint32_t slot = h & g.name_mask;; slot = (slot + 1) & g.name_mask) {
-        const uint4 *e = (const uint4 *)(g.name_tab + (size_t)slot * 16);
-        const uint4 e2 = e[2];
-        if ((e2.x & 0xFFu) == 0) return nullptr;
-        const uint4 e0 = e[0], e1 = e[1];
-        if ((e2.x & 0xFFu) == L && e0.x == d[0] && e0.y == d[1] && e0.z == d[2] && e0.w == d[3] &&
-            e1.x == d[4] && e1.y == d[5] && e1.z == d[6] && e1.w == d[7]) return (const uint32_t *)e;
-    }
+    return h;
 }
 
-// (left, left strand, right, right strand) -> entry of the link hash table, or nullptr
-__device__ inline const uint32_t *link_probe(const GraphView &g, uint32_t l, uint32_t sl, uint32_t r, uint32_t sr) {
-    const uint32_t klo = (r << 1) | sr, khi = (l << 1) | sl | (r >> 31);
+__device__ inline bool name_match(const uint4 e0, const uint4 e1, const uint4 e2, const uint32_t d[8], uint32_t L) {
+    return (e2.x & 0xFFu) == L && e0.x == d[0] && e0.y == d[1] && e0.z == d[2] && e0.w == d[3] &&
+           e1.x == d[4] && e1.y == d[5] && e1.z == d[6] && e1.w == d[7];
+}
+
+__device__ inline uint32_t link_hash(uint32_t klo, uint32_t khi) {
     uint32_t x = klo ^ (khi * 0x9E3779B1u);
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
-    for (uint32_t slot = x & g.link_mask;; slot = (slot + 1) & g.link_mask) {
-        const uint32_t *e = g.link_tab + (size_t)slot * 8;
-        const uint2 k = *(const uint2 *)e;
-        if (k.x == klo && k.y == khi) return e;
-        if ((k.x & k.y) == 0xFFFFFFFFu) return nullptr;
-    }
+    return x;
 }
 
-#ifndef SVJG_UBN
-#define SVJG_UBN 3
-#endif
-constexpr uint32_t UB = SVJG_UBN;                // path nodes handled per lane at a time (independent loads in flight)
+constexpr uint32_t UB = 4;                       // path steps per lane / path nodes per lane quad handled at a time (loads in flight)
 
 // The classify kernel.  One workgroup walks stripes of the GAF text; the next stripe's HBM loads are issued into
 // registers before the current one is processed, so the only HBM read of the text overlaps the parse.  Per stripe:
@@ -239,11 +227,13 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
 
     // stripe prefetch registers
     uint4 pf[PIECES];
+    uint32_t pf_head = '\n';                                           // byte right before the stripe (decides whether it starts a line)
     auto prefetch = [&](uint32_t chunk) {                            // no bounds tests: the buffer is zero padded by TEXT + 64 bytes
         const uint64_t c0 = (uint64_t)(chunk < a.n_chunks ? chunk : a.n_chunks - 1) * CHUNK;
         const uint4 *src = (const uint4 *)(a.gaf + c0) + tid;
 #pragma unroll
         for (uint32_t i = 0; i < PIECES; ++i) pf[i] = src[i * WG];
+        pf_head = c0 ? a.gaf[c0 - 1] : (uint32_t)'\n';
     };
     prefetch(blockIdx.x);
 
@@ -260,6 +250,7 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
         }
         if (tid == 0) misc[0] = 0;
         if (hi_bits & 0x80808080u) a.st->non_ascii = 1;
+        const uint32_t head_byte = pf_head;
         __syncthreads();
         prefetch(chunk + gridDim.x);
         SVJG_STAMP(0);
@@ -292,13 +283,7 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
             cnt += __builtin_popcount(nl);
         }
         uint32_t head = 0;                                               // does the stripe begin at a line start?
-        if (tid == 0) {
-            if (c0 == 0) head = 1;
-            else {
-                uint8_t pb = a.gaf[c0 - 1];
-                head = (pb == '\n') || (pb == '\r' && text[0] != '\n');
-            }
-        }
+        if (tid == 0) head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
         uint32_t total;
         uint32_t o = block_excl_scan(cnt + head, misc + 4, total);
         uint32_t owned = 0;
@@ -401,15 +386,16 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
             __syncthreads();
             SVJG_STAMP(3);
             const uint32_t n_nodes = (a.diag & 2u) ? 0u : misc[3];
-            // ---- R3: one node per lane (UB per lane, so that their table probes overlap) ------------------------------
+            // ---- R3: one node per lane; UB nodes per lane so that ONE round trip to the name table serves the whole round:
+            //      hash all names, issue all entry loads, then compare the spelling (occupied slots walk on, rarely) --------
             for (uint32_t nb = 0; nb < n_nodes; nb += UB * WG) {
-                uint32_t nn[UB], lnv[UB];
-                const uint32_t *ent[UB];
-                bool live[UB];
+                uint32_t nn[UB], lnv[UB], d[UB][8], slot[UB], len[UB];
+                uint4 e0[UB], e1[UB], e2[UB];
+                bool live[UB], probe[UB];
 #pragma unroll
                 for (uint32_t u = 0; u < UB; ++u) {
                     nn[u] = nb + u * WG + tid;
-                    live[u] = false; ent[u] = nullptr; lnv[u] = 0;
+                    live[u] = false; probe[u] = false; lnv[u] = 0; slot[u] = 0; len[u] = 0;
                     if (nn[u] < n_nodes) {
                         lnv[u] = n_line[nn[u]] & 0x7FFFu;
                         const uint32_t meta = l_meta[lnv[u]];
@@ -419,20 +405,32 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
                             const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
                             const uint32_t b0 = (nn[u] + 1 < lnb + lk) ? (uint32_t)n_pos[nn[u] + 1] - 1u : (uint32_t)l_pend[lnv[u]];
                             if (text[a0 - 1] == '<') n_line[nn[u]] = (uint16_t)(lnv[u] | 0x8000u);
-                            if (!(a.diag & 4u)) ent[u] = name_probe(g, text, a0, b0 - a0);
+                            len[u] = b0 - a0;
+                            probe[u] = len[u] - 1u <= 31u && !(a.diag & 4u);     // names of 1..32 bytes; longer ones: exact path
+                            if (probe[u]) slot[u] = name_words(text, a0, len[u], d[u]) & g.name_mask;
                         }
                     }
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < UB; ++u) {
+                    e0[u] = e1[u] = e2[u] = make_uint4(0, 0, 0, 0);
+                    if (probe[u]) { const uint4 *e = (const uint4 *)(g.name_tab + (size_t)slot[u] * 16); e0[u] = e[0]; e1[u] = e[1]; e2[u] = e[2]; }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < UB; ++u) {
                     if (live[u]) {
-                        uint32_t id = NONE32, len = 0;
-                        if (ent[u]) {
-                            const uint4 e2 = ((const uint4 *)ent[u])[2];     // byte length | flags << 8, node id, length in bp
-                            if (!(e2.x & 0x300u)) { id = e2.y; len = e2.z; }  // hazard-prone name / unknown alt length: exact path
+                        uint32_t id = NONE32, lbp = 0;
+                        if (probe[u]) {
+                            while ((e2[u].x & 0xFFu) != 0 && !name_match(e0[u], e1[u], e2[u], d[u], len[u])) {     // occupied by another name
+                                slot[u] = (slot[u] + 1) & g.name_mask;
+                                const uint4 *e = (const uint4 *)(g.name_tab + (size_t)slot[u] * 16);
+                                e0[u] = e[0]; e1[u] = e[1]; e2[u] = e[2];
+                            }
+                            // byte length | flags << 8, node id, length in bp; hazard-prone name / unknown alt length: exact path
+                            if ((e2[u].x & 0xFFu) != 0 && !(e2[u].x & 0x300u)) { id = e2[u].y; lbp = e2[u].z; }
                         }
-                        if (a.diag & 4u) { id = 0; len = 100; }
-                        n_id[nn[u]] = id; n_pre[nn[u]] = len;
+                        if (a.diag & 4u) { id = 0; lbp = 100; }
+                        n_id[nn[u]] = id; n_pre[nn[u]] = lbp;
                         if (id == NONE32) atomicOr(&l_meta[lnv[u]], ST_DEFER << 24);              // ST_OK | ST_DEFER == ST_DEFER
                     }
                 }
@@ -463,35 +461,62 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
             }
             __syncthreads();
             SVJG_STAMP(5);
-            // ---- R5: one path step per lane --------------------------------------------------------------------------
-            for (uint32_t nb = 0; nb < n_nodes; nb += WG) {
-                const uint32_t n = nb + tid;
-                if (n + 1 < n_nodes) {
-                    const uint32_t ln = n_line[n] & 0x7FFFu;
-                    const uint32_t meta = l_meta[ln];
-                    const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
-                    if ((meta >> 24) == ST_OK && n + 1 < lnb + lk) {
-                        // the reference evaluates the link (name, strand) of the FIRST occurrence of each name
-                        // (str.split / list.index, filter-alignments.py:206, :269-271)
-                        const uint32_t fl = n_first[n], fr = n_first[n + 1];
-                        const long long left = (long long)n_pre[fl] - (long long)l_ts[ln];
-                        const long long pre_excl_r = fr > lnb ? (long long)n_pre[fr - 1] : 0;
-                        const long long right = (long long)l_tot[ln] - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
-                        if (left >= (long long)g.d_over && right >= (long long)g.d_over) {
-                            const uint32_t *e = link_probe(g, n_id[n], n_line[fl] >> 15, n_id[n + 1], n_line[fr] >> 15);
-                            if (e) {
-                                const uint32_t nh = e[2], h0 = e[3], h1 = e[4];
-                                for (uint32_t j = 0; j < nh; ++j) {
-                                    const uint32_t hv = nh <= 2 ? (j == 0 ? h0 : h1) : g.hits[h0 + j];
-                                    if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
-                                    if (a.want_hits) {
-                                        unsigned long long idx = atomicAdd(&a.st->n_recs, 1ull);
-                                        if (idx < a.rec_cap) {
-                                            svjg_hitrec r; r.line_start = a.base_offset + c0 + l_start[ln]; r.slot = hv >> 1;
-                                            r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
-                                            a.recs[idx] = r;
-                                        } else atomicOr(&a.st->overflow, 2u);
-                                    }
+            // ---- R5: one path step per lane; UB steps per lane, all link-table entries fetched in one round trip ------------
+            for (uint32_t nb = 0; nb < n_nodes; nb += UB * WG) {
+                uint32_t lnv[UB], klo[UB], khi[UB], slot[UB];
+                uint4 ek[UB];
+                bool go[UB];
+#pragma unroll
+                for (uint32_t u = 0; u < UB; ++u) {
+                    const uint32_t n = nb + u * WG + tid;
+                    go[u] = false; lnv[u] = 0; klo[u] = khi[u] = slot[u] = 0;
+                    if (n + 1 < n_nodes) {
+                        const uint32_t ln = n_line[n] & 0x7FFFu;
+                        const uint32_t meta = l_meta[ln];
+                        const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
+                        if ((meta >> 24) == ST_OK && n + 1 < lnb + lk) {
+                            // the reference evaluates the link (name, strand) of the FIRST occurrence of each name
+                            // (str.split / list.index, filter-alignments.py:206, :269-271)
+                            const uint32_t fl = n_first[n], fr = n_first[n + 1];
+                            const long long left = (long long)n_pre[fl] - (long long)l_ts[ln];
+                            const long long pre_excl_r = fr > lnb ? (long long)n_pre[fr - 1] : 0;
+                            const long long right = (long long)l_tot[ln] - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
+                            if (left >= (long long)g.d_over && right >= (long long)g.d_over) {
+                                go[u] = true; lnv[u] = ln;
+                                klo[u] = (n_id[n + 1] << 1) | (uint32_t)(n_line[fr] >> 15);
+                                khi[u] = (n_id[n] << 1) | (uint32_t)(n_line[fl] >> 15);
+                                slot[u] = link_hash(klo[u], khi[u]) & g.link_mask;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < UB; ++u) {
+                    ek[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
+                    if (go[u]) ek[u] = *(const uint4 *)(g.link_tab + (size_t)slot[u] * 4);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < UB; ++u) {
+                    if (go[u]) {
+                        while (!(ek[u].x == klo[u] && ek[u].y == khi[u]) && (ek[u].x & ek[u].y) != 0xFFFFFFFFu) {   // occupied by another link
+                            slot[u] = (slot[u] + 1) & g.link_mask;
+                            ek[u] = *(const uint4 *)(g.link_tab + (size_t)slot[u] * 4);
+                        }
+                        if (ek[u].x == klo[u] && ek[u].y == khi[u]) {
+                            // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
+                            const uint32_t ea = ek[u].z, eb = ek[u].w;
+                            const bool many = (ea & 0x80000000u) && eb != 0xFFFFFFFFu && ea != 0xFFFFFFFFu;
+                            const uint32_t nh = many ? eb : (eb == 0xFFFFFFFFu ? 1u : 2u);
+                            for (uint32_t j = 0; j < nh; ++j) {
+                                const uint32_t hv = many ? g.hits[(ea & 0x7FFFFFFFu) + j] : (j == 0 ? ea : eb);
+                                if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
+                                if (a.want_hits) {
+                                    unsigned long long idx = atomicAdd(&a.st->n_recs, 1ull);
+                                    if (idx < a.rec_cap) {
+                                        svjg_hitrec r; r.line_start = a.base_offset + c0 + l_start[lnv[u]]; r.slot = hv >> 1;
+                                        r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
+                                        a.recs[idx] = r;
+                                    } else atomicOr(&a.st->overflow, 2u);
                                 }
                             }
                         }

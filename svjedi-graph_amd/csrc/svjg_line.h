@@ -38,7 +38,7 @@ struct GraphView {
     uint32_t d_over;
     const uint32_t *name_tab;    // main kernel: canonical node name -> node (svjg_host_tables.h), 16 words per entry
     uint32_t name_mask;
-    const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 8 words per entry
+    const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 4 words per entry
     uint32_t link_mask;
 };
 

@@ -151,7 +151,7 @@ class Graph:
                     sv_ids.append(sv)
                 hv.append((s << 1) | allele)
             merged.append(hv)
-        if len(sv_ids) >= (1 << 31):
+        if len(sv_ids) >= (1 << 30):
             raise GraphFormatError("too many SVs")
         self.sv_ids = sv_ids
         self.slot_of = slot_of

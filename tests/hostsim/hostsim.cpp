@@ -69,7 +69,11 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
             for (;;) {
                 const uint32_t *e = &kt.links[q * LINK_ENT_WORDS];
                 if (e[0] == 0xFFFFFFFFu && e[1] == 0xFFFFFFFFu) { ++bad; break; }
-                if (e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32)) { if (e[2] != (ed.meta >> 2) || e[3] != ed.h0 || e[4] != ed.h1) ++bad; break; }
+                if (e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32)) {
+                    const uint32_t nh = ed.meta >> 2;
+                    if (nh == 1 ? (e[2] != ed.h0 || e[3] != LINK_NO_HIT) : nh == 2 ? (e[2] != ed.h0 || e[3] != ed.h1) : (e[2] != (LINK_MANY | ed.h0) || e[3] != nh)) ++bad;
+                    break;
+                }
                 q = (q + 1) & kt.link_mask;
             }
         }
