@@ -19,11 +19,12 @@
 namespace svjg {
 
 #ifndef SVJG_WG
-#define SVJG_WG 256
-#define SVJG_PIECES 10
+#define SVJG_WG 512
+#define SVJG_PIECES 5
 #define SVJG_NMAX 1152
 #endif
-constexpr uint32_t WG = SVJG_WG;                   // classify kernel: 3 waves; two workgroups per CU (LDS-bound)
+constexpr uint32_t LR = 256;                     // lines per round (line-granular phases use the first LR lanes)
+constexpr uint32_t WG = SVJG_WG;                   // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS-bound) = 16 waves / CU
 constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
 constexpr uint32_t PIECES = SVJG_PIECES;                 // 16-byte pieces of text per lane and stripe
 constexpr uint32_t SPAN = PIECES * 16;           // 208 B of byte classification per lane
@@ -39,15 +40,15 @@ constexpr uint32_t L_TEXT = 0;
 constexpr uint32_t L_TABBM = L_TEXT + TEXT + 16;                           // u16[TEXT/16] one bit per byte: '\t'
 constexpr uint32_t L_ORIBM = L_TABBM + TEXT / 8;                           // u16[TEXT/16] one bit per byte: '<' or '>'
 constexpr uint32_t L_STARTS = L_ORIBM + TEXT / 8 + 16;                     // u16[MAXSTARTS + 8]
-constexpr uint32_t L_TS = (L_STARTS + (MAXSTARTS + 8) * 2 + 15) / 16 * 16; // u32[WG]  path start column
-constexpr uint32_t L_TE = L_TS + WG * 4;                                   // u32[WG]
-constexpr uint32_t L_TLEN = L_TE + WG * 4;                                 // u32[WG]
-constexpr uint32_t L_TOT = L_TLEN + WG * 4;                                // u32[WG]  sum of node lengths
-constexpr uint32_t L_META = L_TOT + WG * 4;                                // u32[WG]  nbase | k << 16 | status << 24
-constexpr uint32_t L_LSTART = L_META + WG * 4;                             // u16[WG]  line start
-constexpr uint32_t L_PBEG = L_LSTART + WG * 2;                             // u16[WG]  tab before the path column
-constexpr uint32_t L_PEND = L_PBEG + WG * 2;                               // u16[WG]  tab after the path column
-constexpr uint32_t L_NPOS = L_PEND + WG * 2;                               // u16[NMAX]  name start (orientation mark + 1)
+constexpr uint32_t L_TS = (L_STARTS + (MAXSTARTS + 8) * 2 + 15) / 16 * 16; // u32[LR]  path start column
+constexpr uint32_t L_TE = L_TS + LR * 4;                                   // u32[LR]
+constexpr uint32_t L_TLEN = L_TE + LR * 4;                                 // u32[LR]
+constexpr uint32_t L_TOT = L_TLEN + LR * 4;                                // u32[LR]  sum of node lengths
+constexpr uint32_t L_META = L_TOT + LR * 4;                                // u32[LR]  nbase | k << 16 | status << 24
+constexpr uint32_t L_LSTART = L_META + LR * 4;                             // u16[LR]  line start
+constexpr uint32_t L_PBEG = L_LSTART + LR * 2;                             // u16[LR]  tab before the path column
+constexpr uint32_t L_PEND = L_PBEG + LR * 2;                               // u16[LR]  tab after the path column
+constexpr uint32_t L_NPOS = L_PEND + LR * 2;                               // u16[NMAX]  name start (orientation mark + 1)
 constexpr uint32_t L_NLINE = L_NPOS + NMAX * 2;                            // u16[NMAX]  line in round | orientation << 15
 constexpr uint32_t L_NFIRST = L_NLINE + NMAX * 2;                          // u16[NMAX]  first node of the line with the same name
 constexpr uint32_t L_NID = L_NFIRST + NMAX * 2;                            // u32[NMAX]
@@ -184,7 +185,10 @@ __device__ inline uint32_t link_hash(uint32_t klo, uint32_t khi) {
     return x;
 }
 
-constexpr uint32_t UB = 4;                       // path steps per lane / path nodes per lane quad handled at a time (loads in flight)
+#ifndef SVJG_UB
+#define SVJG_UB 1
+#endif
+constexpr uint32_t UB = SVJG_UB;                    // path steps per lane / path nodes per lane quad handled at a time (loads in flight)
 
 // The classify kernel.  One workgroup walks stripes of the GAF text; the next stripe's HBM loads are issued into
 // registers before the current one is processed, so the only HBM read of the text overlaps the parse.  Per stripe:
@@ -202,7 +206,7 @@ constexpr uint32_t UB = 4;                       // path steps per lane / path n
 //   R5 one path STEP (link) per lane: overlap test on the prefix sums, link lookup in the node's CSR row, one 64-bit
 //      atomic (ref | alt << 32) per hit, optional hit records
 //   R6 deferred-line offsets, one aggregated atomic per wave
-__global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify_main(ClassifyArgs a) {
+__global__ __launch_bounds__(WG, (2 * WG) / 256) void k_classify_main(ClassifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *text = lds + L_TEXT;
     uint16_t *tabbm16 = (uint16_t *)(lds + L_TABBM), *oribm16 = (uint16_t *)(lds + L_ORIBM);
@@ -314,12 +318,13 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
         SVJG_STAMP(1);
         if (a.diag & 1u) { if (tid == 0) wg_lines += n_owned; __syncthreads(); continue; }
 
-        for (uint32_t base = 0; base < n_owned; base += WG) {           // uniform trip count across the block
+        for (uint32_t base = 0; base < n_owned; base += LR) {           // uniform trip count across the block
             // ---- R1: one line per lane --------------------------------------------------------------
             if (tid == 0) misc[3] = 0;                                   // node slots in use this round
             const uint32_t li = base + tid;
             uint32_t status = ST_NONE, k = 0, s = 0;
-            if (li < n_owned) {
+            const bool line_lane = tid < LR;
+            if (line_lane && li < n_owned) {
                 s = starts[li];
                 uint32_t e = V;
                 bool complete = true;
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
                 ok &= pbnd > prev + 1;
                 if (!ok) status = ST_DEFER;
             }
-            l_meta[tid] = nbase | (k << 16) | (status << 24);
+            if (line_lane) l_meta[tid] = nbase | (k << 16) | (status << 24);
             __syncthreads();
             SVJG_STAMP(3);
             const uint32_t n_nodes = (a.diag & 2u) ? 0u : misc[3];
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
             __syncthreads();
             SVJG_STAMP(4);
             // ---- R4: one line per lane: prefix sums, first occurrences --------------------------------------
-            {
+            if (line_lane) {
                 const uint32_t meta = l_meta[tid];
                 if ((meta >> 24) == ST_OK) {
                     const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(WG, WG == 192 ? 2 : (2 * WG) / 256) void k_classify
             SVJG_STAMP(6);
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
-                const bool defer = li < n_owned && (l_meta[tid] >> 24) == ST_DEFER;
+                const bool defer = line_lane && li < n_owned && (l_meta[tid] >> 24) == ST_DEFER;
                 unsigned long long db = __ballot(defer);
                 if (db) {
                     unsigned long long dbase = 0;
