@@ -148,6 +148,14 @@ def main():
             "setup_s": {"generate_and_tables": round(t_setup, 1), "h2d_upload": round(t_h2d, 3),
                         "pcie_inclusive_alignments_per_s": n_aln / (t_h2d + ms_per_step * 1e-3)},
         }
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (profiles/<round>/traffic.json)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json"))).get(args.workload)
+            if tr and tr["text_bytes"] == int(gaf.size) and world == 1:
+                res["roofline"]["traffic"] = tr["traffic_bytes"]
+                res["roofline"]["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
+        except (OSError, ValueError, KeyError):
+            pass
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(pre, gaf, graph, counts, rows)
         print(json.dumps(res))
