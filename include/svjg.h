@@ -162,6 +162,12 @@ int svjg_genotype(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, c
 int svjg_write_informative_json(const char *path, const char *gaf, uint64_t n_bytes, const svjg_hitrec *recs,
                                 uint64_t n_recs, const char *const *sv_ids, uint32_t n_slots, int n_threads);
 
+/* Reader side for a stand-alone predict-genotype.py (json.load at predict-genotype.py:67-68, then only len() of the two
+ * lists of each key, :219-226): one scan of the JSON text -> keys (unescaped UTF-8, NUL separated, file order) and
+ * the two list lengths per key.  Buffers are malloc'd by the library and released with svjg_host_free. */
+int svjg_count_informative_json(const char *path, char **keys_out, uint64_t *keys_len, uint64_t **counts_out, uint64_t *n_keys);
+void svjg_host_free(void *p);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the kernels of the last classify / genotype ---- */
 int svjg_last_kernel_ms(svjg_ctx *ctx, float *classify_main_ms, float *classify_slow_ms, float *genotype_ms);
 int svjg_sync(svjg_ctx *ctx);

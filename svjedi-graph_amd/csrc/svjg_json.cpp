@@ -11,6 +11,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -177,4 +178,127 @@ extern "C" int svjg_write_informative_json(const char *path, const char *gaf, ui
     if (!rc) fputs("\n}", fp);
     if (fclose(fp) && !rc) rc = SVJG_E_NOMEM;
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reader side: predict-genotype.py only needs len(dict[key][0]) and len(dict[key][1]) (predict-genotype.py:219-226).
+// svjg_count_informative_json scans the JSON text once (any valid JSON of that shape, not only json.dumps' layout)
+// and returns the keys (unescaped, UTF-8, NUL separated) and the two list lengths per key.
+// ---------------------------------------------------------------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+struct Scan {
+    const uint8_t *p, *e;
+    bool fail = false;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; }
+    bool eat(char c) { ws(); if (p < e && *p == (uint8_t)c) { ++p; return true; } return false; }
+    // string body -> out (unescaped UTF-8) or skipped when out == nullptr
+    bool str(std::string *out) {
+        ws();
+        if (p >= e || *p != '"') return false;
+        ++p;
+        while (p < e && *p != '"') {
+            if (*p == '\\') {
+                if (p + 1 >= e) return false;
+                uint8_t c = p[1];
+                p += 2;
+                if (c == 'u') {
+                    if (p + 4 > e) return false;
+                    auto hx = [&](const uint8_t *q, uint32_t &v) { v = 0; for (int i = 0; i < 4; ++i) { uint8_t h = q[i]; v <<= 4;
+                        if (h >= '0' && h <= '9') v |= h - '0'; else if (h >= 'a' && h <= 'f') v |= h - 'a' + 10; else if (h >= 'A' && h <= 'F') v |= h - 'A' + 10; else return false; } return true; };
+                    uint32_t cp;
+                    if (!hx(p, cp)) return false;
+                    p += 4;
+                    if (cp >= 0xD800 && cp <= 0xDBFF && p + 6 <= e && p[0] == '\\' && p[1] == 'u') {
+                        uint32_t lo;
+                        if (hx(p + 2, lo) && lo >= 0xDC00 && lo <= 0xDFFF) { cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); p += 6; }
+                    }
+                    if (out) {
+                        if (cp < 0x80) *out += (char)cp;
+                        else if (cp < 0x800) { *out += (char)(0xC0 | (cp >> 6)); *out += (char)(0x80 | (cp & 0x3F)); }
+                        else if (cp < 0x10000) { *out += (char)(0xE0 | (cp >> 12)); *out += (char)(0x80 | ((cp >> 6) & 0x3F)); *out += (char)(0x80 | (cp & 0x3F)); }
+                        else { *out += (char)(0xF0 | (cp >> 18)); *out += (char)(0x80 | ((cp >> 12) & 0x3F)); *out += (char)(0x80 | ((cp >> 6) & 0x3F)); *out += (char)(0x80 | (cp & 0x3F)); }
+                    }
+                } else if (out) {
+                    switch (c) { case 'n': *out += '\n'; break; case 't': *out += '\t'; break; case 'r': *out += '\r'; break;
+                                 case 'b': *out += '\b'; break; case 'f': *out += '\f'; break; default: *out += (char)c; }
+                }
+            } else {
+                if (out) *out += (char)*p;
+                ++p;
+            }
+        }
+        if (p >= e) return false;
+        ++p;
+        return true;
+    }
+    bool skip() {                                               // any JSON value
+        ws();
+        if (p >= e) return false;
+        if (*p == '"') return str(nullptr);
+        if (*p == '[') { ++p; if (eat(']')) return true; do { if (!skip()) return false; } while (eat(',')); return eat(']'); }
+        if (*p == '{') { ++p; if (eat('}')) return true; do { if (!str(nullptr) || !eat(':') || !skip()) return false; } while (eat(',')); return eat('}'); }
+        const uint8_t *q = p;
+        while (p < e && *p != ',' && *p != ']' && *p != '}' && *p != ' ' && *p != '\n' && *p != '\r' && *p != '\t') ++p;
+        return p > q;
+    }
+    bool count_list(uint64_t &n) {                              // '[' values ']' -> number of values
+        n = 0;
+        if (!eat('[')) return false;
+        if (eat(']')) return true;
+        do { if (!skip()) return false; ++n; } while (eat(','));
+        return eat(']');
+    }
+};
+
+}  // namespace
+
+extern "C" void svjg_host_free(void *p) { free(p); }
+
+// keys_out: malloc'd blob of n NUL-terminated keys in file order; counts_out: malloc'd uint64[n][2].
+// Returns 0, SVJG_E_NOMEM (cannot read), or SVJG_E_INPUT (not the JSON shape predict-genotype.py needs).
+extern "C" int svjg_count_informative_json(const char *path, char **keys_out, uint64_t *keys_len, uint64_t **counts_out, uint64_t *n_keys)
+{
+    if (!path || !keys_out || !keys_len || !counts_out || !n_keys) return SVJG_E_ARG;
+    *keys_out = nullptr; *counts_out = nullptr; *keys_len = 0; *n_keys = 0;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return SVJG_E_NOMEM;
+    struct stat st;
+    if (fstat(fd, &st)) { close(fd); return SVJG_E_NOMEM; }
+    size_t n = (size_t)st.st_size;
+    const uint8_t *base = n ? (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (n && base == MAP_FAILED) return SVJG_E_NOMEM;
+    Scan s{base, base + n};
+    std::string keys; std::vector<uint64_t> cnt;
+    int rc = 0;
+    if (!s.eat('{')) rc = SVJG_E_INPUT;
+    else if (!s.eat('}')) {
+        do {
+            std::string k;
+            uint64_t a = 0, b = 0;
+            if (!s.str(&k) || !s.eat(':') || !s.eat('[') || !s.count_list(a) || !s.eat(',') || !s.count_list(b)) { rc = SVJG_E_INPUT; break; }
+            while (s.eat(',')) if (!s.skip()) { rc = SVJG_E_INPUT; break; }     // further elements are never looked at
+            if (rc || !s.eat(']')) { rc = SVJG_E_INPUT; break; }
+            if (k.find('\0') != std::string::npos) { rc = SVJG_E_INPUT; break; }
+            keys += k; keys += '\0';
+            cnt.push_back(a); cnt.push_back(b);
+        } while (s.eat(','));
+        if (!rc && !s.eat('}')) rc = SVJG_E_INPUT;
+    }
+    if (!rc) { s.ws(); if (s.p != s.e) rc = SVJG_E_INPUT; }
+    if (n) munmap((void *)base, n);
+    if (rc) return rc;
+    *keys_out = (char *)malloc(keys.size() + 1);
+    *counts_out = (uint64_t *)malloc((cnt.size() + 1) * sizeof(uint64_t));
+    if (!*keys_out || !*counts_out) { free(*keys_out); free(*counts_out); return SVJG_E_NOMEM; }
+    memcpy(*keys_out, keys.data(), keys.size());
+    memcpy(*counts_out, cnt.data(), cnt.size() * sizeof(uint64_t));
+    *keys_len = keys.size(); *n_keys = cnt.size() / 2;
+    return 0;
 }

@@ -502,6 +502,8 @@ __global__ __launch_bounds__(WG, (2 * WG) / 256) void k_classify_main(ClassifyAr
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < UB; ++u) {
+                    uint32_t nh = 0, ea = 0, eb = 0;
+                    bool many = false;
                     if (go[u]) {
                         while (!(ek[u].x == klo[u] && ek[u].y == khi[u]) && (ek[u].x & ek[u].y) != 0xFFFFFFFFu) {   // occupied by another link
                             slot[u] = (slot[u] + 1) & g.link_mask;
@@ -509,21 +511,29 @@ __global__ __launch_bounds__(WG, (2 * WG) / 256) void k_classify_main(ClassifyAr
                         }
                         if (ek[u].x == klo[u] && ek[u].y == khi[u]) {
                             // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
-                            const uint32_t ea = ek[u].z, eb = ek[u].w;
-                            const bool many = (ea & 0x80000000u) && eb != 0xFFFFFFFFu && ea != 0xFFFFFFFFu;
-                            const uint32_t nh = many ? eb : (eb == 0xFFFFFFFFu ? 1u : 2u);
-                            for (uint32_t j = 0; j < nh; ++j) {
-                                const uint32_t hv = many ? g.hits[(ea & 0x7FFFFFFFu) + j] : (j == 0 ? ea : eb);
-                                if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
-                                if (a.want_hits) {
-                                    unsigned long long idx = atomicAdd(&a.st->n_recs, 1ull);
-                                    if (idx < a.rec_cap) {
-                                        svjg_hitrec r; r.line_start = a.base_offset + c0 + l_start[lnv[u]]; r.slot = hv >> 1;
-                                        r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
-                                        a.recs[idx] = r;
-                                    } else atomicOr(&a.st->overflow, 2u);
-                                }
-                            }
+                            ea = ek[u].z; eb = ek[u].w;
+                            many = (ea & 0x80000000u) && eb != 0xFFFFFFFFu && ea != 0xFFFFFFFFu;
+                            nh = many ? eb : (eb == 0xFFFFFFFFu ? 1u : 2u);
+                        }
+                    }
+                    // hit records: one aggregated atomic per wave reserves the slots
+                    unsigned long long rbase = 0;
+                    if (a.want_hits) {
+                        uint32_t wtot, ex = wave_excl_scan(nh, wtot);
+                        if (wtot) {
+                            if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot);
+                            rbase = __shfl(rbase, 0) + ex;
+                        }
+                    }
+                    for (uint32_t j = 0; j < nh; ++j) {
+                        const uint32_t hv = many ? g.hits[(ea & 0x7FFFFFFFu) + j] : (j == 0 ? ea : eb);
+                        if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
+                        if (a.want_hits) {
+                            if (rbase + j < a.rec_cap) {
+                                svjg_hitrec r; r.line_start = a.base_offset + c0 + l_start[lnv[u]]; r.slot = hv >> 1;
+                                r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
+                                a.recs[rbase + j] = r;
+                            } else atomicOr(&a.st->overflow, 2u);
                         }
                     }
                 }

@@ -72,7 +72,7 @@ _SIGS = {
     "svjg_sync": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
-EXPORTS = tuple(_SIGS) + ("svjg_write_informative_json",)
+EXPORTS = tuple(_SIGS) + ("svjg_write_informative_json", "svjg_count_informative_json", "svjg_host_free")
 _lib = None
 _host_lib = None
 
@@ -87,8 +87,34 @@ def load_host_library():
         lib.svjg_write_informative_json.restype = ctypes.c_int
         lib.svjg_write_informative_json.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
                                                     ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.c_int]
+        lib.svjg_count_informative_json.restype = ctypes.c_int
+        lib.svjg_count_informative_json.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64),
+                                                    ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+        lib.svjg_host_free.restype = None
+        lib.svjg_host_free.argtypes = [ctypes.c_void_p]
         _host_lib = lib
     return _host_lib
+
+
+def count_informative_json(path):
+    """-> (list of keys in file order, uint32 array [n, 2] of list lengths) of an _informative_aln.json."""
+    lib = load_host_library()
+    kp, cp = ctypes.c_void_p(), ctypes.c_void_p()
+    kl, nk = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = lib.svjg_count_informative_json(os.fsencode(path), ctypes.byref(kp), ctypes.byref(kl), ctypes.byref(cp), ctypes.byref(nk))
+    if rc == -10:
+        raise ValueError(f"{path}: not the JSON written by filter-alignments.py")
+    if rc:
+        raise OSError(f"cannot read {path}")
+    try:
+        blob = ctypes.string_at(kp, kl.value)
+        keys = [k.decode("utf-8") for k in blob.split(b"\0")[:-1]] if kl.value else []
+        cnt = np.ctypeslib.as_array(ctypes.cast(cp, ctypes.POINTER(ctypes.c_uint64)), shape=(max(1, nk.value) * 2,)).copy()[: nk.value * 2]
+    finally:
+        lib.svjg_host_free(kp); lib.svjg_host_free(cp)
+    if (cnt >= 2 ** 32).any():
+        raise ValueError("list too long")
+    return keys, cnt.astype(np.uint32).reshape(-1, 2)
 
 
 def write_informative_json(path, gaf, recs, sv_ids, n_threads=0):

@@ -3,8 +3,6 @@
 Mirrors predict-genotype.py's decision_vcf (:89-279) for everything that is file format; the likelihood
 (:281-338) and the presence gate (:216) run on the GPU.
 """
-import json
-
 import numpy as np
 
 NONE = 0xFFFFFFFF
@@ -123,11 +121,10 @@ def genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support=3, err=0.
 def run(json_path, vcf_path, out_path, min_support=3, err=0.00005, device=0):
     """predict-genotype.py main(): counts come from the informative-alignment JSON."""
     from . import capi
-    with open(json_path, "r") as fh:
-        d = json.load(fh)
-    keys = list(d)
-    slot_of = {k: i for i, k in enumerate(keys)}
-    counts = np.array([[len(d[k][0]), len(d[k][1])] for k in keys], dtype=np.uint32).reshape(len(keys), 2)
+    keys, counts = capi.count_informative_json(json_path)       # len() of the two lists of every key (:219-226)
+    slot_of = {}
+    for i, k in enumerate(keys):
+        slot_of[k] = i                                           # a repeated key: the last one wins, like json.load
     ctx = capi.Context(device)
     try:
         ctx.alloc_counts(len(keys))

@@ -67,3 +67,24 @@ def test_invalid_utf8(tmp_path):
     recs["n_ref"] = 1
     with pytest.raises(UnicodeDecodeError):
         capi.write_informative_json(str(tmp_path / "o.json"), np.frombuffer(b"r\xff\tx\n", dtype=np.uint8), recs, ["1:DEL-1-2"])
+
+
+def test_count_reader_matches_json_load(golden, tmp_path):
+    files = [f"{golden}/testdir/ref_informative_aln.json", f"{golden}/vcf/cases_informative_aln.json",
+             f"{golden}/quirks/json_escapes.ref.json", f"{golden}/quirks/empty_file.ref.json", f"{golden}/quirks/repeat_flipped.ref.json"]
+    odd = tmp_path / "odd.json"     # other valid spellings of the same shape: compact, extra elements, unicode key, nested values
+    odd.write_text('{"a\\u00e9\\ud83d\\ude00":[["x",1,{"k":[1,2]}],[],"ignored"],\n "b" : [ [ ] , [null, true, 3.5e1] ] }')
+    files.append(str(odd))
+    for f in files:
+        keys, cnt = capi.count_informative_json(f)
+        d = json.load(open(f))
+        assert keys == list(d)
+        assert cnt.tolist() == [[len(d[k][0]), len(d[k][1])] for k in keys]
+
+
+@pytest.mark.parametrize("text", ['{"a": [[1], [2]', '[1, 2]', '{"a": [[1]]}', '{"a": 5}', '{"a": [[1],[2]]} x', ''])
+def test_count_reader_rejects(tmp_path, text):
+    p = tmp_path / "bad.json"
+    p.write_text(text)
+    with pytest.raises(ValueError):
+        capi.count_informative_json(str(p))
