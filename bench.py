@@ -156,7 +156,7 @@ def main():
                 res["roofline"]["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
         except (OSError, ValueError, KeyError):
             pass
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pre, gaf, graph, counts, rows)
         print(json.dumps(res))
     ctx.close()
