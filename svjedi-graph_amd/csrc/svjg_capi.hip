@@ -239,7 +239,10 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
         a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
         size_t lds = LDS_MAIN;
-        uint32_t grid = a.n_chunks < (uint32_t)c->n_cu * 2 ? a.n_chunks : (uint32_t)c->n_cu * 2;
+        int occ = 0;                                          // persistent grid: every CU filled to what LDS / registers admit
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_classify_main, (int)WG, lds) != hipSuccess || occ < 1) occ = 1;
+        const uint32_t full = (uint32_t)c->n_cu * (uint32_t)occ;
+        uint32_t grid = a.n_chunks < full ? a.n_chunks : full;
         if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);

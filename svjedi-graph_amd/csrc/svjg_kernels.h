@@ -23,7 +23,10 @@ namespace svjg {
 #define SVJG_PIECES 5
 #define SVJG_NMAX 1152
 #endif
-constexpr uint32_t LR = 256;                     // lines per round (line-granular phases use the first LR lanes)
+#ifndef SVJG_LR
+#define SVJG_LR 256
+#endif
+constexpr uint32_t LR = SVJG_LR;                  // lines per round (line-granular phases use the first LR lanes)
 constexpr uint32_t WG = SVJG_WG;                   // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS-bound) = 16 waves / CU
 constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
 constexpr uint32_t PIECES = SVJG_PIECES;                 // 16-byte pieces of text per lane and stripe
