@@ -32,7 +32,10 @@ constexpr uint32_t TPB = 256;                    // block size of the small per-
 constexpr uint32_t PIECES = SVJG_PIECES;                 // 16-byte pieces of text per lane and stripe
 constexpr uint32_t SPAN = PIECES * 16;           // 208 B of byte classification per lane
 constexpr uint32_t TEXT = SPAN * WG;             // 39 KB staged in LDS
-constexpr uint32_t LOOK = 4 * 1024;              // look-ahead so that lines starting in the stripe are complete
+#ifndef SVJG_LOOK
+#define SVJG_LOOK 4096
+#endif
+constexpr uint32_t LOOK = SVJG_LOOK;            // look-ahead so that lines starting in the stripe are complete
 constexpr uint32_t CHUNK = TEXT - LOOK;          // bytes of text owned by one workgroup iteration (a "stripe")
 constexpr uint32_t MAXSTARTS = TEXT / 24 + 8;    // a valid line has >= 24 bytes incl. its terminator
 constexpr uint32_t KMAX = 16;                    // path nodes per alignment handled by the main kernel
@@ -209,7 +212,10 @@ constexpr uint32_t UB = SVJG_UB;                    // path steps per lane / pat
 //   R5 one path STEP (link) per lane: overlap test on the prefix sums, link lookup in the node's CSR row, one 64-bit
 //      atomic (ref | alt << 32) per hit, optional hit records
 //   R6 deferred-line offsets, one aggregated atomic per wave
-__global__ __launch_bounds__(WG, (2 * WG) / 256) void k_classify_main(ClassifyArgs a) {
+#ifndef SVJG_MINW
+#define SVJG_MINW ((2 * SVJG_WG) / 256)
+#endif
+__global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *text = lds + L_TEXT;
     uint16_t *tabbm16 = (uint16_t *)(lds + L_TABBM), *oribm16 = (uint16_t *)(lds + L_ORIBM);

@@ -250,3 +250,40 @@ def test_rccl_single_rank_allreduce(ctx, tmp_path):
         assert np.array_equal(c2.counts(), before) and before.sum() > 0
     finally:
         c2.close()
+
+
+def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
+    """Paths with more nodes than the main kernel keeps per alignment (exact path), a stripe full of too-short lines
+    (the reference dies with ValueError), and lines longer than the look-ahead window."""
+    import synth
+    from svjg.graph import Graph
+    pre = str(tmp_path / "c")
+    inf = synth.generate(pre, 2000, 400, 1, "del", 31, write_gaf=False, return_gaf=True)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    names = [n for n in g.node_names if "." not in n.split(":")[-1]]          # reference nodes in genome order
+    lens = {n: int(n.split(":")[1].split("-")[1]) - int(n.split(":")[1].split("-")[0]) + 1 for n in names}
+    lines = []
+    for k, start in ((17, 3), (25, 40), (60, 100), (16, 200), (33, 300)):
+        path = names[start:start + k]
+        tlen = sum(lens[n] for n in path)
+        fwd = "".join(">" + n for n in path)
+        rev = "".join("<" + n for n in reversed(path))
+        for p in (fwd, rev):
+            lines.append(f"r{len(lines)}\t{tlen}\t0\t{tlen}\t+\t{p}\t{tlen}\t5\t{tlen - 7}\t{tlen}\t{tlen}\t60\ttp:A:P\n".encode())
+    big = lines[2].replace(b"\ttp:A:P", b"\ttp:A:P\tzz:Z:" + b"A" * 9000)    # longer than the look-ahead
+    data = inf["gaf"].tobytes() + b"".join(lines) + big + inf["gaf"].tobytes()[:200000]
+    data = data[: data.rfind(b"\n") + 1]
+    want, _, n_lines = orc.filter(data, want_hits=False)
+    ctx.load_graph(g)
+    ctx.classify(np.frombuffer(data, dtype=np.uint8))
+    assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
+    st = ctx.stats()
+    assert st["n_lines"] == n_lines and st["n_deferred"] >= 9
+    # a stripe of lines shorter than any valid GAF line
+    dense = b"x\t1\n" * 20000
+    with pytest.raises(ValueError):
+        ctx.load_graph(g)
+        ctx.classify(np.frombuffer(inf["gaf"].tobytes() + dense, dtype=np.uint8))
+    with pytest.raises(ValueError):
+        orc.filter(inf["gaf"].tobytes() + dense, want_hits=False)
