@@ -156,7 +156,8 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     c->gv.nodes = c->d_nodes; c->gv.n_nodes = (uint32_t)g->n_nodes; c->gv.edges = c->d_edges; c->gv.hits = c->d_hits;
     c->gv.chrom_names = c->d_cnames; c->gv.chrom_off = c->d_coff; c->gv.chrom_lo = c->d_clo; c->gv.chrom_hash = c->d_chash;
     c->gv.n_chrom = g->n_chrom; c->gv.hash_mask = (uint32_t)hash.size() - 1; c->gv.d_over = g->d_over;
-    c->gv.name_tab = c->d_names; c->gv.name_mask = kt.name_mask; c->gv.link_tab = c->d_links; c->gv.link_mask = kt.link_mask;
+    c->gv.name_tab = c->d_names; c->gv.name_mask = kt.name_mask; c->gv.name_seed = kt.name_seed;
+    c->gv.link_tab = c->d_links; c->gv.link_mask = kt.link_mask; c->gv.link_seed = kt.link_seed;
     c->gflags = g->flags;
     c->n_slots = g->n_slots;
     HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)g->n_slots + 1) * 8));

@@ -21,46 +21,54 @@ namespace svjg {
 #ifndef SVJG_WG
 #define SVJG_WG 512
 #define SVJG_PIECES 5
-#define SVJG_NMAX 1152
 #endif
-#ifndef SVJG_LR
-#define SVJG_LR 256
+#ifndef SVJG_LRW
+#define SVJG_LRW 32
 #endif
-constexpr uint32_t LR = SVJG_LR;                  // lines per round (line-granular phases use the first LR lanes)
-constexpr uint32_t WG = SVJG_WG;                   // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS-bound) = 16 waves / CU
+#ifndef SVJG_NMAXW
+#define SVJG_NMAXW 160
+#endif
+constexpr uint32_t WG = SVJG_WG;                 // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS-bound) = 16 waves / CU
+constexpr uint32_t NWAVE = WG / 64;
 constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
-constexpr uint32_t PIECES = SVJG_PIECES;                 // 16-byte pieces of text per lane and stripe
-constexpr uint32_t SPAN = PIECES * 16;           // 208 B of byte classification per lane
-constexpr uint32_t TEXT = SPAN * WG;             // 39 KB staged in LDS
+constexpr uint32_t PIECES = SVJG_PIECES;         // 16-byte pieces of text per lane and stripe
+constexpr uint32_t SPAN = PIECES * 16;           // bytes of byte classification per lane
+constexpr uint32_t SLICE = SPAN * 64;            // bytes of text whose lines one wave owns
+constexpr uint32_t TEXT = SPAN * WG;             // 40 KB staged in LDS
 #ifndef SVJG_LOOK
 #define SVJG_LOOK 4096
 #endif
-constexpr uint32_t LOOK = SVJG_LOOK;            // look-ahead so that lines starting in the stripe are complete
+constexpr uint32_t LOOK = SVJG_LOOK;             // look-ahead so that lines starting in the stripe are complete
 constexpr uint32_t CHUNK = TEXT - LOOK;          // bytes of text owned by one workgroup iteration (a "stripe")
 constexpr uint32_t MAXSTARTS = TEXT / 24 + 8;    // a valid line has >= 24 bytes incl. its terminator
 constexpr uint32_t KMAX = 16;                    // path nodes per alignment handled by the main kernel
-constexpr uint32_t NMAX = SVJG_NMAX;                 // path nodes per round of WG lines
+constexpr uint32_t LRW = SVJG_LRW;               // lines per wave and round (line-granular phases use the first LRW lanes)
+constexpr uint32_t NMAXW = SVJG_NMAXW;           // path nodes per wave and round
+static_assert(LRW <= 64 && KMAX <= NMAXW, "round geometry");
+static_assert(TEXT < 65536, "text offsets are kept in 16 bits");
 
-// LDS carve-up of k_classify_main (bytes)
+// LDS carve-up of k_classify_main (bytes): text and the two byte-class bitmaps are shared by the workgroup,
+// everything else is private to one wave
 constexpr uint32_t L_TEXT = 0;
 constexpr uint32_t L_TABBM = L_TEXT + TEXT + 16;                           // u16[TEXT/16] one bit per byte: '\t'
 constexpr uint32_t L_ORIBM = L_TABBM + TEXT / 8;                           // u16[TEXT/16] one bit per byte: '<' or '>'
-constexpr uint32_t L_STARTS = L_ORIBM + TEXT / 8 + 16;                     // u16[MAXSTARTS + 8]
-constexpr uint32_t L_TS = (L_STARTS + (MAXSTARTS + 8) * 2 + 15) / 16 * 16; // u32[LR]  path start column
-constexpr uint32_t L_TE = L_TS + LR * 4;                                   // u32[LR]
-constexpr uint32_t L_TLEN = L_TE + LR * 4;                                 // u32[LR]
-constexpr uint32_t L_TOT = L_TLEN + LR * 4;                                // u32[LR]  sum of node lengths
-constexpr uint32_t L_META = L_TOT + LR * 4;                                // u32[LR]  nbase | k << 16 | status << 24
-constexpr uint32_t L_LSTART = L_META + LR * 4;                             // u16[LR]  line start
-constexpr uint32_t L_PBEG = L_LSTART + LR * 2;                             // u16[LR]  tab before the path column
-constexpr uint32_t L_PEND = L_PBEG + LR * 2;                               // u16[LR]  tab after the path column
-constexpr uint32_t L_NPOS = L_PEND + LR * 2;                               // u16[NMAX]  name start (orientation mark + 1)
-constexpr uint32_t L_NLINE = L_NPOS + NMAX * 2;                            // u16[NMAX]  line in round | orientation << 15
-constexpr uint32_t L_NFIRST = L_NLINE + NMAX * 2;                          // u16[NMAX]  first node of the line with the same name
-constexpr uint32_t L_NID = L_NFIRST + NMAX * 2;                            // u32[NMAX]
-constexpr uint32_t L_NPRE = L_NID + NMAX * 4;                              // u32[NMAX]  length, then inclusive prefix
-constexpr uint32_t L_MISC = L_NPRE + NMAX * 4;                             // u32[16]
-constexpr uint32_t LDS_MAIN = L_MISC + 64;
+constexpr uint32_t L_MISC = L_ORIBM + TEXT / 8 + 16;                       // u32[32]: [0] line starts in the stripe, [8 + w] first start found by wave w
+constexpr uint32_t L_WAVE = L_MISC + 128;
+constexpr uint32_t W_RSTART = 0;                                           // u16[LRW + 2]  line starts of the round (+ the end of the last line)
+constexpr uint32_t W_TS = (W_RSTART + (LRW + 2) * 2 + 15) / 16 * 16;       // u32[LRW]  path start column
+constexpr uint32_t W_TE = W_TS + LRW * 4;                                  // u32[LRW]
+constexpr uint32_t W_TLEN = W_TE + LRW * 4;                                // u32[LRW]
+constexpr uint32_t W_TOT = W_TLEN + LRW * 4;                               // u32[LRW]  sum of node lengths
+constexpr uint32_t W_META = W_TOT + LRW * 4;                               // u32[LRW]  nbase | k << 16 | status << 24
+constexpr uint32_t W_PBEG = W_META + LRW * 4;                              // u16[LRW]  tab before the path column
+constexpr uint32_t W_PEND = W_PBEG + LRW * 2;                              // u16[LRW]  tab after the path column
+constexpr uint32_t W_NPOS = W_PEND + LRW * 2;                              // u16[NMAXW]  name start (orientation mark + 1)
+constexpr uint32_t W_NLINE = W_NPOS + NMAXW * 2;                           // u16[NMAXW]  line in round | orientation << 15
+constexpr uint32_t W_NFIRST = W_NLINE + NMAXW * 2;                         // u16[NMAXW]  first node of the line with the same name
+constexpr uint32_t W_NID = (W_NFIRST + NMAXW * 2 + 3) / 4 * 4;             // u32[NMAXW]
+constexpr uint32_t W_NPRE = W_NID + NMAXW * 4;                             // u32[NMAXW]  length, then inclusive prefix
+constexpr uint32_t WAVE_BYTES = (W_NPRE + NMAXW * 4 + 15) / 16 * 16;
+constexpr uint32_t LDS_MAIN = L_WAVE + NWAVE * WAVE_BYTES;
 
 // status words (device)
 struct DevStatus {
@@ -97,6 +105,23 @@ __device__ inline uint32_t eq_mask16(uint4 v, uint32_t pat) {          // 16-bit
     const uint32_t lo = __builtin_amdgcn_udot4(zero_bytes(v.x ^ pat), 0x08040201u, __builtin_amdgcn_udot4(zero_bytes(v.y ^ pat), 0x80402010u, 0u, false), false);
     const uint32_t hi = __builtin_amdgcn_udot4(zero_bytes(v.z ^ pat), 0x08040201u, __builtin_amdgcn_udot4(zero_bytes(v.w ^ pat), 0x80402010u, 0u, false), false);
     return (lo | (hi << 8)) >> 7;
+}
+
+// The same for text known to be pure ASCII (every byte < 0x80: no carries between the byte lanes of the SWAR add), four
+// operations per word instead of six.  `pat` bytes must be < 0x80 too.
+__device__ inline uint32_t ne_flags_ascii(uint32_t w, uint32_t pat) { return ((w ^ pat) + 0x7F7F7F7Fu) & 0x80808080u; }   // 0x80 where the byte differs
+__device__ inline uint32_t eq_mask16_ascii(uint4 v, uint32_t pat) {
+    const uint32_t lo = __builtin_amdgcn_udot4(ne_flags_ascii(v.x, pat), 0x08040201u, __builtin_amdgcn_udot4(ne_flags_ascii(v.y, pat), 0x80402010u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(ne_flags_ascii(v.z, pat), 0x08040201u, __builtin_amdgcn_udot4(ne_flags_ascii(v.w, pat), 0x80402010u, 0u, false), false);
+    return ~((lo | (hi << 8)) >> 7) & 0xFFFFu;
+}
+template <bool ASCII> __device__ inline uint32_t eq_mask16_t(uint4 v, uint32_t pat) { return ASCII ? eq_mask16_ascii(v, pat) : eq_mask16(v, pat); }
+template <bool ASCII> __device__ inline bool any_byte_t(uint4 v, uint32_t pat) {
+    if (ASCII) {
+        const uint32_t all = ((v.x ^ pat) + 0x7F7F7F7Fu) & ((v.y ^ pat) + 0x7F7F7F7Fu) & ((v.z ^ pat) + 0x7F7F7F7Fu) & ((v.w ^ pat) + 0x7F7F7F7Fu);
+        return (~all & 0x80808080u) != 0;
+    }
+    return (zero_bytes(v.x ^ pat) | zero_bytes(v.y ^ pat) | zero_bytes(v.z ^ pat) | zero_bytes(v.w ^ pat)) != 0;
 }
 
 __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
@@ -160,8 +185,8 @@ struct BitCursor {
     }
 };
 
-// Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the slot hash of the node-name table
-// (svjg_host_tables.h: name_hash_host).
+// Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the pre-hash of the node-name table
+// (svjg_host_tables.h: name_prehash_host).
 __device__ inline uint32_t name_words(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
     const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
     const uint32_t sh = a0 & 3u;
@@ -176,42 +201,95 @@ __device__ inline uint32_t name_words(const uint8_t *text, uint32_t a0, uint32_t
         prev = nx;
         h += d[i] * C[i];
     }
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
     return h;
 }
 
-__device__ inline bool name_match(const uint4 e0, const uint4 e1, const uint4 e2, const uint32_t d[8], uint32_t L) {
-    return (e2.x & 0xFFu) == L && e0.x == d[0] && e0.y == d[1] && e0.z == d[2] && e0.w == d[3] &&
-           e1.x == d[4] && e1.y == d[5] && e1.z == d[6] && e1.w == d[7];
+// the two candidate slots of a pre-hash in a two-choice table (svjg_host_tables.h: cuckoo_slots_host)
+__device__ inline void cuckoo_slots(uint32_t x, uint32_t seed, uint32_t mask, uint32_t &s1, uint32_t &s2) {
+    uint32_t p = x ^ seed;
+    p ^= p >> 15; p *= 0x2C1B3C6Du; p ^= p >> 12;
+    uint32_t q = (x + seed) * 0x85EBCA6Bu;
+    q ^= q >> 13; q *= 0xC2B2AE35u; q ^= q >> 16;
+    s1 = p & mask; s2 = q & mask;
+    if (s2 == s1) s2 = s1 ^ 1u;
 }
 
-__device__ inline uint32_t link_hash(uint32_t klo, uint32_t khi) {
-    uint32_t x = klo ^ (khi * 0x9E3779B1u);
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13;
-    return x;
+// entry of the node-name table (svjg_host_tables.h): q0 = name bytes 0..15, q1 = bytes 16..23 | meta | length in bp,
+// q2 (fetched for names longer than 24 bytes only) = bytes 24..31
+__device__ inline bool name_match(const uint4 q0, const uint4 q1, const uint4 q2, const uint32_t d[8], uint32_t L) {
+    return (q1.z & 31u) == L - 1u && q0.x == d[0] && q0.y == d[1] && q0.z == d[2] && q0.w == d[3] &&
+           q1.x == d[4] && q1.y == d[5] && (L <= 24u || (q2.x == d[6] && q2.y == d[7]));
 }
 
-#ifndef SVJG_UB
-#define SVJG_UB 1
+__device__ inline uint32_t link_prehash(uint32_t klo, uint32_t khi) { return klo ^ (khi * 0x9E3779B1u); }
+
+#ifndef SVJG_UB3
+#define SVJG_UB3 1
 #endif
-constexpr uint32_t UB = SVJG_UB;                    // path steps per lane / path nodes per lane quad handled at a time (loads in flight)
+#ifndef SVJG_UB5
+#define SVJG_UB5 2
+#endif
+constexpr uint32_t UB3 = SVJG_UB3, UB5 = SVJG_UB5;  // path nodes (R3) / path steps (R5) per lane handled at a time (table loads in flight)
+
+// LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, the fences only pin the compiler
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // The classify kernel.  One workgroup walks stripes of the GAF text; the next stripe's HBM loads are issued into
 // registers before the current one is processed, so the only HBM read of the text overlaps the parse.  Per stripe:
-//   A  registers -> LDS (16 B per lane, coalesced on the HBM side)
-//   B  one 208-byte SPAN per lane, branch-free SWAR classification of every byte: line terminators -> sorted
-//      line-start list (block prefix sum); tab and orientation-mark ('<' '>') bitmaps -> LDS
-//   then, in rounds of WG lines:
+//   A  registers -> LDS (16 B per lane, coalesced on the HBM side)                                   [workgroup barrier]
+//   B  one SPAN per lane, branch-free SWAR classification of every byte: tab and orientation-mark ('<' '>') bitmaps
+//      -> LDS, line terminators -> per-lane masks, wave prefix sum                                    [workgroup barrier]
+//   then every WAVE on its own (no workgroup barriers: the sixteen waves of a CU drift through different phases, so
+//   table latency of one overlaps the parsing of another), for the lines whose preceding terminator lies in the wave's
+//   SLICE of the stripe, in rounds of up to LRW lines / NMAXW path nodes:
 //   R1 one LINE per lane: the twelve column boundaries by bit-scanning the tab bitmap, the nine decimal columns by
-//      SWAR, path geometry; block prefix sum hands every line a contiguous range of node slots
+//      SWAR, path geometry; wave prefix sum hands every line a contiguous range of node slots
 //   R2 one LINE per lane: node slots filled from the orientation bitmap (name position, line, orientation)
-//   R3 one path NODE per lane: name -> (chromosome, coordinates) -> node id through the position buckets of the
-//      sorted node table (L2 / Infinity Cache resident), length
+//   R3 one path NODE per lane: name -> slot of the node-name hash table (Infinity Cache / L2 resident) -> id, length
 //   R4 one LINE per lane: running path length, first occurrence of every name (the reference's list.index /
 //      str.split quirks), validation
-//   R5 one path STEP (link) per lane: overlap test on the prefix sums, link lookup in the node's CSR row, one 64-bit
+//   R5 one path STEP (link) per lane: overlap test on the prefix sums, link hash table lookup, one 64-bit
 //      atomic (ref | alt << 32) per hit, optional hit records
 //   R6 deferred-line offsets, one aggregated atomic per wave
+//                                                                                                     [workgroup barrier]
+// Phase B of k_classify_main for one lane: classes of the SPAN bytes at text + tid * SPAN.  Tab and orientation-mark
+// bitmaps -> LDS; line terminators -> `mask` (two 16-bit masks per word), their number -> cnt, and how many of the
+// lines they start belong to this stripe -> owned.  terminator = '\n', or a '\r' not followed by '\n' (Python
+// universal newlines).
+template <bool ASCII>
+__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint16_t *tabbm16, uint16_t *oribm16, uint32_t tid,
+                                     uint64_t c0, uint32_t V, uint32_t own_lim, uint32_t (&mask)[(PIECES + 1) / 2], uint32_t &cnt, uint32_t &owned) {
+    const uint32_t sp = tid * SPAN;
+#pragma unroll
+    for (uint32_t pc = 0; pc < PIECES; ++pc) {
+        const uint4 v = *(const uint4 *)(text + sp + pc * 16);
+        uint32_t nl = eq_mask16_t<ASCII>(v, 0x0A0A0A0Au);
+        tabbm16[tid * PIECES + pc] = (uint16_t)eq_mask16_t<ASCII>(v, 0x09090909u);
+        oribm16[tid * PIECES + pc] = (uint16_t)eq_mask16_t<ASCII>(make_uint4(v.x | 0x02020202u, v.y | 0x02020202u, v.z | 0x02020202u, v.w | 0x02020202u), 0x3E3E3E3Eu);
+        // carriage returns: cheap any-test first (no text file has them in practice)
+        if (any_byte_t<ASCII>(v, 0x0D0D0D0Du)) {
+            uint32_t cr = eq_mask16(v, 0x0D0D0D0Du);
+            while (cr) {
+                uint32_t b = __builtin_ctz(cr); cr &= cr - 1;
+                uint32_t q = sp + pc * 16 + b;
+                uint8_t nx = (q + 1 < TEXT) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
+                if (nx != '\n') nl |= 1u << b;
+            }
+        }
+        const uint32_t pb = sp + pc * 16;                            // ignore anything at or beyond the valid length
+        if (pb >= V) nl = 0; else if (pb + 16 > V) nl &= (1u << (V - pb)) - 1u;
+        if (pc & 1) mask[pc >> 1] |= nl << 16; else mask[pc >> 1] = nl;
+        cnt += __builtin_popcount(nl);
+        // a terminator at pb + b starts a line at pb + b + 1; the stripe owns it if that is below own_lim
+        const uint32_t keep = own_lim > pb + 1 ? (own_lim - pb - 1 < 16u ? own_lim - pb - 1 : 16u) : 0u;
+        owned += __builtin_popcount(nl & ((1u << keep) - 1u));
+    }
+}
+
 #ifndef SVJG_MINW
 #define SVJG_MINW ((2 * SVJG_WG) / 256)
 #endif
@@ -220,23 +298,21 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     uint8_t *text = lds + L_TEXT;
     uint16_t *tabbm16 = (uint16_t *)(lds + L_TABBM), *oribm16 = (uint16_t *)(lds + L_ORIBM);
     const uint32_t *tabbm = (const uint32_t *)(lds + L_TABBM), *oribm = (const uint32_t *)(lds + L_ORIBM);
-    uint16_t *starts = (uint16_t *)(lds + L_STARTS);
-    uint32_t *l_ts = (uint32_t *)(lds + L_TS), *l_te = (uint32_t *)(lds + L_TE), *l_tlen = (uint32_t *)(lds + L_TLEN);
-    uint32_t *l_tot = (uint32_t *)(lds + L_TOT), *l_meta = (uint32_t *)(lds + L_META);
-    uint16_t *l_start = (uint16_t *)(lds + L_LSTART), *l_pbeg = (uint16_t *)(lds + L_PBEG), *l_pend = (uint16_t *)(lds + L_PEND);
-    uint16_t *n_pos = (uint16_t *)(lds + L_NPOS), *n_line = (uint16_t *)(lds + L_NLINE), *n_first = (uint16_t *)(lds + L_NFIRST);
-    uint32_t *n_id = (uint32_t *)(lds + L_NID), *n_pre = (uint32_t *)(lds + L_NPRE);
     uint32_t *misc = (uint32_t *)(lds + L_MISC);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t *wb = lds + L_WAVE + wave * WAVE_BYTES;                    // this wave's private arrays
+    uint16_t *rstart = (uint16_t *)(wb + W_RSTART);
+    uint32_t *l_ts = (uint32_t *)(wb + W_TS), *l_te = (uint32_t *)(wb + W_TE), *l_tlen = (uint32_t *)(wb + W_TLEN);
+    uint32_t *l_tot = (uint32_t *)(wb + W_TOT), *l_meta = (uint32_t *)(wb + W_META);
+    uint16_t *l_pbeg = (uint16_t *)(wb + W_PBEG), *l_pend = (uint16_t *)(wb + W_PEND);
+    uint16_t *n_pos = (uint16_t *)(wb + W_NPOS), *n_line = (uint16_t *)(wb + W_NLINE), *n_first = (uint16_t *)(wb + W_NFIRST);
+    uint32_t *n_id = (uint32_t *)(wb + W_NID), *n_pre = (uint32_t *)(wb + W_NPRE);
 
     const GraphView g = a.g;
 
-    unsigned long long wg_lines = 0;
-    unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    const bool stamp = (a.diag & 16u) != 0;
-#define SVJG_STAMP(i) do { if (stamp) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tprev; tprev = t_; } } while (0)
-    if (stamp) tprev = __builtin_amdgcn_s_memtime();
+    unsigned long long wave_lines = 0;
 
     // stripe prefetch registers
     uint4 pf[PIECES];
@@ -249,10 +325,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         pf_head = c0 ? a.gaf[c0 - 1] : (uint32_t)'\n';
     };
     prefetch(blockIdx.x);
+    if (tid == 0) misc[1] = 0;                                           // "stripe holds a byte >= 0x80"
+    __syncthreads();
 
     for (uint32_t chunk = blockIdx.x; chunk < a.n_chunks; chunk += gridDim.x) {
         const uint64_t c0 = (uint64_t)chunk * CHUNK;
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (uint64_t)TEXT) ? (a.n_bytes - c0) : (uint64_t)TEXT);   // valid bytes staged
+        const uint32_t own_lim = V < CHUNK ? V : CHUNK;                  // lines starting below this offset belong to the stripe
 
         // ---- A: registers -> LDS, then start the next stripe's HBM loads ---------------------------------
         uint32_t hi_bits = 0;
@@ -262,82 +341,75 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             *(uint4 *)(text + (i * WG + tid) * 16) = pf[i];
         }
         if (tid == 0) misc[0] = 0;
-        if (hi_bits & 0x80808080u) a.st->non_ascii = 1;
+        if (hi_bits & 0x80808080u) { a.st->non_ascii = 1; misc[1] = 1; }
         const uint32_t head_byte = pf_head;
         __syncthreads();
+        const bool ascii = misc[1] == 0;                                 // workgroup-uniform: the cheaper SWAR classes apply
         prefetch(chunk + gridDim.x);
-        SVJG_STAMP(0);
 
         // ---- B: byte classes ----------------------------------------------------------------------------
-        // terminator = '\n', or a '\r' not followed by '\n' (Python universal newlines)
         uint32_t mask[(PIECES + 1) / 2];                                 // two 16-bit terminator masks per word
-        uint32_t cnt = 0;
+        uint32_t cnt = 0, owned = 0;
         const uint32_t sp = tid * SPAN;
-#pragma unroll
-        for (uint32_t pc = 0; pc < PIECES; ++pc) {
-            const uint4 v = *(const uint4 *)(text + sp + pc * 16);
-            uint32_t nl = eq_mask16(v, 0x0A0A0A0Au);
-            tabbm16[tid * PIECES + pc] = (uint16_t)eq_mask16(v, 0x09090909u);
-            oribm16[tid * PIECES + pc] = (uint16_t)eq_mask16(make_uint4(v.x | 0x02020202u, v.y | 0x02020202u, v.z | 0x02020202u, v.w | 0x02020202u), 0x3E3E3E3Eu);
-            // carriage returns: cheap any-test first (no text file has them in practice)
-            const uint32_t crq = zero_bytes(v.x ^ 0x0D0D0D0Du) | zero_bytes(v.y ^ 0x0D0D0D0Du) | zero_bytes(v.z ^ 0x0D0D0D0Du) | zero_bytes(v.w ^ 0x0D0D0D0Du);
-            if (crq) {
-                uint32_t cr = eq_mask16(v, 0x0D0D0D0Du);
-                while (cr) {
-                    uint32_t b = __builtin_ctz(cr); cr &= cr - 1;
-                    uint32_t q = sp + pc * 16 + b;
-                    uint8_t nx = (q + 1 < TEXT) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
-                    if (nx != '\n') nl |= 1u << b;
-                }
-            }
-            uint32_t pb = sp + pc * 16;                                  // ignore anything at or beyond the valid length
-            if (pb >= V) nl = 0; else if (pb + 16 > V) nl &= (1u << (V - pb)) - 1u;
-            if (pc & 1) mask[pc >> 1] |= nl << 16; else mask[pc >> 1] = nl;
-            cnt += __builtin_popcount(nl);
-        }
+        if (ascii) classify_span<true>(a, text, tabbm16, oribm16, tid, c0, V, own_lim, mask, cnt, owned);
+        else classify_span<false>(a, text, tabbm16, oribm16, tid, c0, V, own_lim, mask, cnt, owned);
         uint32_t head = 0;                                               // does the stripe begin at a line start?
-        if (tid == 0) head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
-        uint32_t total;
-        uint32_t o = block_excl_scan(cnt + head, misc + 4, total);
-        uint32_t owned = 0;
-        const bool too_dense = total > MAXSTARTS;
-        if (!too_dense) {
-            if (head) { starts[o++] = 0; owned += (0 < V); }
+        if (tid == 0) { head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n'); owned += head & (0 < own_lim); }
+        // lines belong to the wave that sees the terminator in front of them: one wave prefix sum, no workgroup scan
+        uint32_t wsum;
+        const uint32_t sc = wave_excl_scan((cnt + head) | (owned << 16), wsum);
+        const uint32_t o = sc & 0xFFFFu;                                 // starts found by lower lanes of the wave
+        const uint32_t wtot = __builtin_amdgcn_readfirstlane(wsum & 0xFFFFu), n_w = __builtin_amdgcn_readfirstlane(wsum >> 16);
+        if (o == 0 && cnt + head) {                                      // the wave's first start (ends the previous wave's last line)
+            uint32_t first = 0;
+            if (!head) {
 #pragma unroll
-            for (uint32_t pc = 0; pc < PIECES; ++pc) {
-                uint32_t m = (pc & 1) ? (mask[pc >> 1] >> 16) : (mask[pc >> 1] & 0xFFFFu);
-                while (m) {
-                    uint32_t b = __builtin_ctz(m); m &= m - 1;
-                    uint32_t st = sp + pc * 16 + b + 1;
-                    starts[o++] = (uint16_t)st;
-                    owned += (st < CHUNK && st < V);
+                for (uint32_t pc = PIECES; pc-- > 0;) {
+                    const uint32_t m = (pc & 1) ? (mask[pc >> 1] >> 16) : (mask[pc >> 1] & 0xFFFFu);
+                    if (m) first = sp + pc * 16 + __builtin_ctz(m) + 1;
                 }
             }
+            misc[8 + wave] = first;
         }
-        if (owned) atomicAdd(&misc[0], owned);
+        if (lane == 0) { if (wtot) atomicAdd(&misc[0], wtot); else misc[8 + wave] = 0xFFFFu; }
         __syncthreads();
-        const uint32_t n_owned = misc[0];
-        if (too_dense) {
+        if (tid == 0) misc[1] = 0;                                       // (every wave has read it; set again only after the stripe's last barrier)
+        if (misc[0] > MAXSTARTS) {
             // more than TEXT/24 lines in the stripe: some line has fewer than 12 columns -> ValueError in the reference
             if (tid == 0) atomicMin(&a.st->err, ((a.base_offset + c0) << 3) | SVJG_EXC_VALUE_ERROR);
             __syncthreads();
             continue;
         }
         const bool at_eof = c0 + V == a.n_bytes;
-        SVJG_STAMP(1);
-        if (a.diag & 1u) { if (tid == 0) wg_lines += n_owned; __syncthreads(); continue; }
+        uint32_t nxt = 0xFFFFu;                                          // first line start found by a later wave (0xFFFF: none in the staged text)
+        for (uint32_t w = NWAVE - 1; w > wave; --w) { const uint32_t f = misc[8 + w]; if (f != 0xFFFFu) nxt = f; }
 
-        for (uint32_t base = 0; base < n_owned; base += LR) {           // uniform trip count across the block
+        for (uint32_t base = (a.diag & 1u) ? n_w : 0u, taken = 0; base < n_w; base += taken) {   // wave-uniform trip count
+            // ---- line starts of the round: rstart[i] = start of line base + i, rstart[count] = where the last one ends ----------
+            {
+                uint32_t idx = o;
+                if (head) { if (idx - base <= LRW) rstart[idx - base] = 0; ++idx; }
+#pragma unroll
+                for (uint32_t pc = 0; pc < PIECES; ++pc) {
+                    uint32_t m = (pc & 1) ? (mask[pc >> 1] >> 16) : (mask[pc >> 1] & 0xFFFFu);
+                    while (m) {
+                        const uint32_t b = __builtin_ctz(m); m &= m - 1;
+                        if (idx - base <= LRW) rstart[idx - base] = (uint16_t)(sp + pc * 16 + b + 1);
+                        ++idx;
+                    }
+                }
+                if (lane == 0 && wtot - base <= LRW) rstart[wtot - base] = (uint16_t)nxt;
+            }
+            wave_sync();
             // ---- R1: one line per lane --------------------------------------------------------------
-            if (tid == 0) misc[3] = 0;                                   // node slots in use this round
-            const uint32_t li = base + tid;
+            const uint32_t li = base + lane;
             uint32_t status = ST_NONE, k = 0, s = 0;
-            const bool line_lane = tid < LR;
-            if (line_lane && li < n_owned) {
-                s = starts[li];
+            if (lane < LRW && li < n_w) {
+                s = rstart[lane];
+                const uint32_t nx = rstart[lane + 1];
                 uint32_t e = V;
                 bool complete = true;
-                if (li + 1 < total) e = (uint32_t)starts[li + 1] - 1;
+                if (nx != 0xFFFFu) e = nx - 1;
                 else if (!at_eof) complete = false;
                 status = ST_DEFER;
                 if (complete && !a.all_slow) {
@@ -367,21 +439,23 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     ok &= k >= 1 && k <= KMAX;
                     if (ok) {
                         status = k >= 2 ? ST_OK : ST_NOHIT;
-                        l_ts[tid] = ts; l_te[tid] = te; l_tlen[tid] = tlen; l_pbeg[tid] = (uint16_t)t4; l_pend[tid] = (uint16_t)t5;
+                        l_ts[lane] = ts; l_te[lane] = te; l_tlen[lane] = tlen; l_pbeg[lane] = (uint16_t)t4; l_pend[lane] = (uint16_t)t5;
                     }
                 }
-                l_start[tid] = (uint16_t)s;
             }
             if (status != ST_OK) k = 0;
             uint32_t ntot;
-            uint32_t nbase = block_excl_scan(k, misc + 8, ntot);
-            (void)ntot;
-            if (status == ST_OK && nbase + k > NMAX) { status = ST_DEFER; k = 0; }     // node slots exhausted (very long paths)
-            if (k) atomicMax(&misc[3], nbase + k);
-            SVJG_STAMP(2);
+            const uint32_t nbase = wave_excl_scan(k, ntot);
+            // node slots exhausted: the round ends in front of the first line that does not fit (it opens the next round)
+            const unsigned long long over = __ballot(nbase + k > NMAXW);
+            const uint32_t avail = n_w - base < LRW ? n_w - base : LRW;
+            taken = over ? (uint32_t)__builtin_ctzll(over) : avail;
+            if (taken > avail) taken = avail;
+            if (lane >= taken) { status = ST_NONE; k = 0; }
+            const uint32_t n_nodes = (uint32_t)__shfl(nbase + k, (int)taken - 1);
             // ---- R2: node slots from the orientation bitmap; every name must be non-empty ------------------------
             if (k) {
-                const uint32_t pa = (uint32_t)l_pbeg[tid] + 1, pbnd = l_pend[tid];
+                const uint32_t pa = (uint32_t)l_pbeg[lane] + 1, pbnd = l_pend[lane];
                 BitCursor oc{oribm, pa >> 5, 0, pbnd};
                 oc.cur = oribm[pa >> 5] & (0xFFFFFFFFu << (pa & 31));
                 uint32_t prev = pa - 1;
@@ -391,25 +465,25 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     ok &= (j == 0) | (q > prev + 1);
                     prev = q;
                     n_pos[nbase + j] = (uint16_t)(q + 1);
-                    n_line[nbase + j] = (uint16_t)tid;                  // orientation bit added by the node's lane (R3)
+                    n_line[nbase + j] = (uint16_t)lane;                 // orientation bit added by the node's lane (R3)
                 }
                 ok &= pbnd > prev + 1;
                 if (!ok) status = ST_DEFER;
             }
-            if (line_lane) l_meta[tid] = nbase | (k << 16) | (status << 24);
-            __syncthreads();
-            SVJG_STAMP(3);
-            const uint32_t n_nodes = (a.diag & 2u) ? 0u : misc[3];
-            // ---- R3: one node per lane; UB nodes per lane so that ONE round trip to the name table serves the whole round:
-            //      hash all names, issue all entry loads, then compare the spelling (occupied slots walk on, rarely) --------
-            for (uint32_t nb = 0; nb < n_nodes; nb += UB * WG) {
-                uint32_t nn[UB], lnv[UB], d[UB][8], slot[UB], len[UB];
-                uint4 e0[UB], e1[UB], e2[UB];
-                bool live[UB], probe[UB];
+            if (lane < LRW) l_meta[lane] = nbase | (k << 16) | (status << 24);
+            wave_sync();
+            if (a.diag & 2u) continue;                                   // measurement only: stop after R2
+            // ---- R3: one node per lane: hash the name, fetch BOTH candidate entries of the two-choice name table at once
+            //      (one round trip for every lane, no probe sequences), compare the spelling --------------------------------
+            for (uint32_t nb = 0; nb < n_nodes; nb += UB3 * 64) {
+                uint32_t nn[UB3], lnv[UB3], d[UB3][8], len[UB3];
+                uint4 e0[UB3][2], e1[UB3][2], e2[UB3][2];
+                bool live[UB3], probe[UB3];
 #pragma unroll
-                for (uint32_t u = 0; u < UB; ++u) {
-                    nn[u] = nb + u * WG + tid;
-                    live[u] = false; probe[u] = false; lnv[u] = 0; slot[u] = 0; len[u] = 0;
+                for (uint32_t u = 0; u < UB3; ++u) {
+                    nn[u] = nb + u * 64 + lane;
+                    live[u] = false; probe[u] = false; lnv[u] = 0; len[u] = 0;
+                    uint32_t s1 = 0, s2 = 0;
                     if (nn[u] < n_nodes) {
                         lnv[u] = n_line[nn[u]] & 0x7FFFu;
                         const uint32_t meta = l_meta[lnv[u]];
@@ -421,27 +495,29 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                             if (text[a0 - 1] == '<') n_line[nn[u]] = (uint16_t)(lnv[u] | 0x8000u);
                             len[u] = b0 - a0;
                             probe[u] = len[u] - 1u <= 31u && !(a.diag & 4u);     // names of 1..32 bytes; longer ones: exact path
-                            if (probe[u]) slot[u] = name_words(text, a0, len[u], d[u]) & g.name_mask;
+                            if (probe[u]) cuckoo_slots(name_words(text, a0, len[u], d[u]), g.name_seed, g.name_mask, s1, s2);
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t c = 0; c < 2; ++c) {
+                        e0[u][c] = e2[u][c] = make_uint4(0, 0, 0, 0); e1[u][c] = make_uint4(0, 0, 0xFFFFFFFFu, 0);
+                        if (probe[u]) {
+                            const uint4 *e = (const uint4 *)(g.name_tab + (size_t)(c ? s2 : s1) * 16);
+                            e0[u][c] = e[0]; e1[u][c] = e[1];
+                            if (len[u] > 24u) e2[u][c] = e[2];
                         }
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < UB; ++u) {
-                    e0[u] = e1[u] = e2[u] = make_uint4(0, 0, 0, 0);
-                    if (probe[u]) { const uint4 *e = (const uint4 *)(g.name_tab + (size_t)slot[u] * 16); e0[u] = e[0]; e1[u] = e[1]; e2[u] = e[2]; }
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < UB; ++u) {
+                for (uint32_t u = 0; u < UB3; ++u) {
                     if (live[u]) {
                         uint32_t id = NONE32, lbp = 0;
                         if (probe[u]) {
-                            while ((e2[u].x & 0xFFu) != 0 && !name_match(e0[u], e1[u], e2[u], d[u], len[u])) {     // occupied by another name
-                                slot[u] = (slot[u] + 1) & g.name_mask;
-                                const uint4 *e = (const uint4 *)(g.name_tab + (size_t)slot[u] * 16);
-                                e0[u] = e[0]; e1[u] = e[1]; e2[u] = e[2];
-                            }
-                            // byte length | flags << 8, node id, length in bp; hazard-prone name / unknown alt length: exact path
-                            if ((e2[u].x & 0xFFu) != 0 && !(e2[u].x & 0x300u)) { id = e2[u].y; lbp = e2[u].z; }
+                            const bool m0 = name_match(e0[u][0], e1[u][0], e2[u][0], d[u], len[u]);
+                            const bool m1 = name_match(e0[u][1], e1[u][1], e2[u][1], d[u], len[u]);
+                            const uint32_t mz = m0 ? e1[u][0].z : e1[u][1].z, mw = m0 ? e1[u][0].w : e1[u][1].w;
+                            // id << 7 | flags << 5 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
+                            if ((m0 | m1) && mz != 0xFFFFFFFFu && !(mz & 0x60u)) { id = mz >> 7; lbp = mw; }
                         }
                         if (a.diag & 4u) { id = 0; lbp = 100; }
                         n_id[nn[u]] = id; n_pre[nn[u]] = lbp;
@@ -449,11 +525,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
             }
-            __syncthreads();
-            SVJG_STAMP(4);
+            wave_sync();
+            if (a.diag & 64u) continue;                                  // measurement only: stop after R3
             // ---- R4: one line per lane: prefix sums, first occurrences --------------------------------------
-            if (line_lane) {
-                const uint32_t meta = l_meta[tid];
+            if (lane < taken) {
+                const uint32_t meta = l_meta[lane];
                 if ((meta >> 24) == ST_OK) {
                     const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
                     unsigned long long run = 0, seen1 = 0, seen2 = 0;
@@ -469,21 +545,20 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         seen1 |= b1; seen2 |= b2;
                         n_first[lnb + j] = (uint16_t)(lnb + f);
                     }
-                    l_tot[tid] = (uint32_t)run;
-                    if (run > 0xFFFFFFFFull) l_meta[tid] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
+                    l_tot[lane] = (uint32_t)run;
+                    if (run > 0xFFFFFFFFull) l_meta[lane] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
                 }
             }
-            __syncthreads();
-            SVJG_STAMP(5);
-            // ---- R5: one path step per lane; UB steps per lane, all link-table entries fetched in one round trip ------------
-            for (uint32_t nb = 0; nb < n_nodes; nb += UB * WG) {
-                uint32_t lnv[UB], klo[UB], khi[UB], slot[UB];
-                uint4 ek[UB];
-                bool go[UB];
+            wave_sync();
+            // ---- R5: one path step per lane; UB5 steps per lane, both candidate link-table entries of every step fetched in one round trip ------------
+            for (uint32_t nb = 0; nb < n_nodes; nb += UB5 * 64) {
+                uint32_t lnv[UB5], klo[UB5], khi[UB5], sa[UB5], sb[UB5];
+                uint4 ek[UB5], ek2[UB5];
+                bool go[UB5];
 #pragma unroll
-                for (uint32_t u = 0; u < UB; ++u) {
-                    const uint32_t n = nb + u * WG + tid;
-                    go[u] = false; lnv[u] = 0; klo[u] = khi[u] = slot[u] = 0;
+                for (uint32_t u = 0; u < UB5; ++u) {
+                    const uint32_t n = nb + u * 64 + lane;
+                    go[u] = false; lnv[u] = 0; klo[u] = khi[u] = sa[u] = sb[u] = 0;
                     if (n + 1 < n_nodes) {
                         const uint32_t ln = n_line[n] & 0x7FFFu;
                         const uint32_t meta = l_meta[ln];
@@ -499,25 +574,22 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                                 go[u] = true; lnv[u] = ln;
                                 klo[u] = (n_id[n + 1] << 1) | (uint32_t)(n_line[fr] >> 15);
                                 khi[u] = (n_id[n] << 1) | (uint32_t)(n_line[fl] >> 15);
-                                slot[u] = link_hash(klo[u], khi[u]) & g.link_mask;
+                                cuckoo_slots(link_prehash(klo[u], khi[u]), g.link_seed, g.link_mask, sa[u], sb[u]);
                             }
                         }
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < UB; ++u) {
-                    ek[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
-                    if (go[u]) ek[u] = *(const uint4 *)(g.link_tab + (size_t)slot[u] * 4);
+                for (uint32_t u = 0; u < UB5; ++u) {
+                    ek[u] = ek2[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
+                    if (go[u]) { ek[u] = *(const uint4 *)(g.link_tab + (size_t)sa[u] * 4); ek2[u] = *(const uint4 *)(g.link_tab + (size_t)sb[u] * 4); }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < UB; ++u) {
+                for (uint32_t u = 0; u < UB5; ++u) {
                     uint32_t nh = 0, ea = 0, eb = 0;
                     bool many = false;
                     if (go[u]) {
-                        while (!(ek[u].x == klo[u] && ek[u].y == khi[u]) && (ek[u].x & ek[u].y) != 0xFFFFFFFFu) {   // occupied by another link
-                            slot[u] = (slot[u] + 1) & g.link_mask;
-                            ek[u] = *(const uint4 *)(g.link_tab + (size_t)slot[u] * 4);
-                        }
+                        if (!(ek[u].x == klo[u] && ek[u].y == khi[u])) ek[u] = ek2[u];                 // the other candidate slot
                         if (ek[u].x == klo[u] && ek[u].y == khi[u]) {
                             // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
                             ea = ek[u].z; eb = ek[u].w;
@@ -528,9 +600,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // hit records: one aggregated atomic per wave reserves the slots
                     unsigned long long rbase = 0;
                     if (a.want_hits) {
-                        uint32_t wtot, ex = wave_excl_scan(nh, wtot);
-                        if (wtot) {
-                            if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot);
+                        uint32_t wtot2, ex = wave_excl_scan(nh, wtot2);
+                        if (wtot2) {
+                            if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot2);
                             rbase = __shfl(rbase, 0) + ex;
                         }
                     }
@@ -539,7 +611,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
                         if (a.want_hits) {
                             if (rbase + j < a.rec_cap) {
-                                svjg_hitrec r; r.line_start = a.base_offset + c0 + l_start[lnv[u]]; r.slot = hv >> 1;
+                                svjg_hitrec r; r.line_start = a.base_offset + c0 + rstart[lnv[u]]; r.slot = hv >> 1;
                                 r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
                                 a.recs[rbase + j] = r;
                             } else atomicOr(&a.st->overflow, 2u);
@@ -547,10 +619,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
             }
-            SVJG_STAMP(6);
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
-                const bool defer = line_lane && li < n_owned && (l_meta[tid] >> 24) == ST_DEFER;
+                const bool defer = lane < taken && (l_meta[lane] >> 24) == ST_DEFER;
                 unsigned long long db = __ballot(defer);
                 if (db) {
                     unsigned long long dbase = 0;
@@ -562,14 +633,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
             }
-            __syncthreads();                                             // round state is reused
-            SVJG_STAMP(7);
+            wave_sync();                                                 // round state is reused
         }
-        if (tid == 0) wg_lines += n_owned;
+        wave_lines += n_w;
+        __syncthreads();                                                 // text and bitmaps are overwritten by the next stripe
     }
-    if (tid == 0 && wg_lines) atomicAdd(&a.st->n_lines, wg_lines);
-    if (stamp && tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], ph[i]);
-#undef SVJG_STAMP
+    if (lane == 0 && wave_lines) atomicAdd(&a.st->n_lines, wave_lines);
 }
 
 struct SlowEmit {

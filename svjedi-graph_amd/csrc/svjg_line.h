@@ -37,9 +37,9 @@ struct GraphView {
     uint32_t hash_mask;
     uint32_t d_over;
     const uint32_t *name_tab;    // main kernel: canonical node name -> node (svjg_host_tables.h), 16 words per entry
-    uint32_t name_mask;
+    uint32_t name_mask, name_seed;
     const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 4 words per entry
-    uint32_t link_mask;
+    uint32_t link_mask, link_seed;
 };
 
 

@@ -20,7 +20,7 @@ static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &has
     v.nodes = g->nodes; v.n_nodes = (uint32_t)g->n_nodes; v.edges = g->edges; v.hits = g->hits;
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
-    v.name_tab = nullptr; v.name_mask = 0; v.link_tab = nullptr; v.link_mask = 0;     // main-kernel tables: not used by the exact path
+    v.name_tab = nullptr; v.name_mask = 0; v.name_seed = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;     // main-kernel tables: not used by the exact path
     return v;
 }
 
@@ -49,33 +49,37 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
 // id, every CSR entry is found under its key with the same hits
 extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
     KernelTables kt = build_kernel_tables(*g);
-    uint64_t bad = 0, found = 0;
+    uint64_t bad = kt.names_left_out + kt.links_left_out, found = 0;
     for (uint64_t j = 0; j <= kt.name_mask; ++j) {
         const uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
-        if (!(e[8] & 0xFFu)) continue;
+        if (name_ent_empty(e)) continue;
         ++found;
-        uint64_t q = name_hash_host(e, e[8] & 0xFFu) & kt.name_mask, steps = 0;
-        while (q != j && steps <= kt.name_mask) { if (!(kt.names[q * NAME_ENT_WORDS + 8] & 0xFFu)) { ++bad; break; } q = (q + 1) & kt.name_mask; ++steps; }
-        const svjg_node &nd = g->nodes[e[9]];
+        uint32_t d[8], s1, s2;
+        name_ent_words(e, d);
+        cuckoo_slots_host(name_prehash_host(d, name_ent_len(e)), kt.name_seed, kt.name_mask, s1, s2);
+        if (j != s1 && j != s2) ++bad;                                   // reachable by the kernel's two probes
+        const svjg_node &nd = g->nodes[name_ent_id(e)];
         uint32_t kind = (uint32_t)(nd.key >> 15) & 1u, pos = (uint32_t)(nd.key >> 16);
-        if (e[10] != (kind ? nd.aux : nd.aux - pos + 1)) ++bad;
+        if (e[7] != (kind ? nd.aux : nd.aux - pos + 1)) ++bad;
+        for (uint32_t b = name_ent_len(e); b < 32; ++b) if ((d[b >> 2] >> (8 * (b & 3))) & 0xFFu) ++bad;     // zero padded
     }
     if (found > g->n_nodes) ++bad;
+    uint64_t n_links = 0;
     for (uint64_t n = 0; n < g->n_nodes; ++n)
         for (uint32_t i = g->nodes[n].row & 0x7FFFFFFFu; i < (g->nodes[n + 1].row & 0x7FFFFFFFu); ++i) {
             const svjg_edge &ed = g->edges[i];
             uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
-            uint64_t q = link_hash_host(key) & kt.link_mask;
-            for (;;) {
-                const uint32_t *e = &kt.links[q * LINK_ENT_WORDS];
-                if (e[0] == 0xFFFFFFFFu && e[1] == 0xFFFFFFFFu) { ++bad; break; }
-                if (e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32)) {
-                    const uint32_t nh = ed.meta >> 2;
-                    if (nh == 1 ? (e[2] != ed.h0 || e[3] != LINK_NO_HIT) : nh == 2 ? (e[2] != ed.h0 || e[3] != ed.h1) : (e[2] != (LINK_MANY | ed.h0) || e[3] != nh)) ++bad;
-                    break;
-                }
-                q = (q + 1) & kt.link_mask;
-            }
+            uint32_t s1, s2;
+            cuckoo_slots_host(link_prehash_host(key), kt.link_seed, kt.link_mask, s1, s2);
+            const uint32_t *e = &kt.links[(uint64_t)s1 * LINK_ENT_WORDS];
+            if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) e = &kt.links[(uint64_t)s2 * LINK_ENT_WORDS];
+            if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) { ++bad; continue; }
+            const uint32_t nh = ed.meta >> 2;
+            if (nh == 1 ? (e[2] != ed.h0 || e[3] != LINK_NO_HIT) : nh == 2 ? (e[2] != ed.h0 || e[3] != ed.h1) : (e[2] != (LINK_MANY | ed.h0) || e[3] != nh)) ++bad;
+            ++n_links;
         }
+    uint64_t occupied = 0;
+    for (uint64_t j = 0; j <= kt.link_mask; ++j) occupied += !(kt.links[j * LINK_ENT_WORDS] == 0xFFFFFFFFu && kt.links[j * LINK_ENT_WORDS + 1] == 0xFFFFFFFFu);
+    if (occupied != n_links) ++bad;
     return bad;
 }
