@@ -157,6 +157,7 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     c->gv.chrom_names = c->d_cnames; c->gv.chrom_off = c->d_coff; c->gv.chrom_lo = c->d_clo; c->gv.chrom_hash = c->d_chash;
     c->gv.n_chrom = g->n_chrom; c->gv.hash_mask = (uint32_t)hash.size() - 1; c->gv.d_over = g->d_over;
     c->gv.name_tab = c->d_names; c->gv.name_mask = kt.name_mask; c->gv.name_seed = kt.name_seed;
+    c->gv.name_complete = (kt.names_left_out == 0 && kt.names_skipped == 0) ? 1u : 0u;
     c->gv.link_tab = c->d_links; c->gv.link_mask = kt.link_mask; c->gv.link_seed = kt.link_seed;
     c->gflags = g->flags;
     c->n_slots = g->n_slots;
@@ -260,7 +261,8 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         c->ms_slow = 0;
         if (n_def && !(c->h_st.overflow & 1u)) {
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-            hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)((n_def + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, a, n_def);
+            const uint64_t want_blocks = (n_def + SLOW_TPB - 1) / SLOW_TPB, max_blocks = (uint64_t)c->n_cu * 4;     // 32 KB of LDS each: four per CU
+            hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)(want_blocks < max_blocks ? want_blocks : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
             HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));

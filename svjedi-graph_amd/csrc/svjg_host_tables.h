@@ -84,6 +84,7 @@ struct KernelTables {
     std::vector<uint32_t> names; uint32_t name_mask = 0, name_seed = 0;
     std::vector<uint32_t> links; uint32_t link_mask = 0, link_seed = 0;
     uint64_t names_left_out = 0, links_left_out = 0;
+    uint32_t names_skipped = 0;                               // node names the table cannot hold (> 32 bytes, id too large)
 };
 
 // Two-choice placement by random-walk eviction.  pre[i] = pre-hash of key i; returns owner[slot] = key index or -1.
@@ -133,7 +134,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             uint32_t c = (uint32_t)(nd.key >> 48), pos = (uint32_t)(nd.key >> 16), kind = (uint32_t)(nd.key >> 15) & 1u, cnt = (uint32_t)nd.key & 0x7FFFu;
             std::string nm(g.chrom_names + g.chrom_off[c], g.chrom_off[c + 1] - g.chrom_off[c]);
             nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
-            if (nm.size() > 32 || i > NAME_MAX_ID) continue;    // such a name can only be handled by the exact path
+            if (nm.size() > 32 || i > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path
             uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (size_t b = 0; b < nm.size(); ++b) d[b >> 2] |= (uint32_t)(uint8_t)nm[b] << (8 * (b & 3));
             uint32_t flags = ((nd.row & 0x80000000u) ? 1u : 0u) | ((kind && nd.aux == SVJG_LEN_UNKNOWN) ? 2u : 0u);

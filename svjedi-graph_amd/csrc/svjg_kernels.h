@@ -9,7 +9,7 @@
 //                      D  wave-level commit: packed 64-bit (ref | alt << 32) atomics into the per-SV
 //                         count vector, hit records and deferred-line offsets appended with one
 //                         wave-aggregated atomic each
-//   k_classify_slow  one lane per deferred line, exact string path (svjg::slow_line) straight from HBM
+//   k_classify_slow  one lane per deferred line, exact string path (svjg::slow_line) on an LDS copy of the line
 //   k_logfact_*      log10(i!) table in double-double for the binomial term
 //   k_genotype       one VCF row per lane, fp64 / double-double likelihoods (predict-genotype.py:281-325)
 #pragma once
@@ -41,7 +41,7 @@ constexpr uint32_t TEXT = SPAN * WG;             // 40 KB staged in LDS
 constexpr uint32_t LOOK = SVJG_LOOK;             // look-ahead so that lines starting in the stripe are complete
 constexpr uint32_t CHUNK = TEXT - LOOK;          // bytes of text owned by one workgroup iteration (a "stripe")
 constexpr uint32_t MAXSTARTS = TEXT / 24 + 8;    // a valid line has >= 24 bytes incl. its terminator
-constexpr uint32_t KMAX = 16;                    // path nodes per alignment handled by the main kernel
+constexpr uint32_t KMAX = 128;                   // path nodes per alignment handled by the main kernel (longer paths: exact path)
 constexpr uint32_t LRW = SVJG_LRW;               // lines per wave and round (line-granular phases use the first LRW lanes)
 constexpr uint32_t NMAXW = SVJG_NMAXW;           // path nodes per wave and round
 static_assert(LRW <= 64 && KMAX <= NMAXW, "round geometry");
@@ -656,14 +656,46 @@ struct SlowEmit {
     }
 };
 
-__global__ __launch_bounds__(TPB) void k_classify_slow(ClassifyArgs a, uint64_t n_def) {
-    uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n_def) return;
-    uint64_t s = a.deferred[i], e = s;
-    while (e < a.n_bytes && a.gaf[e] != '\n' && a.gaf[e] != '\r') ++e;
-    SlowEmit em{&a, a.base_offset + s};
-    int rc = slow_line(a.g, a.gaf, s, e, em);
-    if (rc) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (unsigned long long)rc);
+// The exact path: one lane per deferred line (svjg::slow_line, the reference's string semantics).  slow_line indexes
+// the text byte by byte, so every wave first packs its 64 lines into LDS (each lane finds its line's terminator and
+// copies the line, 16 bytes per step) and the string logic then pays LDS latency per byte, not HBM latency.  A line
+// that does not fit (longer than SLOW_MAXLINE, or the 64 lines together exceed the buffer) is read in place.
+constexpr uint32_t SLOW_TPB = 64, SLOW_LDS = 32 * 1024, SLOW_MAXLINE = 16 * 1024;
+__global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint64_t n_def) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t b0 = (uint64_t)blockIdx.x * SLOW_TPB; b0 < n_def; b0 += (uint64_t)gridDim.x * SLOW_TPB) {
+        const bool have = b0 + lane < n_def;
+        uint64_t s = 0, e = 0;
+        if (have) {
+            s = a.deferred[b0 + lane];
+            e = ~0ull;
+            for (uint64_t p = s & ~15ull; e == ~0ull; p += 16) {     // the buffer is 16-byte aligned and zero padded far beyond n_bytes
+                const uint4 v = *(const uint4 *)(a.gaf + p);
+                uint32_t m = eq_mask16(v, 0x0A0A0A0Au) | eq_mask16(v, 0x0D0D0D0Du);
+                if (p + 16 > a.n_bytes) m |= p >= a.n_bytes ? 0xFFFFu : (0xFFFFu << (a.n_bytes - p)) & 0xFFFFu;   // the text ends here
+                if (p < s) m &= 0xFFFFu << (s - p);
+                if (m) e = p + (uint64_t)__builtin_ctz(m);
+            }
+        }
+        const uint64_t a0 = s & ~15ull;
+        const uint64_t span = have ? ((e - a0 + 15) & ~15ull) : 0;        // bytes of the aligned blocks that hold the line
+        const uint32_t want = span <= SLOW_MAXLINE ? (uint32_t)span : 0u;
+        uint32_t tot;
+        const uint32_t off = wave_excl_scan(want, tot);
+        const bool staged = have && want && off + want <= SLOW_LDS;
+        if (staged)
+            for (uint32_t o = 0; o < want; o += 16) *(uint4 *)(stage + off + o) = *(const uint4 *)(a.gaf + a0 + o);
+        __syncthreads();
+        if (have) {
+            const uint8_t *t = staged ? (const uint8_t *)stage + off : a.gaf;
+            const uint64_t s2 = staged ? s - a0 : s;
+            SlowEmit em{&a, a.base_offset + s};
+            int rc = slow_line(a.g, t, s2, s2 + (e - s), em);
+            if (rc) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (unsigned long long)rc);
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

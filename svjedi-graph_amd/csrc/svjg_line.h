@@ -1,5 +1,5 @@
 // Graph-table lookups shared by the classify kernels, and the EXACT per-line routine (slow_line) that
-// evaluates a deferred GAF line straight from HBM with the reference's string semantics, including the
+// evaluates a deferred GAF line with the reference's string semantics, including the
 // exception it would raise.  The main kernel (svjg_kernels.h, k_classify_main) handles the regular case —
 // canonical node names that exist in the graph, plain decimal columns — and defers anything else; nothing
 // is ever guessed.
@@ -15,7 +15,7 @@
 #include "../../include/svjg.h"
 
 #ifndef SVJG_HD
-#define SVJG_HD __host__ __device__ inline
+#define SVJG_HD __host__ __device__ inline __attribute__((always_inline))
 #endif
 
 namespace svjg {
@@ -38,6 +38,7 @@ struct GraphView {
     uint32_t d_over;
     const uint32_t *name_tab;    // main kernel: canonical node name -> node (svjg_host_tables.h), 16 words per entry
     uint32_t name_mask, name_seed;
+    uint32_t name_complete;      // every node name is in name_tab: a miss there means "no such node" (else: search the sorted table)
     const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 4 words per entry
     uint32_t link_mask, link_seed;
 };
@@ -171,21 +172,46 @@ SVJG_HD bool bytes_eq(P t, uint64_t a, uint64_t b, uint64_t n) {
 
 struct NameRef { uint64_t s, e; };     // node name = t[s, e)
 
-// i-th node name of the path t[ps, pe).  oriented: non-empty pieces between '<' / '>' ; otherwise the
-// comma-separated pieces minus their last character (filter-alignments.py:366-371).
+// Node names of the path t[ps, pe), one after the other.  oriented: non-empty pieces between '<' / '>' ; otherwise the
+// comma-separated pieces minus their last character (filter-alignments.py:366-371).  `pos` starts at ps and is
+// advanced past the returned piece; false when the path is exhausted.
 template <class P>
-SVJG_HD bool nth_node(P t, uint64_t ps, uint64_t pe, bool oriented, uint32_t i, NameRef &out) {
-    uint64_t st = ps; uint32_t seen = 0;
-    for (uint64_t q = ps; q <= pe; ++q) {
+SVJG_HD bool next_node(P t, uint64_t pe, bool oriented, uint64_t &pos, NameRef &out) {
+    uint64_t st = pos;
+    for (uint64_t q = pos; q <= pe; ++q) {
         bool brk = q == pe || (oriented ? (t[q] == '<' || t[q] == '>') : t[q] == ',');
         if (!brk) continue;
-        if (q > st) {
-            if (seen == i) { out.s = st; out.e = oriented ? q : q - 1; return true; }
-            ++seen;
-        }
+        if (q > st) { out.s = st; out.e = oriented ? q : q - 1; pos = q + 1; return true; }
         st = q + 1;
     }
+    pos = pe + 1;
     return false;
+}
+
+// Two-choice node-name table of the main kernel (svjg_host_tables.h), probed with the raw bytes of a name of 1..32 bytes:
+// node id, or NONE32 when neither candidate slot holds this spelling.
+template <class P>
+SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
+    const uint32_t len = (uint32_t)(nm.e - nm.s);
+    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t b = 0; b < len; ++b) d[b >> 2] |= (uint32_t)(uint8_t)t[nm.s + b] << (8 * (b & 3));
+    const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+    uint32_t x = len * 0x7FEB352Du;
+    for (int i = 0; i < 8; ++i) x += d[i] * C[i];
+    uint32_t p = x ^ g.name_seed;
+    p ^= p >> 15; p *= 0x2C1B3C6Du; p ^= p >> 12;
+    uint32_t q = (x + g.name_seed) * 0x85EBCA6Bu;
+    q ^= q >> 13; q *= 0xC2B2AE35u; q ^= q >> 16;
+    uint32_t s1 = p & g.name_mask, s2 = q & g.name_mask;
+    if (s2 == s1) s2 = s1 ^ 1u;
+    for (int c = 0; c < 2; ++c) {
+        const uint32_t *e = g.name_tab + (uint64_t)(c ? s2 : s1) * 16;
+        const uint32_t meta = e[6];
+        if (meta == 0xFFFFFFFFu || (meta & 31u) != len - 1u) continue;
+        if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && e[8] == d[6] && e[9] == d[7])
+            return meta >> 7;
+    }
+    return NONE32;
 }
 
 // exact name -> node id (only canonical spellings can be in the table)
@@ -198,6 +224,10 @@ SVJG_HD uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_
         for (uint64_t q = (colon == nm.e ? nm.s : colon + 1); q < nm.e; ++q) if (t[q] == '.') *is_alt_form = true;
     }
     if (colon == nm.e) return NONE32;
+    if (g.name_tab && nm.e - nm.s <= 32) {                             // the canonical spelling is the only one that resolves
+        uint32_t id = name_tab_find(g, t, nm);
+        if (id != NONE32 || g.name_complete) return id;
+    }
     uint32_t h = FNV_INIT;
     for (uint64_t q = nm.s; q < colon; ++q) h = (h ^ (uint32_t)t[q]) * FNV_PRIME;
     uint32_t cidx = chrom_lookup(g, t, nm.s, (uint32_t)(colon - nm.s), h);
@@ -284,19 +314,17 @@ SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emi
     if (pe == ps) return SVJG_EXC_INDEX_ERROR;                     // p[0]
     bool oriented = t[ps] == '<' || t[ps] == '>';
     uint32_t k = 0;
-    { NameRef nm{0, 0}; while (nth_node(t, ps, pe, oriented, k, nm)) ++k; }
+    { NameRef nm{0, 0}; uint64_t pos = ps; while (next_node(t, pe, oriented, pos, nm)) ++k; }
     if (k < 2) return 0;
-    for (uint32_t i = 0; i < k; ++i) {                             // get_aln_links walks every node first
-        NameRef nm{0, 0}; uint32_t st = 0;
-        nth_node(t, ps, pe, oriented, i, nm);
-        int rc = strand_of(t, ps, pe, nm, st);
-        if (rc) return rc;
-    }
+    { NameRef nm{0, 0}; uint64_t pos = ps;                         // get_aln_links walks every node first
+      while (next_node(t, pe, oriented, pos, nm)) { uint32_t st = 0; int rc = strand_of(t, ps, pe, nm, st); if (rc) return rc; } }
     int64_t Tlen = v[6], Ts = v[7], Te = v[8];
-    for (uint32_t i = 0; i + 1 < k; ++i) {
-        NameRef L{0, 0}, R{0, 0}; uint32_t sl = 0, sr = 0;
-        nth_node(t, ps, pe, oriented, i, L);
-        nth_node(t, ps, pe, oriented, i + 1, R);
+    NameRef L{0, 0}, R{0, 0};
+    uint64_t posL = ps;
+    next_node(t, pe, oriented, posL, L);
+    for (uint32_t i = 0; i + 1 < k; ++i, L = R) {
+        uint32_t sl = 0, sr = 0;
+        next_node(t, pe, oriented, posL, R);
         strand_of(t, ps, pe, L, sl);
         strand_of(t, ps, pe, R, sr);
         uint32_t lid = resolve_name(g, t, L, nullptr), rid = resolve_name(g, t, R, nullptr);
@@ -306,12 +334,20 @@ SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emi
         svjg_edge ed = g.edges[ei];
         uint32_t nh = ed.meta >> 2;
         if (!nh) continue;
-        uint32_t il = 0, ir = 0; NameRef nm{0, 0};
-        for (;; ++il) { nth_node(t, ps, pe, oriented, il, nm); if (nm.e - nm.s == L.e - L.s && bytes_eq(t, nm.s, L.s, L.e - L.s)) break; }
-        for (;; ++ir) { nth_node(t, ps, pe, oriented, ir, nm); if (nm.e - nm.s == R.e - R.s && bytes_eq(t, nm.s, R.s, R.e - R.s)) break; }
+        // list.index of both names (:269-271), then the node lengths up to / from there, in the reference's order
+        uint32_t il = 0, ir = 0; NameRef nm{0, 0}; uint64_t pos = ps;
+        for (;; ++il) { next_node(t, pe, oriented, pos, nm); if (nm.e - nm.s == L.e - L.s && bytes_eq(t, nm.s, L.s, L.e - L.s)) break; }
+        pos = ps;
+        for (;; ++ir) { next_node(t, pe, oriented, pos, nm); if (nm.e - nm.s == R.e - R.s && bytes_eq(t, nm.s, R.s, R.e - R.s)) break; }
         int64_t left = 0, right = 0, l1;
-        for (uint32_t j = 0; j <= il; ++j) { nth_node(t, ps, pe, oriented, j, nm); int rc = generic_node_len(g, t, nm, l1); if (rc) return rc; left += l1; }
-        for (uint32_t j = ir; j < k; ++j) { nth_node(t, ps, pe, oriented, j, nm); int rc = generic_node_len(g, t, nm, l1); if (rc) return rc; right += l1; }
+        pos = ps;
+        for (uint32_t j = 0; j <= il; ++j) { next_node(t, pe, oriented, pos, nm); int rc = generic_node_len(g, t, nm, l1); if (rc) return rc; left += l1; }
+        pos = ps;
+        for (uint32_t j = 0; j < k; ++j) {
+            next_node(t, pe, oriented, pos, nm);
+            if (j < ir) continue;
+            int rc = generic_node_len(g, t, nm, l1); if (rc) return rc; right += l1;
+        }
         if (left - Ts >= (int64_t)g.d_over && right - (Tlen - Te - 1) >= (int64_t)g.d_over)
             for (uint32_t j = 0; j < nh; ++j) { uint32_t hv = edge_hit(g, ed, j); emit(hv >> 1, hv & 1u); }
     }

@@ -15,12 +15,16 @@ struct CountEmit {
     void operator()(uint32_t slot, uint32_t allele) { counts[slot * 2 + allele]++; }
 };
 
-static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &hash) {
+static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &hash, const KernelTables *kt = nullptr) {
     GraphView v;
     v.nodes = g->nodes; v.n_nodes = (uint32_t)g->n_nodes; v.edges = g->edges; v.hits = g->hits;
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
-    v.name_tab = nullptr; v.name_mask = 0; v.name_seed = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;     // main-kernel tables: not used by the exact path
+    v.name_tab = nullptr; v.name_mask = 0; v.name_seed = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
+    if (kt) {                                                             // the exact path resolves names through the node-name table
+        v.name_tab = kt->names.data(); v.name_mask = kt->name_mask; v.name_seed = kt->name_seed;
+        v.name_complete = (kt->names_left_out == 0 && kt->names_skipped == 0) ? 1u : 0u;
+    }
     return v;
 }
 
@@ -28,7 +32,8 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
                                 uint32_t *counts, uint64_t *n_lines, int *exc, uint64_t *err_off)
 {
     std::vector<uint32_t> hash = build_chrom_hash(*g);
-    GraphView v = make_view(g, hash);
+    KernelTables kt = build_kernel_tables(*g);
+    GraphView v = make_view(g, hash, (g->flags & 2u) ? nullptr : &kt);      // flags bit 1 (harness only): sorted-table search instead
     const uint8_t *t = (const uint8_t *)gaf;
     *n_lines = 0; *exc = 0; *err_off = 0;
     uint64_t pos = 0;

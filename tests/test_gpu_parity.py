@@ -264,7 +264,7 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
     names = [n for n in g.node_names if "." not in n.split(":")[-1]]          # reference nodes in genome order
     lens = {n: int(n.split(":")[1].split("-")[1]) - int(n.split(":")[1].split("-")[0]) + 1 for n in names}
     lines = []
-    for k, start in ((17, 3), (25, 40), (60, 100), (16, 200), (33, 300)):
+    for k, start in ((17, 3), (25, 40), (60, 100), (16, 200), (33, 300), (128, 350), (129, 10), (150, 500)):
         path = names[start:start + k]
         tlen = sum(lens[n] for n in path)
         fwd = "".join(">" + n for n in path)
@@ -279,7 +279,7 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
     ctx.classify(np.frombuffer(data, dtype=np.uint8))
     assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
     st = ctx.stats()
-    assert st["n_lines"] == n_lines and st["n_deferred"] >= 9
+    assert st["n_lines"] == n_lines and st["n_deferred"] >= 4          # 129 / 150 nodes in both directions (the long line only if it crosses its stripe's look-ahead)
     # a stripe of lines shorter than any valid GAF line
     dense = b"x\t1\n" * 20000
     with pytest.raises(ValueError):

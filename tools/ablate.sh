@@ -1,5 +1,5 @@
 #!/bin/bash
 # measurement only: cost split of k_classify_main via the SVJG_DIAG ablation knob
-for d in 0 1 2 64 4 8; do
+for d in ${DIAGS:-0 1 2 64 4 8}; do
   echo "SVJG_DIAG=$d $(SVJG_DIAG=$d python bench.py --workload ${1:-c3} --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c 'import sys,json; r=json.loads(sys.stdin.readline()); print(r["kernel_ms"], r["roofline"]["achieved"])')"
 done

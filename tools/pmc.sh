@@ -5,7 +5,9 @@ out=${1:-gpurun_out/pmc}
 mkdir -p $out
 export TMPDIR=/tmp
 i=0
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAIT_INST_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU"; do
+GROUPS_DEFAULT=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAIT_INST_LDS" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH" "SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH_LEVEL SQ_ACTIVE_INST_MISC")
+if [ -n "$PMC_GROUPS" ]; then IFS=';' read -ra GROUPS_DEFAULT <<< "$PMC_GROUPS"; fi
+for grp in "${GROUPS_DEFAULT[@]}"; do
   i=$((i+1))
   timeout 150 rocprofv3 --kernel-trace --pmc $grp -d $out/g$i -o p --output-format csv -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $out/g$i.log 2>&1
   f=$(ls -t $out/g$i/*counter_collection.csv 2>/dev/null | head -1)
