@@ -35,6 +35,7 @@ struct svjg_ctx {
     DevStatus *d_st = nullptr;
     unsigned long long *d_dbg = nullptr;
     DevStatus h_st{};
+    uint32_t look = LOOK_MIN;             // look-ahead bytes of the classify stripes; grows when lines get cut off (svjg_kernels.h)
     uint64_t total_deferred = 0;
     // genotype scratch
     dd *d_logfact = nullptr;  uint32_t logfact_n = 0;  dd *d_bsum = nullptr;
@@ -236,7 +237,9 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         ClassifyArgs a{};
         a.gaf = c->d_gaf; a.n_bytes = n; a.base_offset = base_offset; a.g = c->gv;
         a.all_slow = all_slow; a.want_hits = want_hits != 0;
-        a.n_chunks = (uint32_t)((n + CHUNK - 1) / CHUNK);
+        { const char *lk = getenv("SVJG_LOOK"); if (lk) { uint32_t v = (uint32_t)atoi(lk) & ~15u; if (v >= 256 && v <= LOOK_MAX) c->look = v; } }   // measurement knob
+        a.chunk = TEXT - c->look;
+        a.n_chunks = (uint32_t)((n + a.chunk - 1) / a.chunk);
         { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob for profiling only
         a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
         a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
@@ -270,7 +273,13 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
             HIPCHK(c, hipEventElapsedTime(&c->ms_slow, c->ev[2], c->ev[3]));
         }
         HIPCHK(c, hipEventElapsedTime(&c->ms_main, c->ev[0], c->ev[1]));
-        if (!c->h_st.overflow) { c->total_deferred += n_def; break; }
+        if (!c->h_st.overflow) {
+            c->total_deferred += n_def;
+            // many lines ran past the staged text (long lines): widen the look-ahead for the following batches
+            const uint64_t cut = c->h_st.n_incomplete - before.n_incomplete, lines = c->h_st.n_lines - before.n_lines;
+            if (cut * 256 > lines && c->look < LOOK_MAX) c->look *= 2;
+            break;
+        }
         // roll back and retry with worst-case buffers
         if (attempt == 2) { c->err = "output buffers overflowed repeatedly"; return SVJG_E_NOMEM; }
         if (c->h_st.overflow & 1u) def_want = n / 24 + 64;

@@ -35,11 +35,11 @@ constexpr uint32_t PIECES = SVJG_PIECES;         // 16-byte pieces of text per l
 constexpr uint32_t SPAN = PIECES * 16;           // bytes of byte classification per lane
 constexpr uint32_t SLICE = SPAN * 64;            // bytes of text whose lines one wave owns
 constexpr uint32_t TEXT = SPAN * WG;             // 40 KB staged in LDS
-#ifndef SVJG_LOOK
-#define SVJG_LOOK 4096
-#endif
-constexpr uint32_t LOOK = SVJG_LOOK;             // look-ahead so that lines starting in the stripe are complete
-constexpr uint32_t CHUNK = TEXT - LOOK;          // bytes of text owned by one workgroup iteration (a "stripe")
+// A stripe = the bytes of text whose lines one workgroup iteration owns = TEXT minus a look-ahead that lets lines
+// starting near its end be complete.  The look-ahead is a launch parameter (ClassifyArgs::chunk = TEXT - look-ahead): the
+// host starts at LOOK_MIN and doubles it, up to LOOK_MAX, when a batch had many lines cut off by the staged text (they
+// go to the exact path, which is correct but slow), so short-line files do not pay for long-line ones.
+constexpr uint32_t LOOK_MIN = 2048, LOOK_MAX = 16384;
 constexpr uint32_t MAXSTARTS = TEXT / 24 + 8;    // a valid line has >= 24 bytes incl. its terminator
 constexpr uint32_t KMAX = 128;                   // path nodes per alignment handled by the main kernel (longer paths: exact path)
 constexpr uint32_t LRW = SVJG_LRW;               // lines per wave and round (line-granular phases use the first LRW lanes)
@@ -76,6 +76,7 @@ struct DevStatus {
     unsigned long long n_deferred;       // entries appended to the deferred list
     unsigned long long n_recs;           // hit records appended
     unsigned long long err;              // min over (file offset << 3 | exception class); ~0 = none
+    unsigned long long n_incomplete;     // lines deferred because they run past the staged text
     unsigned int non_ascii;
     unsigned int overflow;               // bit 0: deferred list, bit 1: hit-record buffer
 };
@@ -88,6 +89,7 @@ struct ClassifyArgs {
     uint32_t all_slow;
     uint32_t want_hits;
     uint32_t n_chunks;
+    uint32_t chunk;                      // stripe stride in bytes (multiple of 16, TEXT - look-ahead)
     uint32_t diag;                       // measurement only (SVJG_DIAG): 1 stop after B, 2 stop after R2, 4 no node lookup, 8 no atomics
     unsigned long long *counts;          // [n_slots] ref | alt << 32
     uint64_t *deferred;  uint64_t deferred_cap;
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     uint4 pf[PIECES];
     uint32_t pf_head = '\n';                                           // byte right before the stripe (decides whether it starts a line)
     auto prefetch = [&](uint32_t chunk) {                            // no bounds tests: the buffer is zero padded by TEXT + 64 bytes
-        const uint64_t c0 = (uint64_t)(chunk < a.n_chunks ? chunk : a.n_chunks - 1) * CHUNK;
+        const uint64_t c0 = (uint64_t)(chunk < a.n_chunks ? chunk : a.n_chunks - 1) * a.chunk;
         const uint4 *src = (const uint4 *)(a.gaf + c0) + tid;
 #pragma unroll
         for (uint32_t i = 0; i < PIECES; ++i) pf[i] = src[i * WG];
@@ -329,9 +331,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     __syncthreads();
 
     for (uint32_t chunk = blockIdx.x; chunk < a.n_chunks; chunk += gridDim.x) {
-        const uint64_t c0 = (uint64_t)chunk * CHUNK;
+        const uint64_t c0 = (uint64_t)chunk * a.chunk;
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (uint64_t)TEXT) ? (a.n_bytes - c0) : (uint64_t)TEXT);   // valid bytes staged
-        const uint32_t own_lim = V < CHUNK ? V : CHUNK;                  // lines starting below this offset belong to the stripe
+        const uint32_t own_lim = V < a.chunk ? V : a.chunk;                  // lines starting below this offset belong to the stripe
 
         // ---- A: registers -> LDS, then start the next stripe's HBM loads ---------------------------------
         uint32_t hi_bits = 0;
@@ -404,13 +406,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             // ---- R1: one line per lane --------------------------------------------------------------
             const uint32_t li = base + lane;
             uint32_t status = ST_NONE, k = 0, s = 0;
+            bool cut = false;                                            // the line runs past the staged text
             if (lane < LRW && li < n_w) {
                 s = rstart[lane];
                 const uint32_t nx = rstart[lane + 1];
                 uint32_t e = V;
                 bool complete = true;
                 if (nx != 0xFFFFu) e = nx - 1;
-                else if (!at_eof) complete = false;
+                else if (!at_eof) { complete = false; cut = true; }
                 status = ST_DEFER;
                 if (complete && !a.all_slow) {
                     while (e > s && py_space(text[e - 1])) --e;         // line.rstrip()
@@ -622,6 +625,8 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
                 const bool defer = lane < taken && (l_meta[lane] >> 24) == ST_DEFER;
+                const unsigned long long cb = __ballot(cut && lane < taken);
+                if (cb && lane == 0) atomicAdd(&a.st->n_incomplete, (unsigned long long)__popcll(cb));
                 unsigned long long db = __ballot(defer);
                 if (db) {
                     unsigned long long dbase = 0;

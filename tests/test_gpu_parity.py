@@ -287,3 +287,32 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
         ctx.classify(np.frombuffer(inf["gaf"].tobytes() + dense, dtype=np.uint8))
     with pytest.raises(ValueError):
         orc.filter(inf["gaf"].tobytes() + dense, want_hits=False)
+
+
+def test_long_lines_widen_the_look_ahead(ctx, tmp_path):
+    """Every line carries a 3 KB tag: many lines run past the staged text of their stripe and take the exact path; the
+    library widens the look-ahead for the next batch.  Counts are the oracle's both times."""
+    import synth
+    from svjg.graph import Graph
+    pre = str(tmp_path / "c")
+    inf = synth.generate(pre, 3000, 300, 2, "mixed", 41, write_gaf=False, return_gaf=True)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    pad = b"\tzz:Z:" + b"ACGT" * 750
+    data = b"".join(l + pad + b"\n" for l in inf["gaf"].tobytes().split(b"\n")[:-1])
+    want, _, n_lines = orc.filter(data, want_hits=False)
+    arr = np.frombuffer(data, dtype=np.uint8)
+    from svjg import capi
+    c2 = capi.Context(0)                       # a fresh context: the look-ahead is per context and only grows
+    try:
+        c2.load_graph(g)
+        deferred = []
+        for _ in range(4):
+            c2.reset_counts()
+            before = c2.stats()["n_deferred"]
+            c2.classify(arr)
+            assert _counts_dict(g, c2.counts()) == _oracle_dict(orc, want)
+            deferred.append(c2.stats()["n_deferred"] - before)
+        assert deferred[0] > n_lines // 100 and deferred[-1] < deferred[0] // 2
+    finally:
+        c2.close()
