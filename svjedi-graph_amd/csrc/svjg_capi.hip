@@ -259,7 +259,7 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         if (a.diag & 16u) {
             unsigned long long d[8];
             HIPCHK(c, hipMemcpy(d, c->d_dbg, sizeof d, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[svjg diag] workgroup cycles  A %llu  B %llu  R1 %llu  R2 %llu  R3 %llu  R4 %llu  R5 %llu  R6 %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+            fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A %llu  B1 %llu  B2 %llu  R1 %llu  R3 %llu  R4 %llu  R5 %llu  R6+end %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
         }
         c->ms_slow = 0;
         if (n_def && !(c->h_st.overflow & 1u)) {

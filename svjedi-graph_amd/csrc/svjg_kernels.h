@@ -1,14 +1,10 @@
 // HIP kernels of libsvjg_hip.so (gfx950 / MI355X, wave64).  No MFMA anywhere: this is byte / integer
 // work bounded by HBM reads.
 //
-//   k_classify_main  one workgroup per ~44 KB stripe of GAF text:
-//                      A  coalesced 16 B/lane loads HBM -> LDS (the only HBM read of the text)
-//                      B  line-terminator scan over LDS, block prefix sum -> line-start list in LDS
-//                      C  one line per lane: svjg::fast_line (streaming parse + node / link lookups in
-//                         the L2 / Infinity-Cache resident graph tables)
-//                      D  wave-level commit: packed 64-bit (ref | alt << 32) atomics into the per-SV
-//                         count vector, hit records and deferred-line offsets appended with one
-//                         wave-aggregated atomic each
+//   k_classify_main  persistent workgroups over 32 KB stripes of GAF text (see the comment in front of the kernel):
+//                      coalesced HBM -> register -> LDS staging, SWAR byte classes, rank-indexed lists of line
+//                      starts / tabs / orientation marks, then loop-free per-line, per-node and per-link phases with
+//                      node-name and link hash tables, packed 64-bit (ref | alt << 32) atomics into the per-SV count vector
 //   k_classify_slow  one lane per deferred line, exact string path (svjg::slow_line) on an LDS copy of the line
 //   k_logfact_*      log10(i!) table in double-double for the binomial term
 //   k_genotype       one VCF row per lane, fp64 / double-double likelihoods (predict-genotype.py:281-325)
@@ -18,57 +14,57 @@
 
 namespace svjg {
 
-#ifndef SVJG_WG
-#define SVJG_WG 512
-#define SVJG_PIECES 5
-#endif
+constexpr uint32_t WG = 512;                      // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS-bound) = 16 waves / CU
+constexpr uint32_t NWAVE = WG / 64;
+constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
+constexpr uint32_t PIECES = 4;                   // 16-byte pieces of text per lane and stripe
+constexpr uint32_t SPAN = PIECES * 16;           // bytes of byte classification per lane: one 64-bit mask per byte class
+constexpr uint32_t TEXT = SPAN * WG;             // 32 KB staged in LDS
+// A stripe = the bytes of text whose lines one workgroup iteration owns = TEXT minus a look-ahead that lets lines
+// starting near its end be complete.  The look-ahead is a launch parameter (ClassifyArgs::chunk = TEXT - look-ahead): the
+// host starts at LOOK_MIN and doubles it, up to LOOK_MAX, when a batch had many lines cut off by the staged text (they
+// go to the exact path, which is correct but slow), so short-line files do not pay for long-line ones.
+constexpr uint32_t LOOK_MIN = 2048, LOOK_MAX = 16384;
+// Phase B turns the staged text into rank-indexed lists (all positions are offsets into the staged text):
+constexpr uint32_t MAXL = 512;                   // line starts per stripe (a stripe with more goes to the exact path as a whole)
+constexpr uint32_t CAP_T = 4096;                 // tab positions per stripe
+constexpr uint32_t CAP_O = 2048;                 // orientation marks ('<' '>') per stripe
+constexpr uint32_t KMAX = 128;                   // path nodes per alignment handled by the main kernel (longer paths: exact path)
 #ifndef SVJG_LRW
 #define SVJG_LRW 32
 #endif
 #ifndef SVJG_NMAXW
 #define SVJG_NMAXW 160
 #endif
-constexpr uint32_t WG = SVJG_WG;                 // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS-bound) = 16 waves / CU
-constexpr uint32_t NWAVE = WG / 64;
-constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
-constexpr uint32_t PIECES = SVJG_PIECES;         // 16-byte pieces of text per lane and stripe
-constexpr uint32_t SPAN = PIECES * 16;           // bytes of byte classification per lane
-constexpr uint32_t SLICE = SPAN * 64;            // bytes of text whose lines one wave owns
-constexpr uint32_t TEXT = SPAN * WG;             // 40 KB staged in LDS
-// A stripe = the bytes of text whose lines one workgroup iteration owns = TEXT minus a look-ahead that lets lines
-// starting near its end be complete.  The look-ahead is a launch parameter (ClassifyArgs::chunk = TEXT - look-ahead): the
-// host starts at LOOK_MIN and doubles it, up to LOOK_MAX, when a batch had many lines cut off by the staged text (they
-// go to the exact path, which is correct but slow), so short-line files do not pay for long-line ones.
-constexpr uint32_t LOOK_MIN = 2048, LOOK_MAX = 16384;
-constexpr uint32_t MAXSTARTS = TEXT / 24 + 8;    // a valid line has >= 24 bytes incl. its terminator
-constexpr uint32_t KMAX = 128;                   // path nodes per alignment handled by the main kernel (longer paths: exact path)
-constexpr uint32_t LRW = SVJG_LRW;               // lines per wave and round (line-granular phases use the first LRW lanes)
-constexpr uint32_t NMAXW = SVJG_NMAXW;           // path nodes per wave and round
-static_assert(LRW <= 64 && KMAX <= NMAXW, "round geometry");
-static_assert(TEXT < 65536, "text offsets are kept in 16 bits");
+constexpr uint32_t LRW = SVJG_LRW;               // lines per wave and round
+constexpr uint32_t NMAXW = SVJG_NMAXW;           // orientation marks (path nodes) per wave and round
+static_assert(LRW <= 64 && KMAX <= NMAXW && KMAX < 256 && NMAXW < 32768, "round geometry");
+static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
-// LDS carve-up of k_classify_main (bytes): text and the two byte-class bitmaps are shared by the workgroup,
-// everything else is private to one wave
+// LDS carve-up of k_classify_main (bytes): text, the non-digit bitmap and the lists are shared by the workgroup,
+// the round arrays are private to one wave
 constexpr uint32_t L_TEXT = 0;
-constexpr uint32_t L_TABBM = L_TEXT + TEXT + 16;                           // u16[TEXT/16] one bit per byte: '\t'
-constexpr uint32_t L_ORIBM = L_TABBM + TEXT / 8;                           // u16[TEXT/16] one bit per byte: '<' or '>'
-constexpr uint32_t L_MISC = L_ORIBM + TEXT / 8 + 16;                       // u32[32]: [0] line starts in the stripe, [8 + w] first start found by wave w
+constexpr uint32_t L_NDBM = L_TEXT + TEXT + 16;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab
+constexpr uint32_t L_TP = L_NDBM + TEXT / 8 + 16;                          // u16[CAP_T + 16]  position of tab #t of the stripe
+constexpr uint32_t L_OP = L_TP + (CAP_T + 16) * 2;                         // u16[CAP_O + 8]   position of orientation mark #o
+constexpr uint32_t L_OL = L_OP + (CAP_O + 8) * 2;                          // u16[CAP_O + 8]   line (ordinal in the stripe) that holds mark #o
+constexpr uint32_t L_LS = L_OL + (CAP_O + 8) * 2;                          // u16[MAXL + 8]    start of line #l ; [n] = 0xFFFF
+constexpr uint32_t L_LT = L_LS + (MAXL + 8) * 2;                           // u16[MAXL + 8]    tabs in front of line #l
+constexpr uint32_t L_LO = L_LT + (MAXL + 8) * 2;                           // u16[MAXL + 8]    orientation marks in front of line #l
+constexpr uint32_t L_MISC = L_LO + (MAXL + 8) * 2;                         // u32[32]: [1] stripe holds a byte >= 0x80, [8 + w] / [16 + w] scan totals of wave w
 constexpr uint32_t L_WAVE = L_MISC + 128;
-constexpr uint32_t W_RSTART = 0;                                           // u16[LRW + 2]  line starts of the round (+ the end of the last line)
-constexpr uint32_t W_TS = (W_RSTART + (LRW + 2) * 2 + 15) / 16 * 16;       // u32[LRW]  path start column
+constexpr uint32_t W_TS = 0;                                               // u32[LRW]  path start column
 constexpr uint32_t W_TE = W_TS + LRW * 4;                                  // u32[LRW]
 constexpr uint32_t W_TLEN = W_TE + LRW * 4;                                // u32[LRW]
 constexpr uint32_t W_TOT = W_TLEN + LRW * 4;                               // u32[LRW]  sum of node lengths
-constexpr uint32_t W_META = W_TOT + LRW * 4;                               // u32[LRW]  nbase | k << 16 | status << 24
-constexpr uint32_t W_PBEG = W_META + LRW * 4;                              // u16[LRW]  tab before the path column
-constexpr uint32_t W_PEND = W_PBEG + LRW * 2;                              // u16[LRW]  tab after the path column
-constexpr uint32_t W_NPOS = W_PEND + LRW * 2;                              // u16[NMAXW]  name start (orientation mark + 1)
-constexpr uint32_t W_NLINE = W_NPOS + NMAXW * 2;                           // u16[NMAXW]  line in round | orientation << 15
-constexpr uint32_t W_NFIRST = W_NLINE + NMAXW * 2;                         // u16[NMAXW]  first node of the line with the same name
-constexpr uint32_t W_NID = (W_NFIRST + NMAXW * 2 + 3) / 4 * 4;             // u32[NMAXW]
+constexpr uint32_t W_META = W_TOT + LRW * 4;                               // u32[LRW]  first node slot | k << 16 | status << 24
+constexpr uint32_t W_PEND = W_META + LRW * 4;                              // u16[LRW]  tab after the path column
+constexpr uint32_t W_NFIRST = W_PEND + LRW * 2;                            // u16[NMAXW]  first node of the line with the same name
+constexpr uint32_t W_NID = (W_NFIRST + NMAXW * 2 + 3) / 4 * 4;             // u32[NMAXW]  node id | orientation << 31
 constexpr uint32_t W_NPRE = W_NID + NMAXW * 4;                             // u32[NMAXW]  length, then inclusive prefix
 constexpr uint32_t WAVE_BYTES = (W_NPRE + NMAXW * 4 + 15) / 16 * 16;
 constexpr uint32_t LDS_MAIN = L_WAVE + NWAVE * WAVE_BYTES;
+static_assert(L_NDBM % 16 == 0 && L_TP % 16 == 0 && L_OP % 16 == 0 && L_LS % 16 == 0 && L_MISC % 16 == 0, "LDS alignment");
 
 // status words (device)
 struct DevStatus {
@@ -153,40 +149,6 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *slot, uint32_t 
 
 enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round
 
-// plain decimal column text[a, b): 1..9 digits and nothing else -> value.  Straight-line SWAR: three aligned
-// LDS words, digits checked and folded pairwise (no per-digit loop, no divergence).
-__device__ inline bool field_dec(const uint8_t *text, uint32_t a, uint32_t b, uint32_t &v) {
-    const uint32_t n = b - a;
-    const uint32_t *w = (const uint32_t *)(text + (a & ~3u));
-    const uint32_t sh = a & 3u, d0 = w[0], d1 = w[1], d2 = w[2];
-    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh) ^ 0x30303030u;    // chars a .. a+3 as digits
-    uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh) ^ 0x30303030u;    // chars a+4 .. a+7
-    const uint32_t n8 = n < 8 ? n : 8;
-    // keep the first n8 bytes, then shift them to the top of the 64-bit (hi:lo) so that leading bytes are zero digits
-    const uint32_t klo = n8 >= 4 ? 0xFFFFFFFFu : ((1u << ((8 * n8) & 31u)) - 1u);
-    const uint32_t khi = n8 >= 8 ? 0xFFFFFFFFu : (n8 > 4 ? ((1u << ((8 * (n8 - 4)) & 31u)) - 1u) : 0u);
-    lo &= klo; hi &= khi;
-    bool ok = (((lo + 0x76767676u) | lo | (hi + 0x76767676u) | hi) & 0x80808080u) == 0;     // every kept byte is 0..9
-    const unsigned long long x = (((unsigned long long)hi << 32) | lo) << ((8 * (8 - n8)) & 63u);
-    lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
-    uint32_t pl = (lo * 10u + (lo >> 8)) & 0x00FF00FFu, ph = (hi * 10u + (hi >> 8)) & 0x00FF00FFu;
-    uint32_t r = ((pl & 0xFFu) * 100u + (pl >> 16)) * 10000u + (ph & 0xFFu) * 100u + (ph >> 16);
-    if (n == 9) { uint32_t d = (uint32_t)text[a + 8] - '0'; ok &= d <= 9; r = r * 10u + d; }
-    v = r;
-    return ok & (n - 1u <= 8u);
-}
-
-// next set bit of a bitmap, scanning upwards from the cursor (word index wi, remaining bits `cur`); `lim` = end position
-struct BitCursor {
-    const uint32_t *bm; uint32_t wi, cur, lim;
-    __device__ uint32_t next() {                                         // position of the next set bit, or lim
-        while (cur == 0) { ++wi; if ((wi << 5) >= lim) return lim; cur = bm[wi]; }
-        uint32_t b = __builtin_ctz(cur); cur &= cur - 1;
-        uint32_t p = (wi << 5) + b;
-        return p < lim ? p : lim;
-    }
-};
-
 // Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the pre-hash of the node-name table
 // (svjg_host_tables.h: name_prehash_host).
 __device__ inline uint32_t name_words(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
@@ -242,79 +204,128 @@ __device__ inline void wave_sync() {
 
 // The classify kernel.  One workgroup walks stripes of the GAF text; the next stripe's HBM loads are issued into
 // registers before the current one is processed, so the only HBM read of the text overlaps the parse.  Per stripe:
-//   A  registers -> LDS (16 B per lane, coalesced on the HBM side)                                   [workgroup barrier]
-//   B  one SPAN per lane, branch-free SWAR classification of every byte: tab and orientation-mark ('<' '>') bitmaps
-//      -> LDS, line terminators -> per-lane masks, wave prefix sum                                    [workgroup barrier]
-//   then every WAVE on its own (no workgroup barriers: the sixteen waves of a CU drift through different phases, so
-//   table latency of one overlaps the parsing of another), for the lines whose preceding terminator lies in the wave's
-//   SLICE of the stripe, in rounds of up to LRW lines / NMAXW path nodes:
-//   R1 one LINE per lane: the twelve column boundaries by bit-scanning the tab bitmap, the nine decimal columns by
-//      SWAR, path geometry; wave prefix sum hands every line a contiguous range of node slots
-//   R2 one LINE per lane: node slots filled from the orientation bitmap (name position, line, orientation)
-//   R3 one path NODE per lane: name -> slot of the node-name hash table (Infinity Cache / L2 resident) -> id, length
+//   A   registers -> LDS (16 B per lane, coalesced on the HBM side)                                  [workgroup barrier]
+//   B1  one 64-byte SPAN per lane, branch-free SWAR classification of every byte: 64-bit masks of line terminators,
+//       tabs and orientation marks ('<' '>') in registers, the "neither digit nor tab" bitmap -> LDS; workgroup prefix
+//       sum of the three counts                                                                       [workgroup barrier]
+//   B2  every terminator / tab / mark knows its ordinal in the stripe: rank-indexed lists -> LDS
+//         LS[l] LT[l] LO[l]  start of line l, tabs and marks in front of it      TP[t]  position of tab t
+//         OP[o] OL[o]        position of mark o, line that holds it                                  [workgroup barrier]
+//   then every WAVE on its own, for an equal share of the stripe's lines, in rounds of up to LRW lines / NMAXW marks
+//   (no loops over bytes or bits from here on: a line's j-th tab is TP[LT[l] + j], its j-th node starts at OP[LO[l] + j]):
+//   R1 one LINE per lane: twelve column boundaries, column lengths, digits-only test on the bitmap, the four decimal
+//      values that matter (Tlen, Ts, Te, Alen), path geometry
+//   R3 one path NODE per lane: name -> both candidate slots of the node-name hash table (one round trip) -> id, length
 //   R4 one LINE per lane: running path length, first occurrence of every name (the reference's list.index /
-//      str.split quirks), validation
+//      str.split quirks)
 //   R5 one path STEP (link) per lane: overlap test on the prefix sums, link hash table lookup, one 64-bit
 //      atomic (ref | alt << 32) per hit, optional hit records
 //   R6 deferred-line offsets, one aggregated atomic per wave
 //                                                                                                     [workgroup barrier]
-// Phase B of k_classify_main for one lane: classes of the SPAN bytes at text + tid * SPAN.  Tab and orientation-mark
-// bitmaps -> LDS; line terminators -> `mask` (two 16-bit masks per word), their number -> cnt, and how many of the
-// lines they start belong to this stripe -> owned.  terminator = '\n', or a '\r' not followed by '\n' (Python
-// universal newlines).
+
+// 0x80 in every byte of w that is an ASCII digit
+template <bool ASCII> __device__ inline uint32_t digit_flags(uint32_t w) {
+    if (ASCII) return (w + 0x50505050u) & ~(w + 0x46464646u) & 0x80808080u;            // bytes < 0x80: no carries between byte lanes
+    const uint32_t t = w ^ 0x30303030u;                                                 // digit <=> high nibble 0 and low nibble < 10
+    return zero_bytes(t & 0xF0F0F0F0u) & ((~((t & 0x0F0F0F0Fu) + 0x06060606u) & 0x10101010u) << 3);
+}
+// 16-bit mask from four words of 0x80 / 0x00 byte flags
+__device__ inline uint32_t gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    const uint32_t lo = __builtin_amdgcn_udot4(f0, 0x08040201u, __builtin_amdgcn_udot4(f1, 0x80402010u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(f2, 0x08040201u, __builtin_amdgcn_udot4(f3, 0x80402010u, 0u, false), false);
+    return (lo | (hi << 8)) >> 7;
+}
+
+// Phase B1 of k_classify_main for one lane: classes of the SPAN bytes at text + tid * SPAN.
+// terminator = '\n', or a '\r' not followed by '\n' (Python universal newlines).
 template <bool ASCII>
-__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint16_t *tabbm16, uint16_t *oribm16, uint32_t tid,
-                                     uint64_t c0, uint32_t V, uint32_t own_lim, uint32_t (&mask)[(PIECES + 1) / 2], uint32_t &cnt, uint32_t &owned) {
+__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t tid, uint64_t c0, uint32_t V,
+                                     unsigned long long &NL, unsigned long long &TAB, unsigned long long &ORI) {
     const uint32_t sp = tid * SPAN;
+    unsigned long long nl64 = 0, tab64 = 0, ori64 = 0, nd64 = 0;
 #pragma unroll
-    for (uint32_t pc = 0; pc < PIECES; ++pc) {
-        const uint4 v = *(const uint4 *)(text + sp + pc * 16);
+    for (uint32_t c = 0; c < PIECES; ++c) {
+        const uint32_t pc = (c + (tid >> 2)) & 3u;                     // rotated piece order: the 16-byte LDS reads of a wave hit different banks
+        const uint32_t pb = sp + pc * 16;
+        const uint4 v = *(const uint4 *)(text + pb);
         uint32_t nl = eq_mask16_t<ASCII>(v, 0x0A0A0A0Au);
-        tabbm16[tid * PIECES + pc] = (uint16_t)eq_mask16_t<ASCII>(v, 0x09090909u);
-        oribm16[tid * PIECES + pc] = (uint16_t)eq_mask16_t<ASCII>(make_uint4(v.x | 0x02020202u, v.y | 0x02020202u, v.z | 0x02020202u, v.w | 0x02020202u), 0x3E3E3E3Eu);
+        const uint32_t tab = eq_mask16_t<ASCII>(v, 0x09090909u);
+        const uint32_t ori = eq_mask16_t<ASCII>(make_uint4(v.x | 0x02020202u, v.y | 0x02020202u, v.z | 0x02020202u, v.w | 0x02020202u), 0x3E3E3E3Eu);
+        const uint32_t dig = gather16(digit_flags<ASCII>(v.x), digit_flags<ASCII>(v.y), digit_flags<ASCII>(v.z), digit_flags<ASCII>(v.w));
         // carriage returns: cheap any-test first (no text file has them in practice)
         if (any_byte_t<ASCII>(v, 0x0D0D0D0Du)) {
             uint32_t cr = eq_mask16(v, 0x0D0D0D0Du);
             while (cr) {
                 uint32_t b = __builtin_ctz(cr); cr &= cr - 1;
-                uint32_t q = sp + pc * 16 + b;
+                uint32_t q = pb + b;
                 uint8_t nx = (q + 1 < TEXT) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
                 if (nx != '\n') nl |= 1u << b;
             }
         }
-        const uint32_t pb = sp + pc * 16;                            // ignore anything at or beyond the valid length
-        if (pb >= V) nl = 0; else if (pb + 16 > V) nl &= (1u << (V - pb)) - 1u;
-        if (pc & 1) mask[pc >> 1] |= nl << 16; else mask[pc >> 1] = nl;
-        cnt += __builtin_popcount(nl);
-        // a terminator at pb + b starts a line at pb + b + 1; the stripe owns it if that is below own_lim
-        const uint32_t keep = own_lim > pb + 1 ? (own_lim - pb - 1 < 16u ? own_lim - pb - 1 : 16u) : 0u;
-        owned += __builtin_popcount(nl & ((1u << keep) - 1u));
+        if (pb >= V) nl = 0; else if (pb + 16 > V) nl &= (1u << (V - pb)) - 1u;   // ignore anything at or beyond the valid length
+        const uint32_t sh = pc * 16;
+        nl64 |= (unsigned long long)nl << sh; tab64 |= (unsigned long long)tab << sh; ori64 |= (unsigned long long)ori << sh;
+        nd64 |= (unsigned long long)(~(dig | tab) & 0xFFFFu) << sh;
     }
+    *(uint2 *)(ndbm + tid * 2) = make_uint2((uint32_t)nd64, (uint32_t)(nd64 >> 32));
+    NL = nl64; TAB = tab64; ORI = ori64;
+}
+
+// decimal column text[a, a + n), 1 <= n <= 9, known to hold digits only -> value.  Straight-line SWAR on three aligned
+// LDS words: digits folded pairwise (no per-digit loop, no divergence).
+__device__ inline uint32_t field_val(const uint8_t *text, uint32_t a, uint32_t n) {
+    const uint32_t *w = (const uint32_t *)(text + (a & ~3u));
+    const uint32_t sh = a & 3u, d0 = w[0], d1 = w[1], d2 = w[2];
+    const uint32_t lo0 = __builtin_amdgcn_alignbyte(d1, d0, sh) & 0x0F0F0F0Fu;        // chars a .. a+3 as digit values
+    const uint32_t hi0 = __builtin_amdgcn_alignbyte(d2, d1, sh) & 0x0F0F0F0Fu;        // chars a+4 .. a+7
+    const uint32_t n8 = n < 8 ? n : 8;
+    // the first n8 bytes move to the top of the 64-bit (hi:lo): what follows the column drops out, leading bytes are zero digits
+    const unsigned long long x = (((unsigned long long)hi0 << 32) | lo0) << ((8 * (8 - n8)) & 63u);
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t pl = (lo * 10u + (lo >> 8)) & 0x00FF00FFu, ph = (hi * 10u + (hi >> 8)) & 0x00FF00FFu;
+    uint32_t r = ((pl & 0xFFu) * 100u + (pl >> 16)) * 10000u + (ph & 0xFFu) * 100u + (ph >> 16);
+    if (n == 9) r = r * 10u + ((uint32_t)text[a + 8] & 0xFu);
+    return r;
+}
+
+// no bit set in bits [a, a + n) of a bitmap, n <= 64 (three words are read: the bitmap is padded)
+__device__ inline bool bits_clear(const uint32_t *bm, uint32_t a, uint32_t n) {
+    const uint32_t *w = bm + (a >> 5);
+    const uint32_t sh = a & 31u;
+    const unsigned long long lo = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+    unsigned long long x = lo >> sh;
+    if (sh) x |= (unsigned long long)w[2] << (64u - sh);
+    const unsigned long long m = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+    return (x & m) == 0;
 }
 
 #ifndef SVJG_MINW
-#define SVJG_MINW ((2 * SVJG_WG) / 256)
+#define SVJG_MINW 4
 #endif
 __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *text = lds + L_TEXT;
-    uint16_t *tabbm16 = (uint16_t *)(lds + L_TABBM), *oribm16 = (uint16_t *)(lds + L_ORIBM);
-    const uint32_t *tabbm = (const uint32_t *)(lds + L_TABBM), *oribm = (const uint32_t *)(lds + L_ORIBM);
+    uint32_t *ndbm = (uint32_t *)(lds + L_NDBM);
+    uint16_t *TP = (uint16_t *)(lds + L_TP), *OP = (uint16_t *)(lds + L_OP), *OL = (uint16_t *)(lds + L_OL);
+    uint16_t *LS = (uint16_t *)(lds + L_LS), *LT = (uint16_t *)(lds + L_LT), *LO = (uint16_t *)(lds + L_LO);
     uint32_t *misc = (uint32_t *)(lds + L_MISC);
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t *wb = lds + L_WAVE + wave * WAVE_BYTES;                    // this wave's private arrays
-    uint16_t *rstart = (uint16_t *)(wb + W_RSTART);
     uint32_t *l_ts = (uint32_t *)(wb + W_TS), *l_te = (uint32_t *)(wb + W_TE), *l_tlen = (uint32_t *)(wb + W_TLEN);
     uint32_t *l_tot = (uint32_t *)(wb + W_TOT), *l_meta = (uint32_t *)(wb + W_META);
-    uint16_t *l_pbeg = (uint16_t *)(wb + W_PBEG), *l_pend = (uint16_t *)(wb + W_PEND);
-    uint16_t *n_pos = (uint16_t *)(wb + W_NPOS), *n_line = (uint16_t *)(wb + W_NLINE), *n_first = (uint16_t *)(wb + W_NFIRST);
+    uint16_t *l_pend = (uint16_t *)(wb + W_PEND), *n_first = (uint16_t *)(wb + W_NFIRST);
     uint32_t *n_id = (uint32_t *)(wb + W_NID), *n_pre = (uint32_t *)(wb + W_NPRE);
 
     const GraphView g = a.g;
 
     unsigned long long wave_lines = 0;
+    // measurement only (SVJG_DIAG & 16): time this wave spends per phase
+    unsigned long long stamp = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool timing = (a.diag & 16u) != 0;
+    auto tick = [&](int ph) { if (timing) { const unsigned long long t = __builtin_readcyclecounter(); acc[ph] += t - stamp; stamp = t; } };
+    if (timing) stamp = __builtin_readcyclecounter();
 
     // stripe prefetch registers
     uint4 pf[PIECES];
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         const uint64_t c0 = (uint64_t)chunk * a.chunk;
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (uint64_t)TEXT) ? (a.n_bytes - c0) : (uint64_t)TEXT);   // valid bytes staged
         const uint32_t own_lim = V < a.chunk ? V : a.chunk;                  // lines starting below this offset belong to the stripe
+        const bool at_eof = c0 + V == a.n_bytes;
 
         // ---- A: registers -> LDS, then start the next stripe's HBM loads ---------------------------------
         uint32_t hi_bits = 0;
@@ -342,160 +354,171 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             hi_bits |= pf[i].x | pf[i].y | pf[i].z | pf[i].w;
             *(uint4 *)(text + (i * WG + tid) * 16) = pf[i];
         }
-        if (tid == 0) misc[0] = 0;
         if (hi_bits & 0x80808080u) { a.st->non_ascii = 1; misc[1] = 1; }
         const uint32_t head_byte = pf_head;
         __syncthreads();
         const bool ascii = misc[1] == 0;                                 // workgroup-uniform: the cheaper SWAR classes apply
         prefetch(chunk + gridDim.x);
+        tick(0);
 
-        // ---- B: byte classes ----------------------------------------------------------------------------
-        uint32_t mask[(PIECES + 1) / 2];                                 // two 16-bit terminator masks per word
-        uint32_t cnt = 0, owned = 0;
+        // ---- B1: byte classes, counts, workgroup prefix sum ------------------------------------------------
+        unsigned long long NL, TAB, ORI;
         const uint32_t sp = tid * SPAN;
-        if (ascii) classify_span<true>(a, text, tabbm16, oribm16, tid, c0, V, own_lim, mask, cnt, owned);
-        else classify_span<false>(a, text, tabbm16, oribm16, tid, c0, V, own_lim, mask, cnt, owned);
+        if (ascii) classify_span<true>(a, text, ndbm, tid, c0, V, NL, TAB, ORI);
+        else classify_span<false>(a, text, ndbm, tid, c0, V, NL, TAB, ORI);
         uint32_t head = 0;                                               // does the stripe begin at a line start?
-        if (tid == 0) { head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n'); owned += head & (0 < own_lim); }
-        // lines belong to the wave that sees the terminator in front of them: one wave prefix sum, no workgroup scan
-        uint32_t wsum;
-        const uint32_t sc = wave_excl_scan((cnt + head) | (owned << 16), wsum);
-        const uint32_t o = sc & 0xFFFFu;                                 // starts found by lower lanes of the wave
-        const uint32_t wtot = __builtin_amdgcn_readfirstlane(wsum & 0xFFFFu), n_w = __builtin_amdgcn_readfirstlane(wsum >> 16);
-        if (o == 0 && cnt + head) {                                      // the wave's first start (ends the previous wave's last line)
-            uint32_t first = 0;
-            if (!head) {
+        if (tid == 0) head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
+        // a terminator at sp + b starts a line at sp + b + 1; the stripe owns it if that is below own_lim
+        const uint32_t keep = own_lim > sp + 1 ? (own_lim - sp - 1 < 64u ? own_lim - sp - 1 : 64u) : 0u;
+        const unsigned long long OWN = NL & (keep >= 64u ? ~0ull : ((1ull << keep) - 1ull));
+        const uint32_t cA = ((uint32_t)__popcll(NL) + head) | (((uint32_t)__popcll(OWN) + (head & (uint32_t)(0 < own_lim))) << 16);
+        const uint32_t cB = (uint32_t)__popcll(TAB) | ((uint32_t)__popcll(ORI) << 16);
+        uint32_t wA, wB;
+        const uint32_t exA = wave_excl_scan(cA, wA), exB = wave_excl_scan(cB, wB);
+        if (lane == 0) { misc[8 + wave] = wA; misc[16 + wave] = wB; }
+        __syncthreads();
+        uint32_t baseA = 0, baseB = 0, totA = 0, totB = 0;
 #pragma unroll
-                for (uint32_t pc = PIECES; pc-- > 0;) {
-                    const uint32_t m = (pc & 1) ? (mask[pc >> 1] >> 16) : (mask[pc >> 1] & 0xFFFFu);
-                    if (m) first = sp + pc * 16 + __builtin_ctz(m) + 1;
+        for (uint32_t w = 0; w < NWAVE; ++w) {
+            const uint32_t xa = misc[8 + w], xb = misc[16 + w];
+            if (w < wave) { baseA += xa; baseB += xb; }
+            totA += xa; totB += xb;
+        }
+        if (tid == 0) misc[1] = 0;                                       // (every wave has read it; set again only after the stripe's last barrier)
+        const uint32_t n_s = totA & 0xFFFFu, n_own = totA >> 16;         // line starts in the staged text, and how many of them this stripe owns
+        const uint32_t tot_tab = totB & 0xFFFFu, tot_ori = totB >> 16;
+        const uint32_t sb = ((baseA + exA) & 0xFFFFu) + (tid == 0 ? head : 0u);    // ordinal of the first line start this lane creates
+        tick(1);
+
+        if (a.all_slow || n_s > MAXL || tot_tab > CAP_T || tot_ori > CAP_O) {
+            // the lists cannot hold this stripe (or the caller wants the exact path): every owned line is deferred as it is
+            const uint32_t mine = (uint32_t)__popcll(OWN) + ((tid == 0) ? (head & (uint32_t)(0 < own_lim)) : 0u);
+            uint32_t wt;
+            const uint32_t ex = wave_excl_scan(mine, wt);
+            unsigned long long dbase = 0;
+            if (wt) {
+                if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)wt);
+                dbase = __shfl(dbase, 0) + ex;
+                if (tid == 0 && head && 0 < own_lim) { if (dbase < a.deferred_cap) a.deferred[dbase] = c0; else atomicOr(&a.st->overflow, 1u); ++dbase; }
+                for (unsigned long long m = OWN; m; m &= m - 1, ++dbase) {
+                    if (dbase < a.deferred_cap) a.deferred[dbase] = c0 + sp + (uint32_t)__builtin_ctzll(m) + 1u; else atomicOr(&a.st->overflow, 1u);
                 }
             }
-            misc[8 + wave] = first;
-        }
-        if (lane == 0) { if (wtot) atomicAdd(&misc[0], wtot); else misc[8 + wave] = 0xFFFFu; }
-        __syncthreads();
-        if (tid == 0) misc[1] = 0;                                       // (every wave has read it; set again only after the stripe's last barrier)
-        if (misc[0] > MAXSTARTS) {
-            // more than TEXT/24 lines in the stripe: some line has fewer than 12 columns -> ValueError in the reference
-            if (tid == 0) atomicMin(&a.st->err, ((a.base_offset + c0) << 3) | SVJG_EXC_VALUE_ERROR);
+            if (tid == 0) wave_lines += n_own;
             __syncthreads();
             continue;
         }
-        const bool at_eof = c0 + V == a.n_bytes;
-        uint32_t nxt = 0xFFFFu;                                          // first line start found by a later wave (0xFFFF: none in the staged text)
-        for (uint32_t w = NWAVE - 1; w > wave; --w) { const uint32_t f = misc[8 + w]; if (f != 0xFFFFu) nxt = f; }
 
-        for (uint32_t base = (a.diag & 1u) ? n_w : 0u, taken = 0; base < n_w; base += taken) {   // wave-uniform trip count
-            // ---- line starts of the round: rstart[i] = start of line base + i, rstart[count] = where the last one ends ----------
-            {
-                uint32_t idx = o;
-                if (head) { if (idx - base <= LRW) rstart[idx - base] = 0; ++idx; }
-#pragma unroll
-                for (uint32_t pc = 0; pc < PIECES; ++pc) {
-                    uint32_t m = (pc & 1) ? (mask[pc >> 1] >> 16) : (mask[pc >> 1] & 0xFFFFu);
-                    while (m) {
-                        const uint32_t b = __builtin_ctz(m); m &= m - 1;
-                        if (idx - base <= LRW) rstart[idx - base] = (uint16_t)(sp + pc * 16 + b + 1);
-                        ++idx;
-                    }
-                }
-                if (lane == 0 && wtot - base <= LRW) rstart[wtot - base] = (uint16_t)nxt;
+        // ---- B2: rank-indexed lists ----------------------------------------------------------------------
+        {
+            const uint32_t tb = (baseB + exB) & 0xFFFFu, ob = (baseB + exB) >> 16;
+            if (tid == 0) {
+                if (head) { LS[0] = 0; LT[0] = 0; LO[0] = 0; }
+                LS[n_s] = 0xFFFFu; LT[n_s] = (uint16_t)tot_tab; LO[n_s] = (uint16_t)tot_ori;
             }
-            wave_sync();
+            uint32_t j = sb;
+            for (unsigned long long m = NL; m; m &= m - 1, ++j) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                const unsigned long long below = (1ull << b) - 1ull;
+                LS[j] = (uint16_t)(sp + b + 1);
+                LT[j] = (uint16_t)(tb + (uint32_t)__popcll(TAB & below));
+                LO[j] = (uint16_t)(ob + (uint32_t)__popcll(ORI & below));
+            }
+            j = tb;
+            for (unsigned long long m = TAB; m; m &= m - 1, ++j) TP[j] = (uint16_t)(sp + (uint32_t)__builtin_ctzll(m));
+            j = ob;
+            for (unsigned long long m = ORI; m; m &= m - 1, ++j) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                OP[j] = (uint16_t)(sp + b);
+                OL[j] = (uint16_t)(sb + (uint32_t)__popcll(NL & ((1ull << b) - 1ull)) - 1u);   // 0xFFFF: tail of a line of the previous stripe
+            }
+        }
+        __syncthreads();
+        tick(2);
+
+        // ---- rounds: this wave's share of the stripe's lines -----------------------------------------------
+        const uint32_t per = (n_own + NWAVE - 1) / NWAVE;
+        const uint32_t l_lo = wave * per < n_own ? wave * per : n_own, l_hi = l_lo + per < n_own ? l_lo + per : n_own;
+        for (uint32_t lbase = (a.diag & 1u) ? l_hi : l_lo, taken = 0; lbase < l_hi; lbase += taken) {   // wave-uniform trip count
+            const uint32_t cnt = l_hi - lbase < LRW ? l_hi - lbase : LRW;
+            const uint32_t obase = LO[lbase];
             // ---- R1: one line per lane --------------------------------------------------------------
-            const uint32_t li = base + lane;
-            uint32_t status = ST_NONE, k = 0, s = 0;
+            uint32_t status = ST_NONE, k = 0, s = 0, rel = 0, kall = 0;
             bool cut = false;                                            // the line runs past the staged text
-            if (lane < LRW && li < n_w) {
-                s = rstart[lane];
-                const uint32_t nx = rstart[lane + 1];
+            if (lane < cnt) {
+                const uint32_t L = lbase + lane;
+                s = LS[L];
+                const uint32_t nx = LS[L + 1], tr = LT[L], tn = LT[L + 1], o0 = LO[L], o1 = LO[L + 1];
+                kall = o1 - o0; rel = o0 - obase;
                 uint32_t e = V;
                 bool complete = true;
                 if (nx != 0xFFFFu) e = nx - 1;
                 else if (!at_eof) { complete = false; cut = true; }
                 status = ST_DEFER;
-                if (complete && !a.all_slow) {
-                    while (e > s && py_space(text[e - 1])) --e;         // line.rstrip()
-                    BitCursor tc{tabbm, s >> 5, 0, e};
-                    tc.cur = tabbm[s >> 5] & (0xFFFFFFFFu << (s & 31));
-                    const uint32_t t0 = tc.next(), t1 = tc.next(), t2 = tc.next(), t3 = tc.next(), t4 = tc.next(), t5 = tc.next();
-                    const uint32_t t6 = tc.next(), t7 = tc.next(), t8 = tc.next(), t9 = tc.next(), t10 = tc.next(), t11 = tc.next();
-                    bool ok = t10 < e;                                   // twelve columns
-                    uint32_t qlen, qs, qe, tlen, ts, te, am, alen, aq;
-                    ok &= field_dec(text, t0 + 1, t1, qlen) & field_dec(text, t1 + 1, t2, qs) & field_dec(text, t2 + 1, t3, qe);
-                    ok &= field_dec(text, t5 + 1, t6, tlen) & field_dec(text, t6 + 1, t7, ts) & field_dec(text, t7 + 1, t8, te);
-                    ok &= field_dec(text, t8 + 1, t9, am) & field_dec(text, t9 + 1, t10, alen) & field_dec(text, t10 + 1, t11, aq);
-                    ok &= alen != 0;                                     // ZeroDivisionError unless an id:f: tag exists: exact path decides
-                    // path column (t4, t5): starts with an orientation mark; count the marks
-                    const uint32_t pa = t4 + 1, pbnd = t5;
-                    if (ok && pa < pbnd) {
-                        const uint32_t w0 = pa >> 5, w1 = (pbnd - 1) >> 5;
-                        for (uint32_t w = w0; w <= w1; ++w) {
-                            uint32_t m = oribm[w];
-                            if (w == w0) m &= 0xFFFFFFFFu << (pa & 31);
-                            if (w == w1 && ((pbnd & 31) != 0)) m &= (1u << (pbnd & 31)) - 1u;
-                            k += __builtin_popcount(m);
-                        }
-                        ok &= ((oribm[w0] >> (pa & 31)) & 1u) != 0;
-                    } else ok = false;
-                    ok &= k >= 1 && k <= KMAX;
+                if (complete) {
+                    uint32_t nt = tn - tr;
+                    if (e > s && py_space(text[e - 1])) {                // line.rstrip(): blanks, a CR, trailing tabs
+                        do --e; while (e > s && py_space(text[e - 1]));
+                        while (nt && TP[tr + nt - 1] >= e) --nt;
+                    }
+                    const uint16_t *tp = TP + tr;
+                    const uint32_t t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3], t4 = tp[4], t5 = tp[5];
+                    const uint32_t t6 = tp[6], t7 = tp[7], t8 = tp[8], t9 = tp[9], t10 = tp[10], t11 = nt >= 12u ? (uint32_t)tp[11] : e;
+                    bool ok = nt >= 11u;                                 // twelve columns
+                    // the nine decimal columns: 1..9 characters each, nothing but digits in them
+                    ok &= (t1 - t0 - 2u <= 8u) & (t2 - t1 - 2u <= 8u) & (t3 - t2 - 2u <= 8u);
+                    ok &= (t6 - t5 - 2u <= 8u) & (t7 - t6 - 2u <= 8u) & (t8 - t7 - 2u <= 8u);
+                    ok &= (t9 - t8 - 2u <= 8u) & (t10 - t9 - 2u <= 8u) & (t11 - t10 - 2u <= 8u);
                     if (ok) {
-                        status = k >= 2 ? ST_OK : ST_NOHIT;
-                        l_ts[lane] = ts; l_te[lane] = te; l_tlen[lane] = tlen; l_pbeg[lane] = (uint16_t)t4; l_pend[lane] = (uint16_t)t5;
+                        ok = bits_clear(ndbm, t0 + 1, t3 - t0 - 1) & bits_clear(ndbm, t5 + 1, t11 - t5 - 1);
+                        const uint32_t alen = field_val(text, t9 + 1, t10 - t9 - 1);
+                        ok &= alen != 0;                                 // ZeroDivisionError unless an id:f: tag exists: exact path decides
+                        // path column (t4, t5): every orientation mark of the line sits in it, the first one right after t4
+                        k = kall;
+                        ok &= k >= 1 && k <= KMAX && t5 > t4 + 1;
+                        if (ok) ok = (uint32_t)OP[o0] == t4 + 1 && (uint32_t)OP[o0 + k - 1] < t5;
+                        if (ok) {
+                            status = k >= 2 ? ST_OK : ST_NOHIT;
+                            l_tlen[lane] = field_val(text, t5 + 1, t6 - t5 - 1);
+                            l_ts[lane] = field_val(text, t6 + 1, t7 - t6 - 1);
+                            l_te[lane] = field_val(text, t7 + 1, t8 - t7 - 1);
+                            l_pend[lane] = (uint16_t)t5;
+                        }
                     }
                 }
             }
             if (status != ST_OK) k = 0;
-            uint32_t ntot;
-            const uint32_t nbase = wave_excl_scan(k, ntot);
-            // node slots exhausted: the round ends in front of the first line that does not fit (it opens the next round)
-            const unsigned long long over = __ballot(nbase + k > NMAXW);
-            const uint32_t avail = n_w - base < LRW ? n_w - base : LRW;
-            taken = over ? (uint32_t)__builtin_ctzll(over) : avail;
-            if (taken > avail) taken = avail;
+            // node slots of the round = the marks of its lines; the round ends in front of the first line that does not fit
+            const unsigned long long over = __ballot(lane < cnt && rel + kall > NMAXW);
+            taken = over ? (uint32_t)__builtin_ctzll(over) : cnt;
+            uint32_t n_nodes;
+            if (taken == 0) { taken = 1; n_nodes = 0; if (lane == 0) { status = ST_DEFER; k = 0; } }   // more marks than a round holds (> KMAX): exact path
+            else n_nodes = (uint32_t)LO[lbase + taken] - obase;
             if (lane >= taken) { status = ST_NONE; k = 0; }
-            const uint32_t n_nodes = (uint32_t)__shfl(nbase + k, (int)taken - 1);
-            // ---- R2: node slots from the orientation bitmap; every name must be non-empty ------------------------
-            if (k) {
-                const uint32_t pa = (uint32_t)l_pbeg[lane] + 1, pbnd = l_pend[lane];
-                BitCursor oc{oribm, pa >> 5, 0, pbnd};
-                oc.cur = oribm[pa >> 5] & (0xFFFFFFFFu << (pa & 31));
-                uint32_t prev = pa - 1;
-                bool ok = true;
-                for (uint32_t j = 0; j < k; ++j) {
-                    const uint32_t q = oc.next();
-                    ok &= (j == 0) | (q > prev + 1);
-                    prev = q;
-                    n_pos[nbase + j] = (uint16_t)(q + 1);
-                    n_line[nbase + j] = (uint16_t)lane;                 // orientation bit added by the node's lane (R3)
-                }
-                ok &= pbnd > prev + 1;
-                if (!ok) status = ST_DEFER;
-            }
-            if (lane < LRW) l_meta[lane] = nbase | (k << 16) | (status << 24);
+            if (lane < LRW) l_meta[lane] = rel | (k << 16) | (status << 24);
             wave_sync();
-            if (a.diag & 2u) continue;                                   // measurement only: stop after R2
+            tick(3);
+            if (a.diag & 2u) continue;                                   // measurement only: stop after R1
             // ---- R3: one node per lane: hash the name, fetch BOTH candidate entries of the two-choice name table at once
             //      (one round trip for every lane, no probe sequences), compare the spelling --------------------------------
             for (uint32_t nb = 0; nb < n_nodes; nb += UB3 * 64) {
-                uint32_t nn[UB3], lnv[UB3], d[UB3][8], len[UB3];
+                uint32_t nn[UB3], lnv[UB3], d[UB3][8], len[UB3], ori[UB3];
                 uint4 e0[UB3][2], e1[UB3][2], e2[UB3][2];
                 bool live[UB3], probe[UB3];
 #pragma unroll
                 for (uint32_t u = 0; u < UB3; ++u) {
                     nn[u] = nb + u * 64 + lane;
-                    live[u] = false; probe[u] = false; lnv[u] = 0; len[u] = 0;
+                    live[u] = false; probe[u] = false; lnv[u] = 0; len[u] = 0; ori[u] = 0;
                     uint32_t s1 = 0, s2 = 0;
                     if (nn[u] < n_nodes) {
-                        lnv[u] = n_line[nn[u]] & 0x7FFFu;
+                        lnv[u] = (uint32_t)OL[obase + nn[u]] - lbase;
                         const uint32_t meta = l_meta[lnv[u]];
                         if ((meta >> 24) == ST_OK) {
                             live[u] = true;
-                            const uint32_t a0 = n_pos[nn[u]];
+                            const uint32_t a0 = (uint32_t)OP[obase + nn[u]] + 1u;
                             const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
-                            const uint32_t b0 = (nn[u] + 1 < lnb + lk) ? (uint32_t)n_pos[nn[u] + 1] - 1u : (uint32_t)l_pend[lnv[u]];
-                            if (text[a0 - 1] == '<') n_line[nn[u]] = (uint16_t)(lnv[u] | 0x8000u);
+                            const uint32_t b0 = (nn[u] + 1 < lnb + lk) ? (uint32_t)OP[obase + nn[u] + 1] : (uint32_t)l_pend[lnv[u]];
+                            ori[u] = text[a0 - 1] == '<' ? 0x80000000u : 0u;
                             len[u] = b0 - a0;
                             probe[u] = len[u] - 1u <= 31u && !(a.diag & 4u);     // names of 1..32 bytes; longer ones: exact path
                             if (probe[u]) cuckoo_slots(name_words(text, a0, len[u], d[u]), g.name_seed, g.name_mask, s1, s2);
@@ -523,12 +546,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                             if ((m0 | m1) && mz != 0xFFFFFFFFu && !(mz & 0x60u)) { id = mz >> 7; lbp = mw; }
                         }
                         if (a.diag & 4u) { id = 0; lbp = 100; }
-                        n_id[nn[u]] = id; n_pre[nn[u]] = lbp;
+                        n_id[nn[u]] = id == NONE32 ? NONE32 : (id | ori[u]); n_pre[nn[u]] = lbp;
                         if (id == NONE32) atomicOr(&l_meta[lnv[u]], ST_DEFER << 24);              // ST_OK | ST_DEFER == ST_DEFER
                     }
                 }
             }
             wave_sync();
+            tick(4);
             if (a.diag & 64u) continue;                                  // measurement only: stop after R3
             // ---- R4: one line per lane: prefix sums, first occurrences --------------------------------------
             if (lane < taken) {
@@ -537,14 +561,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
                     unsigned long long run = 0, seen1 = 0, seen2 = 0;
                     for (uint32_t j = 0; j < lk; ++j) {
-                        const uint32_t idj = n_id[lnb + j];
+                        const uint32_t idj = n_id[lnb + j] & 0x7FFFFFFFu;
                         run += n_pre[lnb + j];
                         n_pre[lnb + j] = (uint32_t)run;
                         uint32_t f = j;
                         // two-hash filter: only a possible revisit pays for the search of the first occurrence
                         const unsigned long long b1 = 1ull << (idj & 63), b2 = 1ull << ((idj * 0x9E3779B1u) >> 26);
                         if ((seen1 & b1) && (seen2 & b2))
-                            for (uint32_t jj = 0; jj < j; ++jj) if (n_id[lnb + jj] == idj) { f = jj; break; }
+                            for (uint32_t jj = 0; jj < j; ++jj) if ((n_id[lnb + jj] & 0x7FFFFFFFu) == idj) { f = jj; break; }
                         seen1 |= b1; seen2 |= b2;
                         n_first[lnb + j] = (uint16_t)(lnb + f);
                     }
@@ -553,17 +577,18 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 }
             }
             wave_sync();
+            tick(5);
             // ---- R5: one path step per lane; UB5 steps per lane, both candidate link-table entries of every step fetched in one round trip ------------
             for (uint32_t nb = 0; nb < n_nodes; nb += UB5 * 64) {
-                uint32_t lnv[UB5], klo[UB5], khi[UB5], sa[UB5], sb[UB5];
+                uint32_t lnv[UB5], klo[UB5], khi[UB5], sa[UB5], sb2[UB5];
                 uint4 ek[UB5], ek2[UB5];
                 bool go[UB5];
 #pragma unroll
                 for (uint32_t u = 0; u < UB5; ++u) {
                     const uint32_t n = nb + u * 64 + lane;
-                    go[u] = false; lnv[u] = 0; klo[u] = khi[u] = sa[u] = sb[u] = 0;
+                    go[u] = false; lnv[u] = 0; klo[u] = khi[u] = sa[u] = sb2[u] = 0;
                     if (n + 1 < n_nodes) {
-                        const uint32_t ln = n_line[n] & 0x7FFFu;
+                        const uint32_t ln = (uint32_t)OL[obase + n] - lbase;
                         const uint32_t meta = l_meta[ln];
                         const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
                         if ((meta >> 24) == ST_OK && n + 1 < lnb + lk) {
@@ -575,9 +600,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                             const long long right = (long long)l_tot[ln] - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
                             if (left >= (long long)g.d_over && right >= (long long)g.d_over) {
                                 go[u] = true; lnv[u] = ln;
-                                klo[u] = (n_id[n + 1] << 1) | (uint32_t)(n_line[fr] >> 15);
-                                khi[u] = (n_id[n] << 1) | (uint32_t)(n_line[fl] >> 15);
-                                cuckoo_slots(link_prehash(klo[u], khi[u]), g.link_seed, g.link_mask, sa[u], sb[u]);
+                                const uint32_t xr = n_id[fr], xl = n_id[fl];             // id | orientation << 31  ->  id << 1 | orientation
+                                klo[u] = (xr << 1) | (xr >> 31);
+                                khi[u] = (xl << 1) | (xl >> 31);
+                                cuckoo_slots(link_prehash(klo[u], khi[u]), g.link_seed, g.link_mask, sa[u], sb2[u]);
                             }
                         }
                     }
@@ -585,7 +611,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
 #pragma unroll
                 for (uint32_t u = 0; u < UB5; ++u) {
                     ek[u] = ek2[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
-                    if (go[u]) { ek[u] = *(const uint4 *)(g.link_tab + (size_t)sa[u] * 4); ek2[u] = *(const uint4 *)(g.link_tab + (size_t)sb[u] * 4); }
+                    if (go[u]) { ek[u] = *(const uint4 *)(g.link_tab + (size_t)sa[u] * 4); ek2[u] = *(const uint4 *)(g.link_tab + (size_t)sb2[u] * 4); }
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < UB5; ++u) {
@@ -614,7 +640,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
                         if (a.want_hits) {
                             if (rbase + j < a.rec_cap) {
-                                svjg_hitrec r; r.line_start = a.base_offset + c0 + rstart[lnv[u]]; r.slot = hv >> 1;
+                                svjg_hitrec r; r.line_start = a.base_offset + c0 + LS[lbase + lnv[u]]; r.slot = hv >> 1;
                                 r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
                                 a.recs[rbase + j] = r;
                             } else atomicOr(&a.st->overflow, 2u);
@@ -622,6 +648,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
             }
+            tick(6);
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
                 const bool defer = lane < taken && (l_meta[lane] >> 24) == ST_DEFER;
@@ -640,10 +667,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             }
             wave_sync();                                                 // round state is reused
         }
-        wave_lines += n_w;
-        __syncthreads();                                                 // text and bitmaps are overwritten by the next stripe
+        wave_lines += l_hi - l_lo;
+        __syncthreads();                                                 // text, bitmap and lists are overwritten by the next stripe
+        tick(7);
     }
     if (lane == 0 && wave_lines) atomicAdd(&a.st->n_lines, wave_lines);
+    if (timing && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc[i]);
 }
 
 struct SlowEmit {
