@@ -31,45 +31,46 @@ inline std::vector<uint32_t> build_chrom_hash(const svjg_graph &g) {
 
 }  // namespace svjg
 
+#include <algorithm>
 #include <string>
+#include "svjg_line.h"
 
 namespace svjg {
 
-// ---- hash tables of the main kernel --------------------------------------------------------------------
-// Both tables are two-choice (cuckoo) tables built here on the host: every key sits in one of its TWO candidate
-// slots, so the kernel fetches both candidates at once and a lookup is exactly one round trip to memory for every
-// lane of a wave (with linear probing, some lane of nearly every wave had to walk on: a second, dependent trip).
-// NAME TABLE: canonical node name (<= 32 bytes, zero padded to eight words) -> node.  The kernel hashes the raw
-// bytes of a path segment and compares them with the stored spelling: no number parsing on the device, and
-// only names spelled exactly like the graph's can match (anything else goes to the exact path).
-//   entry = 16 words (one 64-byte line): [0..5] name bytes 0..23, [6] node id << 7 | flags << 5 | (byte length - 1)
-//                     (flags: bit 0 hazard-prone, bit 1 length unknown; all ones = empty slot), [7] node length in bp,
-//                     [8..9] name bytes 24..31, [10..15] unused.  Names of up to 24 bytes (all of the usual
-//                     "chrN:start-end") are decided by the first two 16-byte loads.
-//   (A 16-byte fingerprint entry was measured too: 2 % faster, not worth giving up the exact comparison.)
-// LINK TABLE: (left id, left strand, right id, right strand) -> hits, same content as the CSR rows.
+// ---- tables of the main kernel ---------------------------------------------------------------------------------
+// The kernel is bound by how many 64-byte lines it pulls from beyond the L2 (random lines of a table of tens of MB come
+// at ~66 G lines/s on MI355X, tools/ubench/randread.hip), so the tables are built for ONE line per path node:
+// NODE RECORDS: perfect hash (hash and displace, svjg_line.h: name_prehash / name_bucket / name_slot) of the canonical
+// node names (<= 32 bytes).  The kernel hashes the raw bytes of a path segment, reads the bucket's 2-byte displacement
+// (a small array that stays cached), fetches the one record the name can be in and compares the spelling: no number
+// parsing on the device, and only names spelled exactly like the graph's can match (anything else: exact path).
+//   record = 16 words (one 64-byte line):
+//     [0..5] name bytes 0..23   [6] node id << 7 | flags << 5 | (byte length - 1)   (flags: bit 0 hazard-prone name,
+//     bit 1 length unknown; all ones = empty slot)   [7] node length in bp | REC_ROW_INLINE if the node has no other links
+//     than the inline ones   [8..9] name bytes 24..31
+//     [10..12], [13..15] two of the node's links, reference-allele links first: key = right id << 2 | left strand |
+//     right strand << 1 (all ones = none), then the two hit words of a link-table entry.  Most path steps are answered
+//     from the record that the node lookup fetched anyway and never touch the link table.
+// LINK TABLE: (left id, left strand, right id, right strand) -> hits, same content as the CSR rows; two-choice (cuckoo)
+// table: every key sits in one of its TWO candidate slots.  The SLOT of a link is hashed from the name digests of its two
+// nodes and the strands (name_x32), not from the ids.
 //   entry = 4 words (one 16-byte load): [0] key low, [1] key high, [2] a, [3] b with
 //       1 hit : a = hit, b = LINK_NO_HIT        2 hits: a, b = the hits
 //       more  : a = LINK_MANY | index into hits[], b = number of hits
 //   key = left << 33 | left strand << 32 | right << 1 | right strand ; all ones = empty slot.
-// A key the builder cannot place (three keys with one pre-hash; never seen) is left out: the kernel then finds
-// nothing and hands the line to the exact path.
 constexpr uint32_t NAME_ENT_WORDS = 16, LINK_ENT_WORDS = 4;
 constexpr uint32_t LINK_NO_HIT = 0xFFFFFFFFu, LINK_MANY = 0x80000000u;
 constexpr uint32_t NAME_EMPTY = 0xFFFFFFFFu, NAME_MAX_ID = (1u << 25) - 2u;
+constexpr uint32_t REC_ROW_INLINE = 0x80000000u, REC_NO_LINK = 0xFFFFFFFFu;
 inline bool name_ent_empty(const uint32_t *e) { return e[6] == NAME_EMPTY; }
 inline uint32_t name_ent_len(const uint32_t *e) { return (e[6] & 31u) + 1u; }
 inline uint32_t name_ent_id(const uint32_t *e) { return e[6] >> 7; }
 inline void name_ent_words(const uint32_t *e, uint32_t d[8]) { for (int w = 0; w < 6; ++w) d[w] = e[w]; d[6] = e[8]; d[7] = e[9]; }
 
-// pre-hash of a name (the kernel's name_words computes the same sum) and of a link key
-inline uint32_t name_prehash_host(const uint32_t *d, uint32_t len) {
-    static const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
-    uint32_t h = len * 0x7FEB352Du;
-    for (int i = 0; i < 8; ++i) h += d[i] * C[i];
-    return h;
+// xl, xr = name digests (name_x32) of the left / right node, sl, sr = strands (1 = '-')
+inline uint32_t link_prehash_host(uint32_t xl, uint32_t sl, uint32_t xr, uint32_t sr) {
+    return xl * 0x9E3779B1u + (xr ^ (sl * 0x68E31DA4u) ^ (sr * 0xB5297A4Du)) * 0x85EBCA77u;
 }
-inline uint32_t link_prehash_host(uint64_t key) { return (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x9E3779B1u); }
 // the two candidate slots of a pre-hash (svjg_kernels.h: cuckoo_slots is the device twin)
 inline void cuckoo_slots_host(uint32_t x, uint32_t seed, uint32_t mask, uint32_t &s1, uint32_t &s2) {
     uint32_t a = x ^ seed;
@@ -81,10 +82,13 @@ inline void cuckoo_slots_host(uint32_t x, uint32_t seed, uint32_t mask, uint32_t
 }
 
 struct KernelTables {
-    std::vector<uint32_t> names; uint32_t name_mask = 0, name_seed = 0;
+    std::vector<uint32_t> names; uint32_t name_slots = 0, name_buckets = 0;
+    std::vector<uint16_t> disp;                               // displacement of every bucket of the name hash
     std::vector<uint32_t> links; uint32_t link_mask = 0, link_seed = 0;
     uint64_t names_left_out = 0, links_left_out = 0;
     uint32_t names_skipped = 0;                               // node names the table cannot hold (> 32 bytes, id too large)
+    std::vector<uint32_t> node_pre; std::vector<uint8_t> node_has;   // per node: name digest, "is in the name table" (table checks)
+    std::vector<uint32_t> node_slot;                          // per node: its record (table checks)
 };
 
 // Two-choice placement by random-walk eviction.  pre[i] = pre-hash of key i; returns owner[slot] = key index or -1.
@@ -119,16 +123,51 @@ inline std::vector<int64_t> cuckoo_place(const std::vector<uint32_t> &pre, uint3
     return best;
 }
 
+// Hash and displace: keys h[i] (64-bit pre-hashes, distinct) -> a slot of its own for every key.  Buckets are worked
+// off largest first; a bucket's displacement is the first value that sends all its keys to free, distinct slots.
+// false: some bucket found no displacement below 65536 (the caller retries with more room).
+inline bool chd_place(const std::vector<uint64_t> &h, uint32_t n_slots, uint32_t n_buckets, std::vector<uint16_t> &disp, std::vector<uint32_t> &slot_of) {
+    std::vector<std::vector<uint32_t>> bk(n_buckets);
+    for (uint32_t i = 0; i < h.size(); ++i) bk[name_bucket(h[i], n_buckets)].push_back(i);
+    std::vector<uint32_t> order(n_buckets);
+    for (uint32_t b = 0; b < n_buckets; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bk[x].size() > bk[y].size(); });
+    std::vector<uint8_t> used(n_slots, 0);
+    disp.assign(n_buckets, 0);
+    slot_of.assign(h.size(), 0);
+    std::vector<uint32_t> tmp;
+    for (uint32_t b : order) {
+        const std::vector<uint32_t> &keys = bk[b];
+        if (keys.empty()) break;
+        uint32_t d = 0;
+        for (; d < 65536; ++d) {
+            tmp.clear();
+            bool ok = true;
+            for (uint32_t k : keys) {
+                const uint32_t s = name_slot(h[k], d, n_slots);
+                if (used[s]) { ok = false; break; }
+                for (uint32_t t : tmp) if (t == s) { ok = false; break; }
+                if (!ok) break;
+                tmp.push_back(s);
+            }
+            if (ok) break;
+        }
+        if (d == 65536) return false;
+        disp[b] = (uint16_t)d;
+        for (size_t j = 0; j < keys.size(); ++j) { used[tmp[j]] = 1; slot_of[keys[j]] = tmp[j]; }
+    }
+    return true;
+}
+
 inline KernelTables build_kernel_tables(const svjg_graph &g) {
     KernelTables kt;
-    uint64_t nsz = 16;
-    while (nsz < 5 * g.n_nodes / 2 + 2) nsz *= 2;            // load <= 0.4
-    kt.names.assign(nsz * NAME_ENT_WORDS, 0);
-    for (uint64_t j = 0; j < nsz; ++j) kt.names[j * NAME_ENT_WORDS + 6] = NAME_EMPTY;
-    kt.name_mask = (uint32_t)nsz - 1;
+    std::vector<uint32_t> node_pre((size_t)g.n_nodes, 0);    // name digest of every node the name table holds
+    std::vector<uint8_t> node_has((size_t)g.n_nodes, 0);
+    std::vector<uint32_t> node_slot((size_t)g.n_nodes, 0);
     {
-        std::vector<uint32_t> ent;                            // 10 words per candidate: d[0..7], meta, len_bp
-        std::vector<uint32_t> pre;
+        std::vector<uint32_t> ent;                            // 10 words per key: d[0..7], meta, len_bp
+        std::vector<uint64_t> hs;
+        std::vector<uint32_t> key_node;
         for (uint64_t i = 0; i < g.n_nodes; ++i) {
             const svjg_node &nd = g.nodes[i];
             uint32_t c = (uint32_t)(nd.key >> 48), pos = (uint32_t)(nd.key >> 16), kind = (uint32_t)(nd.key >> 15) & 1u, cnt = (uint32_t)nd.key & 0x7FFFu;
@@ -139,37 +178,96 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             for (size_t b = 0; b < nm.size(); ++b) d[b >> 2] |= (uint32_t)(uint8_t)nm[b] << (8 * (b & 3));
             uint32_t flags = ((nd.row & 0x80000000u) ? 1u : 0u) | ((kind && nd.aux == SVJG_LEN_UNKNOWN) ? 2u : 0u);
             uint32_t len_bp = kind ? nd.aux : nd.aux - pos + 1;
+            if (len_bp & REC_ROW_INLINE) flags |= 2u;         // (no node is 2 Gbp long; keeps the flag bit free)
             for (int w = 0; w < 8; ++w) ent.push_back(d[w]);
             ent.push_back(((uint32_t)i << 7) | (flags << 5) | ((uint32_t)nm.size() - 1u));
-            ent.push_back(len_bp);
-            pre.push_back(name_prehash_host(d, (uint32_t)nm.size()));
+            ent.push_back(len_bp & ~REC_ROW_INLINE);
+            hs.push_back(name_prehash(d, (uint32_t)nm.size()));
+            key_node.push_back((uint32_t)i);
         }
-        std::vector<int64_t> owner = cuckoo_place(pre, kt.name_mask, kt.name_seed, kt.names_left_out);
-        for (uint64_t j = 0; j < nsz; ++j) {
-            if (owner[j] < 0) continue;
-            const uint32_t *src = &ent[(size_t)owner[j] * 10];
+        // two names with one 64-bit pre-hash cannot be told apart by any displacement: both stay out (exact path)
+        {
+            std::vector<uint32_t> idx(hs.size());
+            for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
+            std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return hs[x] < hs[y]; });
+            std::vector<uint8_t> drop(hs.size(), 0);
+            for (size_t i = 1; i < idx.size(); ++i) if (hs[idx[i]] == hs[idx[i - 1]]) { drop[idx[i]] = drop[idx[i - 1]] = 1; }
+            size_t w = 0;
+            for (size_t i = 0; i < hs.size(); ++i) {
+                if (drop[i]) { ++kt.names_left_out; continue; }
+                if (w != i) { hs[w] = hs[i]; key_node[w] = key_node[i]; for (int q = 0; q < 10; ++q) ent[w * 10 + q] = ent[i * 10 + q]; }
+                ++w;
+            }
+            hs.resize(w); key_node.resize(w); ent.resize(w * 10);
+        }
+        const uint64_t n = hs.size();
+        std::vector<uint32_t> slot_of;
+        uint64_t slots = n + n / 4 + 16;                      // load <= 0.8
+        for (int grow = 0;; ++grow) {
+            kt.name_slots = (uint32_t)slots;
+            kt.name_buckets = (uint32_t)(n / 3 + 1);
+            if (chd_place(hs, kt.name_slots, kt.name_buckets, kt.disp, slot_of)) break;
+            if (grow == 6) { kt.names_left_out += n; hs.clear(); key_node.clear(); slot_of.clear(); break; }   // never seen: everything takes the exact path
+            slots += slots / 4;
+        }
+        kt.names.assign((size_t)kt.name_slots * NAME_ENT_WORDS, 0);
+        for (uint64_t j = 0; j < kt.name_slots; ++j) {
             uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
+            e[6] = NAME_EMPTY; e[10] = e[13] = REC_NO_LINK;
+        }
+        for (uint64_t k = 0; k < hs.size(); ++k) {
+            const uint32_t *src = &ent[(size_t)k * 10];
+            uint32_t *e = &kt.names[(size_t)slot_of[k] * NAME_ENT_WORDS];
             for (int w = 0; w < 6; ++w) e[w] = src[w];
             e[6] = src[8]; e[7] = src[9]; e[8] = src[6]; e[9] = src[7];
+            const uint32_t node = key_node[k];
+            node_pre[node] = name_x32(hs[k]); node_has[node] = 1; node_slot[node] = slot_of[k];
+            // inline links: up to two rows of the node, those whose hits are all reference-allele first
+            const uint32_t a = g.nodes[node].row & 0x7FFFFFFFu, b = g.nodes[node + 1].row & 0x7FFFFFFFu;
+            std::vector<uint32_t> rows;
+            for (int pass = 0; pass < 2; ++pass)
+                for (uint32_t i = a; i < b; ++i) {
+                    const svjg_edge &ed = g.edges[i];
+                    const uint32_t nh = ed.meta >> 2;
+                    if (!nh || ed.right > NAME_MAX_ID) continue;
+                    bool alt = false;
+                    for (uint32_t q = 0; q < nh; ++q) alt |= ((nh <= 2 ? (q ? ed.h1 : ed.h0) : g.hits[ed.h0 + q]) & 1u) != 0;
+                    if ((int)alt == pass) rows.push_back(i);
+                }
+            uint32_t n_live = 0;
+            for (uint32_t i = a; i < b; ++i) n_live += (g.edges[i].meta >> 2) != 0;
+            for (size_t q = 0; q < rows.size() && q < 2; ++q) {
+                const svjg_edge &ed = g.edges[rows[q]];
+                const uint32_t nh = ed.meta >> 2;
+                uint32_t *l = e + 10 + 3 * q;
+                l[0] = (ed.right << 2) | (ed.meta & 3u);
+                if (nh == 1) { l[1] = ed.h0; l[2] = LINK_NO_HIT; }
+                else if (nh == 2) { l[1] = ed.h0; l[2] = ed.h1; }
+                else { l[1] = LINK_MANY | ed.h0; l[2] = nh; }
+            }
+            if (n_live <= 2 && rows.size() == n_live) e[7] |= REC_ROW_INLINE;
         }
     }
+    // a link that cannot be placed would be a silent miss in the kernel: grow the table until every link sits in one of its
+    // two slots (links_left_out stays > 0 only if that fails; the library then routes everything through the exact path)
     uint64_t lsz = 16;
     while (lsz < 5 * g.n_edges / 2 + 2) lsz *= 2;
-    kt.links.assign(lsz * LINK_ENT_WORDS, 0xFFFFFFFFu);
-    kt.link_mask = (uint32_t)lsz - 1;
-    {
+    for (int grow = 0; grow < 4; ++grow, lsz *= 2) {
+        kt.links.assign(lsz * LINK_ENT_WORDS, 0xFFFFFFFFu);
+        kt.link_mask = (uint32_t)lsz - 1;
         std::vector<uint32_t> ent, pre;                       // 4 words per candidate
         for (uint64_t n = 0; n < g.n_nodes; ++n) {
             uint32_t a = g.nodes[n].row & 0x7FFFFFFFu, b = g.nodes[n + 1].row & 0x7FFFFFFFu;
             for (uint32_t i = a; i < b; ++i) {
                 const svjg_edge &ed = g.edges[i];
+                if (!node_has[n] || !node_has[ed.right]) continue;   // a node outside the name table sends its lines to the exact path anyway
                 uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
                 const uint32_t nh = ed.meta >> 2;
                 ent.push_back((uint32_t)key); ent.push_back((uint32_t)(key >> 32));
                 if (nh == 1) { ent.push_back(ed.h0); ent.push_back(LINK_NO_HIT); }
                 else if (nh == 2) { ent.push_back(ed.h0); ent.push_back(ed.h1); }
                 else { ent.push_back(LINK_MANY | ed.h0); ent.push_back(nh); }
-                pre.push_back(link_prehash_host(key));
+                pre.push_back(link_prehash_host(node_pre[n], ed.meta & 1u, node_pre[ed.right], (ed.meta >> 1) & 1u));
             }
         }
         std::vector<int64_t> owner = cuckoo_place(pre, kt.link_mask, kt.link_seed, kt.links_left_out);
@@ -177,7 +275,9 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             if (owner[j] < 0) continue;
             for (int w = 0; w < 4; ++w) kt.links[j * LINK_ENT_WORDS + w] = ent[(size_t)owner[j] * 4 + w];
         }
+        if (kt.links_left_out == 0) break;
     }
+    kt.node_pre.swap(node_pre); kt.node_has.swap(node_has); kt.node_slot.swap(node_slot);
     return kt;
 }
 

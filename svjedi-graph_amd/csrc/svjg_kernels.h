@@ -29,16 +29,12 @@ constexpr uint32_t LOOK_MIN = 2048, LOOK_MAX = 16384;
 constexpr uint32_t MAXL = 512;                   // line starts per stripe (a stripe with more goes to the exact path as a whole)
 constexpr uint32_t CAP_T = 4096;                 // tab positions per stripe
 constexpr uint32_t CAP_O = 2048;                 // orientation marks ('<' '>') per stripe
-constexpr uint32_t KMAX = 128;                   // path nodes per alignment handled by the main kernel (longer paths: exact path)
+constexpr uint32_t KMAX = 64;                    // path nodes per alignment handled by the main kernel: one wave pass (longer paths: exact path)
 #ifndef SVJG_LRW
 #define SVJG_LRW 32
 #endif
-#ifndef SVJG_NMAXW
-#define SVJG_NMAXW 160
-#endif
 constexpr uint32_t LRW = SVJG_LRW;               // lines per wave and round
-constexpr uint32_t NMAXW = SVJG_NMAXW;           // orientation marks (path nodes) per wave and round
-static_assert(LRW <= 64 && KMAX <= NMAXW && KMAX < 256 && NMAXW < 32768, "round geometry");
+static_assert(LRW <= 64 && KMAX <= 64, "round geometry: a line's nodes fit one wave pass");
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
 // LDS carve-up of k_classify_main (bytes): text, the non-digit bitmap and the lists are shared by the workgroup,
@@ -56,13 +52,9 @@ constexpr uint32_t L_WAVE = L_MISC + 128;
 constexpr uint32_t W_TS = 0;                                               // u32[LRW]  path start column
 constexpr uint32_t W_TE = W_TS + LRW * 4;                                  // u32[LRW]
 constexpr uint32_t W_TLEN = W_TE + LRW * 4;                                // u32[LRW]
-constexpr uint32_t W_TOT = W_TLEN + LRW * 4;                               // u32[LRW]  sum of node lengths
-constexpr uint32_t W_META = W_TOT + LRW * 4;                               // u32[LRW]  first node slot | k << 16 | status << 24
+constexpr uint32_t W_META = W_TLEN + LRW * 4;                              // u32[LRW]  first mark of the line (relative to the round) | k << 16 | status << 24
 constexpr uint32_t W_PEND = W_META + LRW * 4;                              // u16[LRW]  tab after the path column
-constexpr uint32_t W_NFIRST = W_PEND + LRW * 2;                            // u16[NMAXW]  first node of the line with the same name
-constexpr uint32_t W_NID = (W_NFIRST + NMAXW * 2 + 3) / 4 * 4;             // u32[NMAXW]  node id | orientation << 31
-constexpr uint32_t W_NPRE = W_NID + NMAXW * 4;                             // u32[NMAXW]  length, then inclusive prefix
-constexpr uint32_t WAVE_BYTES = (W_NPRE + NMAXW * 4 + 15) / 16 * 16;
+constexpr uint32_t WAVE_BYTES = (W_PEND + LRW * 2 + 15) / 16 * 16;
 constexpr uint32_t LDS_MAIN = L_WAVE + NWAVE * WAVE_BYTES;
 static_assert(L_NDBM % 16 == 0 && L_TP % 16 == 0 && L_OP % 16 == 0 && L_LS % 16 == 0 && L_MISC % 16 == 0, "LDS alignment");
 
@@ -149,13 +141,13 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *slot, uint32_t 
 
 enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round
 
-// Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the pre-hash of the node-name table
-// (svjg_host_tables.h: name_prehash_host).
-__device__ inline uint32_t name_words(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
+// Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the 64-bit pre-hash of the node-name table
+// (svjg_line.h: name_prehash).
+__device__ inline uint64_t name_words(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
     const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
     const uint32_t sh = a0 & 3u;
     uint32_t prev = w[0];
-    uint32_t h = L * 0x7FEB352Du;
+    uint64_t h = (uint64_t)L * 0x7FEB352Du;
     const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
 #pragma unroll
     for (uint32_t i = 0; i < 8; ++i) {
@@ -163,7 +155,7 @@ __device__ inline uint32_t name_words(const uint8_t *text, uint32_t a0, uint32_t
         const uint32_t nb = L > 4 * i ? L - 4 * i : 0u;                 // bytes of the name in this word
         d[i] = __builtin_amdgcn_alignbyte(nx, prev, sh) & (nb >= 4 ? 0xFFFFFFFFu : ((1u << ((8 * nb) & 31u)) - 1u));
         prev = nx;
-        h += d[i] * C[i];
+        h += (uint64_t)d[i] * C[i];
     }
     return h;
 }
@@ -178,22 +170,21 @@ __device__ inline void cuckoo_slots(uint32_t x, uint32_t seed, uint32_t mask, ui
     if (s2 == s1) s2 = s1 ^ 1u;
 }
 
-// entry of the node-name table (svjg_host_tables.h): q0 = name bytes 0..15, q1 = bytes 16..23 | meta | length in bp,
-// q2 (fetched for names longer than 24 bytes only) = bytes 24..31
-__device__ inline bool name_match(const uint4 q0, const uint4 q1, const uint4 q2, const uint32_t d[8], uint32_t L) {
-    return (q1.z & 31u) == L - 1u && q0.x == d[0] && q0.y == d[1] && q0.z == d[2] && q0.w == d[3] &&
-           q1.x == d[4] && q1.y == d[5] && (L <= 24u || (q2.x == d[6] && q2.y == d[7]));
+// record of the node-name table (svjg_host_tables.h): r0 = name bytes 0..15, r1 = bytes 16..23 | meta | length in bp,
+// r2.xy = bytes 24..31 (only names longer than 24 bytes look at them)
+__device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[8], uint32_t L) {
+    return (r1.z & 31u) == L - 1u && r0.x == d[0] && r0.y == d[1] && r0.z == d[2] && r0.w == d[3] &&
+           r1.x == d[4] && r1.y == d[5] && (L <= 24u || (r2.x == d[6] && r2.y == d[7]));
 }
 
-__device__ inline uint32_t link_prehash(uint32_t klo, uint32_t khi) { return klo ^ (khi * 0x9E3779B1u); }
+// slot hash of a link from the name digests (name_x32) of its two nodes and their strands (svjg_host_tables.h: link_prehash_host)
+__device__ inline uint32_t link_prehash(uint32_t xl, uint32_t sl, uint32_t xr, uint32_t sr) {
+    return xl * 0x9E3779B1u + (xr ^ (sl * 0x68E31DA4u) ^ (sr * 0xB5297A4Du)) * 0x85EBCA77u;
+}
 
-#ifndef SVJG_UB3
-#define SVJG_UB3 1
-#endif
-#ifndef SVJG_UB5
-#define SVJG_UB5 2
-#endif
-constexpr uint32_t UB3 = SVJG_UB3, UB5 = SVJG_UB5;  // path nodes (R3) / path steps (R5) per lane handled at a time (table loads in flight)
+// Workgroup barrier for data handed over through LDS only.  __syncthreads() also drains the wave's global-memory queue
+// (s_waitcnt vmcnt(0)): that would stall on the next stripe's prefetch and on the count atomics still in flight.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, the fences only pin the compiler
 __device__ inline void wave_sync() {
@@ -211,15 +202,16 @@ __device__ inline void wave_sync() {
 //   B2  every terminator / tab / mark knows its ordinal in the stripe: rank-indexed lists -> LDS
 //         LS[l] LT[l] LO[l]  start of line l, tabs and marks in front of it      TP[t]  position of tab t
 //         OP[o] OL[o]        position of mark o, line that holds it                                  [workgroup barrier]
-//   then every WAVE on its own, for an equal share of the stripe's lines, in rounds of up to LRW lines / NMAXW marks
+//   then every WAVE on its own, for an equal share of the stripe's lines, in rounds of up to LRW lines
 //   (no loops over bytes or bits from here on: a line's j-th tab is TP[LT[l] + j], its j-th node starts at OP[LO[l] + j]):
 //   R1 one LINE per lane: twelve column boundaries, column lengths, digits-only test on the bitmap, the four decimal
 //      values that matter (Tlen, Ts, Te, Alen), path geometry
-//   R3 one path NODE per lane: name -> both candidate slots of the node-name hash table (one round trip) -> id, length
-//   R4 one LINE per lane: running path length, first occurrence of every name (the reference's list.index /
-//      str.split quirks)
-//   R5 one path STEP (link) per lane: overlap test on the prefix sums, link hash table lookup, one 64-bit
-//      atomic (ref | alt << 32) per hit, optional hit records
+//   NP node passes over up to 64 consecutive marks covering whole lines, one path NODE per lane, everything in registers:
+//      name -> both candidate slots of the node-name hash table, and in the SAME round trip both candidate slots of
+//      the link to the next node (link slots are hashed from the two name pre-hashes); then id / length, running path
+//      length by a segmented wave scan, first occurrence of every name (the reference's list.index / str.split
+//      quirks) by wave shuffles, overlap test, link key check, one 64-bit atomic (ref | alt << 32) per hit,
+//      optional hit records
 //   R6 deferred-line offsets, one aggregated atomic per wave
 //                                                                                                     [workgroup barrier]
 
@@ -314,18 +306,19 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t *wb = lds + L_WAVE + wave * WAVE_BYTES;                    // this wave's private arrays
     uint32_t *l_ts = (uint32_t *)(wb + W_TS), *l_te = (uint32_t *)(wb + W_TE), *l_tlen = (uint32_t *)(wb + W_TLEN);
-    uint32_t *l_tot = (uint32_t *)(wb + W_TOT), *l_meta = (uint32_t *)(wb + W_META);
-    uint16_t *l_pend = (uint16_t *)(wb + W_PEND), *n_first = (uint16_t *)(wb + W_NFIRST);
-    uint32_t *n_id = (uint32_t *)(wb + W_NID), *n_pre = (uint32_t *)(wb + W_NPRE);
+    uint32_t *l_meta = (uint32_t *)(wb + W_META);
+    uint16_t *l_pend = (uint16_t *)(wb + W_PEND);
 
     const GraphView g = a.g;
 
     unsigned long long wave_lines = 0;
-    // measurement only (SVJG_DIAG & 16): time this wave spends per phase
-    unsigned long long stamp = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool timing = (a.diag & 16u) != 0;
-    auto tick = [&](int ph) { if (timing) { const unsigned long long t = __builtin_readcyclecounter(); acc[ph] += t - stamp; stamp = t; } };
-    if (timing) stamp = __builtin_readcyclecounter();
+    // measurement only (build with -DSVJG_TIMING, run with SVJG_DIAG & 16): time this wave spends per phase
+#ifdef SVJG_TIMING
+    unsigned long long stamp = __builtin_readcyclecounter(), acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&](int ph) { const unsigned long long t = __builtin_readcyclecounter(); acc[ph] += t - stamp; stamp = t; };
+#else
+    auto tick = [](int) {};
+#endif
 
     // stripe prefetch registers
     uint4 pf[PIECES];
@@ -339,7 +332,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     };
     prefetch(blockIdx.x);
     if (tid == 0) misc[1] = 0;                                           // "stripe holds a byte >= 0x80"
-    __syncthreads();
+    lds_barrier();
 
     for (uint32_t chunk = blockIdx.x; chunk < a.n_chunks; chunk += gridDim.x) {
         const uint64_t c0 = (uint64_t)chunk * a.chunk;
@@ -356,7 +349,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         }
         if (hi_bits & 0x80808080u) { a.st->non_ascii = 1; misc[1] = 1; }
         const uint32_t head_byte = pf_head;
-        __syncthreads();
+        lds_barrier();
         const bool ascii = misc[1] == 0;                                 // workgroup-uniform: the cheaper SWAR classes apply
         prefetch(chunk + gridDim.x);
         tick(0);
@@ -376,7 +369,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         uint32_t wA, wB;
         const uint32_t exA = wave_excl_scan(cA, wA), exB = wave_excl_scan(cB, wB);
         if (lane == 0) { misc[8 + wave] = wA; misc[16 + wave] = wB; }
-        __syncthreads();
+        lds_barrier();
         uint32_t baseA = 0, baseB = 0, totA = 0, totB = 0;
 #pragma unroll
         for (uint32_t w = 0; w < NWAVE; ++w) {
@@ -405,7 +398,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 }
             }
             if (tid == 0) wave_lines += n_own;
-            __syncthreads();
+            lds_barrier();
             continue;
         }
 
@@ -433,7 +426,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 OL[j] = (uint16_t)(sb + (uint32_t)__popcll(NL & ((1ull << b) - 1ull)) - 1u);   // 0xFFFF: tail of a line of the previous stripe
             }
         }
-        __syncthreads();
+        lds_barrier();
         tick(2);
 
         // ---- rounds: this wave's share of the stripe's lines -----------------------------------------------
@@ -488,167 +481,153 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 }
             }
             if (status != ST_OK) k = 0;
-            // node slots of the round = the marks of its lines; the round ends in front of the first line that does not fit
-            const unsigned long long over = __ballot(lane < cnt && rel + kall > NMAXW);
-            taken = over ? (uint32_t)__builtin_ctzll(over) : cnt;
-            uint32_t n_nodes;
-            if (taken == 0) { taken = 1; n_nodes = 0; if (lane == 0) { status = ST_DEFER; k = 0; } }   // more marks than a round holds (> KMAX): exact path
-            else n_nodes = (uint32_t)LO[lbase + taken] - obase;
-            if (lane >= taken) { status = ST_NONE; k = 0; }
+            const uint32_t taken_r = cnt;                                // the round takes all its lines; their marks are worked off in passes
+            taken = taken_r;
             if (lane < LRW) l_meta[lane] = rel | (k << 16) | (status << 24);
             wave_sync();
             tick(3);
             if (a.diag & 2u) continue;                                   // measurement only: stop after R1
-            // ---- R3: one node per lane: hash the name, fetch BOTH candidate entries of the two-choice name table at once
-            //      (one round trip for every lane, no probe sequences), compare the spelling --------------------------------
-            for (uint32_t nb = 0; nb < n_nodes; nb += UB3 * 64) {
-                uint32_t nn[UB3], lnv[UB3], d[UB3][8], len[UB3], ori[UB3];
-                uint4 e0[UB3][2], e1[UB3][2], e2[UB3][2];
-                bool live[UB3], probe[UB3];
+            // ---- node passes: up to 64 consecutive marks that cover whole lines; one mark (path node) per lane ----------------
+            for (uint32_t i0 = 0; i0 < cnt;) {
+                const uint32_t p0 = (uint32_t)__shfl((int)rel, (int)i0);
+                const unsigned long long nofit = __ballot(lane >= i0 && lane < cnt && rel + kall - p0 > 64u);
+                uint32_t i1 = nofit ? (uint32_t)__builtin_ctzll(nofit) : cnt;
+                if (i1 == i0) { ++i0; continue; }                        // a line with more than 64 marks (> KMAX): already deferred
+                const uint32_t n_pass = (uint32_t)__shfl((int)(rel + kall), (int)i1 - 1) - p0;
+                const unsigned long long okl = __ballot(lane >= i0 && lane < i1 && status == ST_OK);
+                i0 = i1;
+                if (!okl) continue;                                      // no line of the pass has a path to look at
+                // -- the node of this lane: line, index in the line, name --
+                const bool act = lane < n_pass;
+                const uint32_t o = obase + p0 + lane;
+                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, x = 0, oribit = 0, d[8];
+                uint64_t h = 0;
+                bool live = false, probe = false;
+                if (act) {
+                    ln = (uint32_t)OL[o] - lbase;
+                    const uint32_t meta = l_meta[ln];
+                    live = (meta >> 24) == ST_OK;
+                    lnb = (meta & 0xFFFFu) - p0; lk = (meta >> 16) & 0xFFu; j = lane - lnb;
+                }
+                if (!live) { j = 0; lk = 0; }
+                if (live) {
+                    const uint32_t a0 = (uint32_t)OP[o] + 1u;
+                    const uint32_t b0 = (j + 1 < lk) ? (uint32_t)OP[o + 1] : (uint32_t)l_pend[ln];
+                    oribit = text[a0 - 1] == '<' ? 1u : 0u;
+                    len = b0 - a0;
+                    probe = len - 1u <= 31u;                             // names of 1..32 bytes; longer ones: exact path
+                    if (probe) { h = name_words(text, a0, len, d); x = name_x32(h); }
+                }
+                // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
+                //    the name can be in: 64 bytes with the spelling, id, length and the node's two commonest links --
+                uint32_t dsp = 0;
+                if (probe) dsp = g.name_disp[name_bucket(h, g.name_buckets)];
+                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0xFFFFFFFFu, 0), r2 = make_uint4(0, 0, 0xFFFFFFFFu, 0), r3 = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+                if (probe) {
+                    const uint4 *e = (const uint4 *)(g.name_tab + (size_t)name_slot(h, dsp, g.name_slots) * 16);
+                    r0 = e[0]; r1 = e[1]; r2 = e[2]; r3 = e[3];
+                }
+                uint32_t id = NONE32, lbp = 0;
+                bool row_inline = false;
+                // id << 7 | flags << 5 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
+                if (probe && name_match(r0, r1, r2, d, len) && r1.z != 0xFFFFFFFFu && !(r1.z & 0x60u)) { id = r1.z >> 7; lbp = r1.w & 0x7FFFFFFFu; row_inline = (r1.w >> 31) != 0; }
+                // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact path
+                if (live && (id == NONE32 || lbp >= (1u << 25))) atomicOr(&l_meta[ln], ST_DEFER << 24);   // ST_OK | ST_DEFER == ST_DEFER
+                wave_sync();
+                if (live) live = (l_meta[ln] >> 24) == ST_OK;
+                if (!live) { j = 0; lk = 0; id = NONE32; lbp = 0; }
+                tick(4);
+                // -- running path length (inclusive) by a segmented wave scan, total of the line --
+                uint32_t pre = lbp;
 #pragma unroll
-                for (uint32_t u = 0; u < UB3; ++u) {
-                    nn[u] = nb + u * 64 + lane;
-                    live[u] = false; probe[u] = false; lnv[u] = 0; len[u] = 0; ori[u] = 0;
-                    uint32_t s1 = 0, s2 = 0;
-                    if (nn[u] < n_nodes) {
-                        lnv[u] = (uint32_t)OL[obase + nn[u]] - lbase;
-                        const uint32_t meta = l_meta[lnv[u]];
-                        if ((meta >> 24) == ST_OK) {
-                            live[u] = true;
-                            const uint32_t a0 = (uint32_t)OP[obase + nn[u]] + 1u;
-                            const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
-                            const uint32_t b0 = (nn[u] + 1 < lnb + lk) ? (uint32_t)OP[obase + nn[u] + 1] : (uint32_t)l_pend[lnv[u]];
-                            ori[u] = text[a0 - 1] == '<' ? 0x80000000u : 0u;
-                            len[u] = b0 - a0;
-                            probe[u] = len[u] - 1u <= 31u && !(a.diag & 4u);     // names of 1..32 bytes; longer ones: exact path
-                            if (probe[u]) cuckoo_slots(name_words(text, a0, len[u], d[u]), g.name_seed, g.name_mask, s1, s2);
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t c = 0; c < 2; ++c) {
-                        e0[u][c] = e2[u][c] = make_uint4(0, 0, 0, 0); e1[u][c] = make_uint4(0, 0, 0xFFFFFFFFu, 0);
-                        if (probe[u]) {
-                            const uint4 *e = (const uint4 *)(g.name_tab + (size_t)(c ? s2 : s1) * 16);
-                            e0[u][c] = e[0]; e1[u][c] = e[1];
-                            if (len[u] > 24u) e2[u][c] = e[2];
-                        }
+                for (uint32_t dd = 1; dd < 64; dd <<= 1) {
+                    const uint32_t y = (uint32_t)__shfl_up((int)pre, dd);
+                    if (j >= dd) pre += y;
+                }
+                const uint32_t tot = (uint32_t)__shfl((int)pre, (int)(lane + (lk ? lk - 1 - j : 0u)));
+                // -- first occurrence of every name in its line (the reference's list.index / str.split quirks).  Ids grow along
+                //    a forward path and fall along a reverse one: such lines cannot revisit a node and need no search --
+                uint32_t f = lane;
+                {
+                    const uint32_t prev = (uint32_t)__shfl_up((int)id, 1);
+                    const unsigned long long up = __ballot(live && (j == 0 || id > prev)), dn = __ballot(live && (j == 0 || id < prev));
+                    const unsigned long long lm = (lk >= 64u ? ~0ull : ((1ull << lk) - 1ull)) << (lnb & 63u);
+                    const bool search = live && (up & lm) != lm && (dn & lm) != lm;
+                    for (uint32_t dd = 1; __ballot(search && j >= dd); ++dd) {
+                        const uint32_t y = (uint32_t)__shfl_up((int)id, dd);
+                        if (search && j >= dd && y == id) f = lane - dd;
                     }
                 }
-#pragma unroll
-                for (uint32_t u = 0; u < UB3; ++u) {
-                    if (live[u]) {
-                        uint32_t id = NONE32, lbp = 0;
-                        if (probe[u]) {
-                            const bool m0 = name_match(e0[u][0], e1[u][0], e2[u][0], d[u], len[u]);
-                            const bool m1 = name_match(e0[u][1], e1[u][1], e2[u][1], d[u], len[u]);
-                            const uint32_t mz = m0 ? e1[u][0].z : e1[u][1].z, mw = m0 ? e1[u][0].w : e1[u][1].w;
-                            // id << 7 | flags << 5 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
-                            if ((m0 | m1) && mz != 0xFFFFFFFFu && !(mz & 0x60u)) { id = mz >> 7; lbp = mw; }
-                        }
-                        if (a.diag & 4u) { id = 0; lbp = 100; }
-                        n_id[nn[u]] = id == NONE32 ? NONE32 : (id | ori[u]); n_pre[nn[u]] = lbp;
-                        if (id == NONE32) atomicOr(&l_meta[lnv[u]], ST_DEFER << 24);              // ST_OK | ST_DEFER == ST_DEFER
+                tick(5);
+                // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
+                //    (str.split / list.index, filter-alignments.py:206, :269-271) --
+                const uint32_t fl = f, fr = (uint32_t)__shfl_down((int)f, 1);
+                const uint32_t pre_l = (uint32_t)__shfl((int)pre, (int)fl);
+                const uint32_t pre_rx = (uint32_t)__shfl((int)pre, (int)((fr - 1u) & 63u));
+                const uint32_t idl = (uint32_t)__shfl((int)id, (int)fl), idr = (uint32_t)__shfl((int)id, (int)(fr & 63u));
+                const uint32_t orl = (uint32_t)__shfl((int)oribit, (int)fl), orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
+                bool go = false;
+                uint32_t klo = 0, khi = 0;
+                if (live && j + 1 < lk) {
+                    const long long left = (long long)pre_l - (long long)l_ts[ln];
+                    const long long pre_excl_r = fr > lnb ? (long long)pre_rx : 0;
+                    const long long right = (long long)tot - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
+                    go = left >= (long long)g.d_over && right >= (long long)g.d_over;
+                    klo = (idr << 1) | orr; khi = (idl << 1) | orl;
+                }
+                // the link is looked for among the two that sit in the left node's record; the link table is asked only if it
+                // is not there and the node has more links (or for a revisited node: the link between the first occurrences)
+                uint32_t nh = 0, ea = 0, eb = 0;
+                bool found = false, ask = false;
+                if (go) {
+                    if (fl != lane || fr != lane + 1u) ask = true;
+                    else {
+                        const uint32_t want = (idr << 2) | orl | (orr << 1);
+                        if (r2.z == want) { ea = r2.w; eb = r3.x; found = true; }
+                        else if (r3.y == want) { ea = r3.z; eb = r3.w; found = true; }
+                        else ask = !row_inline;
                     }
                 }
-            }
-            wave_sync();
-            tick(4);
-            if (a.diag & 64u) continue;                                  // measurement only: stop after R3
-            // ---- R4: one line per lane: prefix sums, first occurrences --------------------------------------
-            if (lane < taken) {
-                const uint32_t meta = l_meta[lane];
-                if ((meta >> 24) == ST_OK) {
-                    const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
-                    unsigned long long run = 0, seen1 = 0, seen2 = 0;
-                    for (uint32_t j = 0; j < lk; ++j) {
-                        const uint32_t idj = n_id[lnb + j] & 0x7FFFFFFFu;
-                        run += n_pre[lnb + j];
-                        n_pre[lnb + j] = (uint32_t)run;
-                        uint32_t f = j;
-                        // two-hash filter: only a possible revisit pays for the search of the first occurrence
-                        const unsigned long long b1 = 1ull << (idj & 63), b2 = 1ull << ((idj * 0x9E3779B1u) >> 26);
-                        if ((seen1 & b1) && (seen2 & b2))
-                            for (uint32_t jj = 0; jj < j; ++jj) if ((n_id[lnb + jj] & 0x7FFFFFFFu) == idj) { f = jj; break; }
-                        seen1 |= b1; seen2 |= b2;
-                        n_first[lnb + j] = (uint16_t)(lnb + f);
-                    }
-                    l_tot[lane] = (uint32_t)run;
-                    if (run > 0xFFFFFFFFull) l_meta[lane] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
-                }
-            }
-            wave_sync();
-            tick(5);
-            // ---- R5: one path step per lane; UB5 steps per lane, both candidate link-table entries of every step fetched in one round trip ------------
-            for (uint32_t nb = 0; nb < n_nodes; nb += UB5 * 64) {
-                uint32_t lnv[UB5], klo[UB5], khi[UB5], sa[UB5], sb2[UB5];
-                uint4 ek[UB5], ek2[UB5];
-                bool go[UB5];
-#pragma unroll
-                for (uint32_t u = 0; u < UB5; ++u) {
-                    const uint32_t n = nb + u * 64 + lane;
-                    go[u] = false; lnv[u] = 0; klo[u] = khi[u] = sa[u] = sb2[u] = 0;
-                    if (n + 1 < n_nodes) {
-                        const uint32_t ln = (uint32_t)OL[obase + n] - lbase;
-                        const uint32_t meta = l_meta[ln];
-                        const uint32_t lnb = meta & 0xFFFFu, lk = (meta >> 16) & 0xFFu;
-                        if ((meta >> 24) == ST_OK && n + 1 < lnb + lk) {
-                            // the reference evaluates the link (name, strand) of the FIRST occurrence of each name
-                            // (str.split / list.index, filter-alignments.py:206, :269-271)
-                            const uint32_t fl = n_first[n], fr = n_first[n + 1];
-                            const long long left = (long long)n_pre[fl] - (long long)l_ts[ln];
-                            const long long pre_excl_r = fr > lnb ? (long long)n_pre[fr - 1] : 0;
-                            const long long right = (long long)l_tot[ln] - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
-                            if (left >= (long long)g.d_over && right >= (long long)g.d_over) {
-                                go[u] = true; lnv[u] = ln;
-                                const uint32_t xr = n_id[fr], xl = n_id[fl];             // id | orientation << 31  ->  id << 1 | orientation
-                                klo[u] = (xr << 1) | (xr >> 31);
-                                khi[u] = (xl << 1) | (xl >> 31);
-                                cuckoo_slots(link_prehash(klo[u], khi[u]), g.link_seed, g.link_mask, sa[u], sb2[u]);
-                            }
-                        }
+                if (__ballot(ask)) {
+                    const uint32_t xl = (uint32_t)__shfl((int)x, (int)fl), xr = (uint32_t)__shfl((int)x, (int)(fr & 63u));
+                    if (ask) {
+                        uint32_t sa, sb2;
+                        cuckoo_slots(link_prehash(xl, orl, xr, orr), g.link_seed, g.link_mask, sa, sb2);
+                        uint4 ek = *(const uint4 *)(g.link_tab + (size_t)sa * 4);
+                        const uint4 ek2 = *(const uint4 *)(g.link_tab + (size_t)sb2 * 4);
+                        if (!(ek.x == klo && ek.y == khi)) ek = ek2;                          // the other candidate slot
+                        if (ek.x == klo && ek.y == khi) { ea = ek.z; eb = ek.w; found = true; }
                     }
                 }
-#pragma unroll
-                for (uint32_t u = 0; u < UB5; ++u) {
-                    ek[u] = ek2[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0, 0);
-                    if (go[u]) { ek[u] = *(const uint4 *)(g.link_tab + (size_t)sa[u] * 4); ek2[u] = *(const uint4 *)(g.link_tab + (size_t)sb2[u] * 4); }
+                bool many = false;
+                if (found) {
+                    // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
+                    many = (ea & 0x80000000u) && eb != 0xFFFFFFFFu && ea != 0xFFFFFFFFu;
+                    nh = many ? eb : (eb == 0xFFFFFFFFu ? 1u : 2u);
                 }
-#pragma unroll
-                for (uint32_t u = 0; u < UB5; ++u) {
-                    uint32_t nh = 0, ea = 0, eb = 0;
-                    bool many = false;
-                    if (go[u]) {
-                        if (!(ek[u].x == klo[u] && ek[u].y == khi[u])) ek[u] = ek2[u];                 // the other candidate slot
-                        if (ek[u].x == klo[u] && ek[u].y == khi[u]) {
-                            // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
-                            ea = ek[u].z; eb = ek[u].w;
-                            many = (ea & 0x80000000u) && eb != 0xFFFFFFFFu && ea != 0xFFFFFFFFu;
-                            nh = many ? eb : (eb == 0xFFFFFFFFu ? 1u : 2u);
-                        }
+                // hit records: one aggregated atomic per wave reserves the slots
+                unsigned long long rbase = 0;
+                if (a.want_hits) {
+                    uint32_t wtot2, ex = wave_excl_scan(nh, wtot2);
+                    if (wtot2) {
+                        if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot2);
+                        rbase = __shfl(rbase, 0) + ex;
                     }
-                    // hit records: one aggregated atomic per wave reserves the slots
-                    unsigned long long rbase = 0;
+                }
+                for (uint32_t jj = 0; jj < nh; ++jj) {
+                    const uint32_t hv = many ? g.hits[(ea & 0x7FFFFFFFu) + jj] : (jj == 0 ? ea : eb);
+                    if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
                     if (a.want_hits) {
-                        uint32_t wtot2, ex = wave_excl_scan(nh, wtot2);
-                        if (wtot2) {
-                            if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot2);
-                            rbase = __shfl(rbase, 0) + ex;
-                        }
-                    }
-                    for (uint32_t j = 0; j < nh; ++j) {
-                        const uint32_t hv = many ? g.hits[(ea & 0x7FFFFFFFu) + j] : (j == 0 ? ea : eb);
-                        if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
-                        if (a.want_hits) {
-                            if (rbase + j < a.rec_cap) {
-                                svjg_hitrec r; r.line_start = a.base_offset + c0 + LS[lbase + lnv[u]]; r.slot = hv >> 1;
-                                r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
-                                a.recs[rbase + j] = r;
-                            } else atomicOr(&a.st->overflow, 2u);
-                        }
+                        if (rbase + jj < a.rec_cap) {
+                            svjg_hitrec r; r.line_start = a.base_offset + c0 + LS[lbase + ln]; r.slot = hv >> 1;
+                            r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
+                            a.recs[rbase + jj] = r;
+                        } else atomicOr(&a.st->overflow, 2u);
                     }
                 }
+                tick(6);
             }
-            tick(6);
+            wave_sync();
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
                 const bool defer = lane < taken && (l_meta[lane] >> 24) == ST_DEFER;
@@ -668,12 +647,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             wave_sync();                                                 // round state is reused
         }
         wave_lines += l_hi - l_lo;
-        __syncthreads();                                                 // text, bitmap and lists are overwritten by the next stripe
+        lds_barrier();                                                 // text, bitmap and lists are overwritten by the next stripe
         tick(7);
     }
     if (lane == 0 && wave_lines) atomicAdd(&a.st->n_lines, wave_lines);
-    if (timing && lane == 0)
+#ifdef SVJG_TIMING
+    if ((a.diag & 16u) && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc[i]);
+#endif
 }
 
 struct SlowEmit {

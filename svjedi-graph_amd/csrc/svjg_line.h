@@ -36,13 +36,32 @@ struct GraphView {
     uint32_t n_chrom;
     uint32_t hash_mask;
     uint32_t d_over;
-    const uint32_t *name_tab;    // main kernel: canonical node name -> node (svjg_host_tables.h), 16 words per entry
-    uint32_t name_mask, name_seed;
+    const uint32_t *name_tab;    // canonical node name -> node record (svjg_host_tables.h), 16 words (one 64-byte line) per slot
+    const uint16_t *name_disp;   // perfect hash of the node names: displacement of every bucket
+    uint32_t name_slots, name_buckets;
     uint32_t name_complete;      // every node name is in name_tab: a miss there means "no such node" (else: search the sorted table)
     const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 4 words per entry
     uint32_t link_mask, link_seed;
 };
 
+
+// ---- perfect hash of the node names (hash and displace; built by svjg_host_tables.h) -------------------------------
+// pre-hash = 64-bit multilinear sum of the name's eight zero-padded words and its length; bucket from the pre-hash,
+// slot from the pre-hash and the bucket's displacement: every name of the graph has a slot of its own, so a lookup
+// touches one 2-byte displacement (a small, cache-resident array) and exactly ONE 64-byte record.
+SVJG_HD uint32_t fmix32(uint32_t z) { z ^= z >> 16; z *= 0x7FEB352Du; z ^= z >> 15; z *= 0x846CA68Bu; z ^= z >> 16; return z; }
+SVJG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+SVJG_HD uint64_t name_prehash(const uint32_t d[8], uint32_t len) {
+    const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+    uint64_t h = (uint64_t)len * 0x7FEB352Du;
+    for (int i = 0; i < 8; ++i) h += (uint64_t)d[i] * C[i];
+    return h;
+}
+SVJG_HD uint32_t name_bucket(uint64_t h, uint32_t n_buckets) { return mulhi32(fmix32((uint32_t)(h >> 32) ^ ((uint32_t)h * 0x85EBCA77u)), n_buckets); }
+SVJG_HD uint32_t name_slot(uint64_t h, uint32_t disp, uint32_t n_slots) {
+    return mulhi32(fmix32(((uint32_t)h ^ ((uint32_t)(h >> 32) * 0x9E3779B1u)) + disp * 0x632BE5ABu), n_slots);
+}
+SVJG_HD uint32_t name_x32(uint64_t h) { return (uint32_t)h ^ (uint32_t)(h >> 32); }    // 32-bit digest used to hash links by their two names
 
 SVJG_HD bool py_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 
@@ -188,29 +207,20 @@ SVJG_HD bool next_node(P t, uint64_t pe, bool oriented, uint64_t &pos, NameRef &
     return false;
 }
 
-// Two-choice node-name table of the main kernel (svjg_host_tables.h), probed with the raw bytes of a name of 1..32 bytes:
-// node id, or NONE32 when neither candidate slot holds this spelling.
+// Node-name table of the main kernel (svjg_host_tables.h), probed with the raw bytes of a name of 1..32 bytes:
+// node id, or NONE32 when the name's slot does not hold this spelling.
 template <class P>
 SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
     const uint32_t len = (uint32_t)(nm.e - nm.s);
     uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t b = 0; b < len; ++b) d[b >> 2] |= (uint32_t)(uint8_t)t[nm.s + b] << (8 * (b & 3));
-    const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
-    uint32_t x = len * 0x7FEB352Du;
-    for (int i = 0; i < 8; ++i) x += d[i] * C[i];
-    uint32_t p = x ^ g.name_seed;
-    p ^= p >> 15; p *= 0x2C1B3C6Du; p ^= p >> 12;
-    uint32_t q = (x + g.name_seed) * 0x85EBCA6Bu;
-    q ^= q >> 13; q *= 0xC2B2AE35u; q ^= q >> 16;
-    uint32_t s1 = p & g.name_mask, s2 = q & g.name_mask;
-    if (s2 == s1) s2 = s1 ^ 1u;
-    for (int c = 0; c < 2; ++c) {
-        const uint32_t *e = g.name_tab + (uint64_t)(c ? s2 : s1) * 16;
-        const uint32_t meta = e[6];
-        if (meta == 0xFFFFFFFFu || (meta & 31u) != len - 1u) continue;
-        if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && e[8] == d[6] && e[9] == d[7])
-            return meta >> 7;
-    }
+    const uint64_t h = name_prehash(d, len);
+    const uint32_t slot = name_slot(h, g.name_disp[name_bucket(h, g.name_buckets)], g.name_slots);
+    const uint32_t *e = g.name_tab + (uint64_t)slot * 16;
+    const uint32_t meta = e[6];
+    if (meta == 0xFFFFFFFFu || (meta & 31u) != len - 1u) return NONE32;
+    if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && e[8] == d[6] && e[9] == d[7])
+        return meta >> 7;
     return NONE32;
 }
 

@@ -20,9 +20,9 @@ static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &has
     v.nodes = g->nodes; v.n_nodes = (uint32_t)g->n_nodes; v.edges = g->edges; v.hits = g->hits;
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
-    v.name_tab = nullptr; v.name_mask = 0; v.name_seed = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
+    v.name_tab = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
     if (kt) {                                                             // the exact path resolves names through the node-name table
-        v.name_tab = kt->names.data(); v.name_mask = kt->name_mask; v.name_seed = kt->name_seed;
+        v.name_tab = kt->names.data(); v.name_disp = kt->disp.data(); v.name_slots = kt->name_slots; v.name_buckets = kt->name_buckets;
         v.name_complete = (kt->names_left_out == 0 && kt->names_skipped == 0) ? 1u : 0u;
     }
     return v;
@@ -55,18 +55,39 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
 extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
     KernelTables kt = build_kernel_tables(*g);
     uint64_t bad = kt.names_left_out + kt.links_left_out, found = 0;
-    for (uint64_t j = 0; j <= kt.name_mask; ++j) {
+    for (uint64_t j = 0; j < kt.name_slots; ++j) {
         const uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
-        if (name_ent_empty(e)) continue;
+        if (name_ent_empty(e)) { if (e[10] != REC_NO_LINK || e[13] != REC_NO_LINK) ++bad; continue; }
         ++found;
-        uint32_t d[8], s1, s2;
+        uint32_t d[8];
         name_ent_words(e, d);
-        cuckoo_slots_host(name_prehash_host(d, name_ent_len(e)), kt.name_seed, kt.name_mask, s1, s2);
-        if (j != s1 && j != s2) ++bad;                                   // reachable by the kernel's two probes
-        const svjg_node &nd = g->nodes[name_ent_id(e)];
+        const uint64_t h = name_prehash(d, name_ent_len(e));
+        if (j != name_slot(h, kt.disp[name_bucket(h, kt.name_buckets)], kt.name_slots)) ++bad;   // the kernel's one probe lands here
+        const uint32_t id = name_ent_id(e);
+        if (!kt.node_has[id] || kt.node_slot[id] != j || kt.node_pre[id] != name_x32(h)) ++bad;
+        const svjg_node &nd = g->nodes[id];
         uint32_t kind = (uint32_t)(nd.key >> 15) & 1u, pos = (uint32_t)(nd.key >> 16);
-        if (e[7] != (kind ? nd.aux : nd.aux - pos + 1)) ++bad;
+        if ((e[7] & ~REC_ROW_INLINE) != (kind ? nd.aux : nd.aux - pos + 1) && !(e[6] & 0x40u)) ++bad;
         for (uint32_t b = name_ent_len(e); b < 32; ++b) if ((d[b >> 2] >> (8 * (b & 3))) & 0xFFu) ++bad;     // zero padded
+        // inline links = rows of this node, with the hits of the CSR row; REC_ROW_INLINE only if no row is missing
+        const uint32_t ra = nd.row & 0x7FFFFFFFu, rb = g->nodes[id + 1].row & 0x7FFFFFFFu;
+        uint32_t live = 0, inl = 0;
+        for (uint32_t i = ra; i < rb; ++i) live += (g->edges[i].meta >> 2) != 0;
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t *l = e + 10 + 3 * q;
+            if (l[0] == REC_NO_LINK) continue;
+            ++inl;
+            bool ok = false;
+            for (uint32_t i = ra; i < rb; ++i) {
+                const svjg_edge &ed = g->edges[i];
+                if (((ed.right << 2) | (ed.meta & 3u)) != l[0]) continue;
+                const uint32_t nh = ed.meta >> 2;
+                ok = nh == 1 ? (l[1] == ed.h0 && l[2] == LINK_NO_HIT) : nh == 2 ? (l[1] == ed.h0 && l[2] == ed.h1) : (l[1] == (LINK_MANY | ed.h0) && l[2] == nh);
+            }
+            if (!ok) ++bad;
+        }
+        if (e[10] != REC_NO_LINK && e[10] == e[13]) ++bad;
+        if ((e[7] & REC_ROW_INLINE) && inl != live) ++bad;
     }
     if (found > g->n_nodes) ++bad;
     uint64_t n_links = 0;
@@ -75,7 +96,8 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
             const svjg_edge &ed = g->edges[i];
             uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
             uint32_t s1, s2;
-            cuckoo_slots_host(link_prehash_host(key), kt.link_seed, kt.link_mask, s1, s2);
+            if (!kt.node_has[n] || !kt.node_has[ed.right]) continue;          // such lines take the exact path
+            cuckoo_slots_host(link_prehash_host(kt.node_pre[n], ed.meta & 1u, kt.node_pre[ed.right], (ed.meta >> 1) & 1u), kt.link_seed, kt.link_mask, s1, s2);
             const uint32_t *e = &kt.links[(uint64_t)s1 * LINK_ENT_WORDS];
             if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) e = &kt.links[(uint64_t)s2 * LINK_ENT_WORDS];
             if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) { ++bad; continue; }
