@@ -14,7 +14,10 @@
 
 namespace svjg {
 
-constexpr uint32_t WG = 512;                      // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS-bound) = 16 waves / CU
+#ifndef SVJG_WG
+#define SVJG_WG 512
+#endif
+constexpr uint32_t WG = SVJG_WG;                 // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS / register bound) = 16 waves / CU
 constexpr uint32_t NWAVE = WG / 64;
 constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
 constexpr uint32_t PIECES = 4;                   // 16-byte pieces of text per lane and stripe
@@ -24,11 +27,11 @@ constexpr uint32_t TEXT = SPAN * WG;             // 32 KB staged in LDS
 // starting near its end be complete.  The look-ahead is a launch parameter (ClassifyArgs::chunk = TEXT - look-ahead): the
 // host starts at LOOK_MIN and doubles it, up to LOOK_MAX, when a batch had many lines cut off by the staged text (they
 // go to the exact path, which is correct but slow), so short-line files do not pay for long-line ones.
-constexpr uint32_t LOOK_MIN = 2048, LOOK_MAX = 16384;
+constexpr uint32_t LOOK_MIN = 1024, LOOK_MAX = 16384;
 // Phase B turns the staged text into rank-indexed lists (all positions are offsets into the staged text):
-constexpr uint32_t MAXL = 512;                   // line starts per stripe (a stripe with more goes to the exact path as a whole)
-constexpr uint32_t CAP_T = 4096;                 // tab positions per stripe
-constexpr uint32_t CAP_O = 2048;                 // orientation marks ('<' '>') per stripe
+constexpr uint32_t MAXL = TEXT / 64;                 // line starts per stripe (a stripe with more goes to the exact path as a whole)
+constexpr uint32_t CAP_T = TEXT / 8;                // tab positions per stripe
+constexpr uint32_t CAP_O = TEXT / 16;               // orientation marks ('<' '>') per stripe
 constexpr uint32_t KMAX = 64;                    // path nodes per alignment handled by the main kernel: one wave pass (longer paths: exact path)
 #ifndef SVJG_LRW
 #define SVJG_LRW 32
@@ -438,6 +441,8 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             // ---- R1: one line per lane --------------------------------------------------------------
             uint32_t status = ST_NONE, k = 0, s = 0, rel = 0, kall = 0;
             bool cut = false;                                            // the line runs past the staged text
+            uint32_t li = lane;                                          // index into the round arrays; opaque to the compiler so that the
+            asm volatile("" : "+v"(li));                                 // addresses are recomputed here instead of being kept (and spilled) across the stripe loop
             if (lane < cnt) {
                 const uint32_t L = lbase + lane;
                 s = LS[L];
@@ -472,10 +477,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (ok) ok = (uint32_t)OP[o0] == t4 + 1 && (uint32_t)OP[o0 + k - 1] < t5;
                         if (ok) {
                             status = k >= 2 ? ST_OK : ST_NOHIT;
-                            l_tlen[lane] = field_val(text, t5 + 1, t6 - t5 - 1);
-                            l_ts[lane] = field_val(text, t6 + 1, t7 - t6 - 1);
-                            l_te[lane] = field_val(text, t7 + 1, t8 - t7 - 1);
-                            l_pend[lane] = (uint16_t)t5;
+                            l_tlen[li] = field_val(text, t5 + 1, t6 - t5 - 1);
+                            l_ts[li] = field_val(text, t6 + 1, t7 - t6 - 1);
+                            l_te[li] = field_val(text, t7 + 1, t8 - t7 - 1);
+                            l_pend[li] = (uint16_t)t5;
                         }
                     }
                 }
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             if (status != ST_OK) k = 0;
             const uint32_t taken_r = cnt;                                // the round takes all its lines; their marks are worked off in passes
             taken = taken_r;
-            if (lane < LRW) l_meta[lane] = rel | (k << 16) | (status << 24);
+            if (lane < LRW) l_meta[li] = rel | (k << 16) | (status << 24);
             wave_sync();
             tick(3);
             if (a.diag & 2u) continue;                                   // measurement only: stop after R1
@@ -630,7 +635,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             wave_sync();
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
-                const bool defer = lane < taken && (l_meta[lane] >> 24) == ST_DEFER;
+                uint32_t lr = lane;
+                asm volatile("" : "+v"(lr));
+                const bool defer = lane < taken && (l_meta[lr] >> 24) == ST_DEFER;
                 const unsigned long long cb = __ballot(cut && lane < taken);
                 if (cb && lane == 0) atomicAdd(&a.st->n_incomplete, (unsigned long long)__popcll(cb));
                 unsigned long long db = __ballot(defer);
