@@ -117,15 +117,21 @@ template <bool ASCII> __device__ inline bool any_byte_t(uint4 v, uint32_t pat) {
     return (zero_bytes(v.x ^ pat) | zero_bytes(v.y ^ pat) | zero_bytes(v.z ^ pat) | zero_bytes(v.w ^ pat)) != 0;
 }
 
-__device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
-    uint32_t lane = __lane_id();
+// Wave prefix sums without LDS traffic: DPP row shifts inside the four rows of 16 lanes, then the row totals are
+// broadcast into the following rows (row_bcast:15 / row_bcast:31), six VALU operations in all.
+__device__ inline uint32_t wave_incl_scan(uint32_t v) {
     uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    total = __shfl(x, 63);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);     // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);     // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);     // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);     // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
+    const uint32_t x = wave_incl_scan(v);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
     return x - v;
 }
 
@@ -542,14 +548,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 if (live) live = (l_meta[ln] >> 24) == ST_OK;
                 if (!live) { j = 0; lk = 0; id = NONE32; lbp = 0; }
                 tick(4);
-                // -- running path length (inclusive) by a segmented wave scan, total of the line --
-                uint32_t pre = lbp;
-#pragma unroll
-                for (uint32_t dd = 1; dd < 64; dd <<= 1) {
-                    const uint32_t y = (uint32_t)__shfl_up((int)pre, dd);
-                    if (j >= dd) pre += y;
-                }
-                const uint32_t tot = (uint32_t)__shfl((int)pre, (int)(lane + (lk ? lk - 1 - j : 0u)));
+                // -- running path length of the line (inclusive) = wave prefix sum minus what precedes the line's first node --
+                const uint32_t gsum = wave_incl_scan(lbp);               // every lbp < 2^25: no overflow over 64 lanes
+                const uint32_t gfirst = (uint32_t)__shfl((int)(gsum - lbp), (int)lnb);
+                const uint32_t glast = (uint32_t)__shfl((int)gsum, (int)(lane + (lk ? lk - 1 - j : 0u)));
+                const uint32_t pre = gsum - gfirst, tot = glast - gfirst;
                 // -- first occurrence of every name in its line (the reference's list.index / str.split quirks).  Ids grow along
                 //    a forward path and fall along a reverse one: such lines cannot revisit a node and need no search --
                 uint32_t f = lane;
@@ -558,9 +561,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const unsigned long long up = __ballot(live && (j == 0 || id > prev)), dn = __ballot(live && (j == 0 || id < prev));
                     const unsigned long long lm = (lk >= 64u ? ~0ull : ((1ull << lk) - 1ull)) << (lnb & 63u);
                     const bool search = live && (up & lm) != lm && (dn & lm) != lm;
-                    for (uint32_t dd = 1; __ballot(search && j >= dd); ++dd) {
-                        const uint32_t y = (uint32_t)__shfl_up((int)id, dd);
-                        if (search && j >= dd && y == id) f = lane - dd;
+                    for (uint32_t dd = 1; __ballot(search && j >= dd); dd += 4) {       // four distances per trip: one wait for four shuffles
+                        const uint32_t y0 = (uint32_t)__shfl_up((int)id, dd), y1 = (uint32_t)__shfl_up((int)id, dd + 1);
+                        const uint32_t y2 = (uint32_t)__shfl_up((int)id, dd + 2), y3 = (uint32_t)__shfl_up((int)id, dd + 3);
+                        if (search && j >= dd && y0 == id) f = lane - dd;
+                        if (search && j >= dd + 1 && y1 == id) f = lane - dd - 1;
+                        if (search && j >= dd + 2 && y2 == id) f = lane - dd - 2;
+                        if (search && j >= dd + 3 && y3 == id) f = lane - dd - 3;
                     }
                 }
                 tick(5);
