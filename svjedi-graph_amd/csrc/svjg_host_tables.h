@@ -47,10 +47,12 @@ namespace svjg {
 //   record = 16 words (one 64-byte line):
 //     [0..5] name bytes 0..23   [6] node id << 7 | flags << 5 | (byte length - 1)   (flags: bit 0 hazard-prone name,
 //     bit 1 length unknown; all ones = empty slot)   [7] node length in bp | REC_ROW_INLINE if the node has no other links
-//     than the inline ones   [8..9] name bytes 24..31
-//     [10..12], [13..15] two of the node's links, reference-allele links first: key = right id << 2 | left strand |
-//     right strand << 1 (all ones = none), then the two hit words of a link-table entry.  Most path steps are answered
-//     from the record that the node lookup fetched anyway and never touch the link table.
+//     than the inline ones
+//     names of up to 24 bytes: [8..15] = four inline links;  longer names: [8..9] = name bytes 24..31, [10..15] = three
+//     inline links.  An inline link = two words: key = right id << 2 | left strand | right strand << 1 (all ones = none),
+//     value = the hit (slot << 1 | allele) of a one-hit link, or REC_MANY | index into the inline hit list
+//     (ihits[index] = number of hits, then the hits).  Reference-allele links come first.  Nearly every path step is
+//     answered from the record that the node lookup fetched anyway and never touches the link table.
 // LINK TABLE: (left id, left strand, right id, right strand) -> hits, same content as the CSR rows; two-choice (cuckoo)
 // table: every key sits in one of its TWO candidate slots.  The SLOT of a link is hashed from the name digests of its two
 // nodes and the strands (name_x32), not from the ids.
@@ -61,11 +63,13 @@ namespace svjg {
 constexpr uint32_t NAME_ENT_WORDS = 16, LINK_ENT_WORDS = 4;
 constexpr uint32_t LINK_NO_HIT = 0xFFFFFFFFu, LINK_MANY = 0x80000000u;
 constexpr uint32_t NAME_EMPTY = 0xFFFFFFFFu, NAME_MAX_ID = (1u << 25) - 2u;
-constexpr uint32_t REC_ROW_INLINE = 0x80000000u, REC_NO_LINK = 0xFFFFFFFFu;
+constexpr uint32_t REC_ROW_INLINE = 0x80000000u, REC_NO_LINK = 0xFFFFFFFFu, REC_MANY = 0x80000000u;
 inline bool name_ent_empty(const uint32_t *e) { return e[6] == NAME_EMPTY; }
 inline uint32_t name_ent_len(const uint32_t *e) { return (e[6] & 31u) + 1u; }
 inline uint32_t name_ent_id(const uint32_t *e) { return e[6] >> 7; }
-inline void name_ent_words(const uint32_t *e, uint32_t d[8]) { for (int w = 0; w < 6; ++w) d[w] = e[w]; d[6] = e[8]; d[7] = e[9]; }
+inline void name_ent_words(const uint32_t *e, uint32_t d[8]) { for (int w = 0; w < 6; ++w) d[w] = e[w]; const bool lg = name_ent_len(e) > 24u; d[6] = lg ? e[8] : 0u; d[7] = lg ? e[9] : 0u; }
+inline bool nm_len_gt24(uint32_t meta) { return (meta & 31u) + 1u > 24u; }
+inline uint32_t rec_first_link(const uint32_t *e) { return name_ent_len(e) > 24u ? 10u : 8u; }   // word of the first inline link
 
 // xl, xr = name digests (name_x32) of the left / right node, sl, sr = strands (1 = '-')
 inline uint32_t link_prehash_host(uint32_t xl, uint32_t sl, uint32_t xr, uint32_t sr) {
@@ -84,6 +88,7 @@ inline void cuckoo_slots_host(uint32_t x, uint32_t seed, uint32_t mask, uint32_t
 struct KernelTables {
     std::vector<uint32_t> names; uint32_t name_slots = 0, name_buckets = 0;
     std::vector<uint16_t> disp;                               // displacement of every bucket of the name hash
+    std::vector<uint32_t> ihits;                              // hit lists of inline links with more than one hit: count, hits...
     std::vector<uint32_t> links; uint32_t link_mask = 0, link_seed = 0;
     uint64_t names_left_out = 0, links_left_out = 0;
     uint32_t names_skipped = 0;                               // node names the table cannot hold (> 32 bytes, id too large)
@@ -213,13 +218,14 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
         kt.names.assign((size_t)kt.name_slots * NAME_ENT_WORDS, 0);
         for (uint64_t j = 0; j < kt.name_slots; ++j) {
             uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
-            e[6] = NAME_EMPTY; e[10] = e[13] = REC_NO_LINK;
+            e[6] = NAME_EMPTY; e[8] = e[10] = e[12] = e[14] = REC_NO_LINK;
         }
         for (uint64_t k = 0; k < hs.size(); ++k) {
             const uint32_t *src = &ent[(size_t)k * 10];
             uint32_t *e = &kt.names[(size_t)slot_of[k] * NAME_ENT_WORDS];
             for (int w = 0; w < 6; ++w) e[w] = src[w];
-            e[6] = src[8]; e[7] = src[9]; e[8] = src[6]; e[9] = src[7];
+            e[6] = src[8]; e[7] = src[9];
+            if (nm_len_gt24(src[8])) { e[8] = src[6]; e[9] = src[7]; }
             const uint32_t node = key_node[k];
             node_pre[node] = name_x32(hs[k]); node_has[node] = 1; node_slot[node] = slot_of[k];
             // inline links: up to two rows of the node, those whose hits are all reference-allele first
@@ -236,16 +242,21 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
                 }
             uint32_t n_live = 0;
             for (uint32_t i = a; i < b; ++i) n_live += (g.edges[i].meta >> 2) != 0;
-            for (size_t q = 0; q < rows.size() && q < 2; ++q) {
+            const uint32_t w0 = nm_len_gt24(src[8]) ? 10u : 8u, cap = (16u - w0) / 2u;
+            for (uint32_t w = w0; w < 16; w += 2) e[w] = REC_NO_LINK, e[w + 1] = 0;
+            for (size_t q = 0; q < rows.size() && q < cap; ++q) {
                 const svjg_edge &ed = g.edges[rows[q]];
                 const uint32_t nh = ed.meta >> 2;
-                uint32_t *l = e + 10 + 3 * q;
+                uint32_t *l = e + w0 + 2 * q;
                 l[0] = (ed.right << 2) | (ed.meta & 3u);
-                if (nh == 1) { l[1] = ed.h0; l[2] = LINK_NO_HIT; }
-                else if (nh == 2) { l[1] = ed.h0; l[2] = ed.h1; }
-                else { l[1] = LINK_MANY | ed.h0; l[2] = nh; }
+                if (nh == 1) l[1] = ed.h0;
+                else {
+                    l[1] = REC_MANY | (uint32_t)kt.ihits.size();
+                    kt.ihits.push_back(nh);
+                    for (uint32_t j = 0; j < nh; ++j) kt.ihits.push_back(nh <= 2 ? (j ? ed.h1 : ed.h0) : g.hits[ed.h0 + j]);
+                }
             }
-            if (n_live <= 2 && rows.size() == n_live) e[7] |= REC_ROW_INLINE;
+            if (n_live <= cap && rows.size() == n_live) e[7] |= REC_ROW_INLINE;
         }
     }
     // a link that cannot be placed would be a silent miss in the kernel: grow the table until every link sits in one of its

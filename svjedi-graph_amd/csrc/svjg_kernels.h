@@ -533,7 +533,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's two commonest links --
                 uint32_t dsp = 0;
                 if (probe) dsp = g.name_disp[name_bucket(h, g.name_buckets)];
-                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0xFFFFFFFFu, 0), r2 = make_uint4(0, 0, 0xFFFFFFFFu, 0), r3 = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0xFFFFFFFFu, 0), r2 = make_uint4(0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0), r3 = make_uint4(0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0);
                 if (probe) {
                     const uint4 *e = (const uint4 *)(g.name_tab + (size_t)name_slot(h, dsp, g.name_slots) * 16);
                     r0 = e[0]; r1 = e[1]; r2 = e[2]; r3 = e[3];
@@ -587,17 +587,25 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     go = left >= (long long)g.d_over && right >= (long long)g.d_over;
                     klo = (idr << 1) | orr; khi = (idl << 1) | orl;
                 }
-                // the link is looked for among the two that sit in the left node's record; the link table is asked only if it
-                // is not there and the node has more links (or for a revisited node: the link between the first occurrences)
-                uint32_t nh = 0, ea = 0, eb = 0;
-                bool found = false, ask = false;
+                // the link is looked for among the (up to four) that sit in the left node's record; the link table is asked only
+                // if it is not there and the node has more links (or for a revisited node: the link between the first occurrences)
+                uint32_t nh = 0, h0 = 0, h1 = 0;
+                const uint32_t *hp = nullptr;                             // more than two hits: the list
+                bool ask = false;
                 if (go) {
                     if (fl != lane || fr != lane + 1u) ask = true;
                     else {
                         const uint32_t want = (idr << 2) | orl | (orr << 1);
-                        if (r2.z == want) { ea = r2.w; eb = r3.x; found = true; }
-                        else if (r3.y == want) { ea = r3.z; eb = r3.w; found = true; }
-                        else ask = !row_inline;
+                        uint32_t v = 0; bool found = true;
+                        if (len <= 24u && r2.x == want) v = r2.y;
+                        else if (r2.z == want) v = r2.w;
+                        else if (r3.x == want) v = r3.y;
+                        else if (r3.z == want) v = r3.w;
+                        else { found = false; ask = !row_inline; }
+                        if (found) {
+                            if (v & 0x80000000u) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1]; }
+                            else { nh = 1; h0 = v; }
+                        }
                     }
                 }
                 if (__ballot(ask)) {
@@ -608,14 +616,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         uint4 ek = *(const uint4 *)(g.link_tab + (size_t)sa * 4);
                         const uint4 ek2 = *(const uint4 *)(g.link_tab + (size_t)sb2 * 4);
                         if (!(ek.x == klo && ek.y == khi)) ek = ek2;                          // the other candidate slot
-                        if (ek.x == klo && ek.y == khi) { ea = ek.z; eb = ek.w; found = true; }
+                        if (ek.x == klo && ek.y == khi) {
+                            // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
+                            if ((ek.z & 0x80000000u) && ek.w != 0xFFFFFFFFu && ek.z != 0xFFFFFFFFu) { hp = g.hits + (ek.z & 0x7FFFFFFFu); nh = ek.w; }
+                            else { h0 = ek.z; h1 = ek.w; nh = ek.w == 0xFFFFFFFFu ? 1u : 2u; }
+                        }
                     }
-                }
-                bool many = false;
-                if (found) {
-                    // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
-                    many = (ea & 0x80000000u) && eb != 0xFFFFFFFFu && ea != 0xFFFFFFFFu;
-                    nh = many ? eb : (eb == 0xFFFFFFFFu ? 1u : 2u);
                 }
                 // hit records: one aggregated atomic per wave reserves the slots
                 unsigned long long rbase = 0;
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
                 for (uint32_t jj = 0; jj < nh; ++jj) {
-                    const uint32_t hv = many ? g.hits[(ea & 0x7FFFFFFFu) + jj] : (jj == 0 ? ea : eb);
+                    const uint32_t hv = hp ? hp[jj] : (jj == 0 ? h0 : h1);
                     if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
                     if (a.want_hits) {
                         if (rbase + jj < a.rec_cap) {

@@ -36,6 +36,7 @@ struct GraphView {
     uint32_t n_chrom;
     uint32_t hash_mask;
     uint32_t d_over;
+    const uint32_t *name_ihits;  // hit lists of the records' inline links with more than one hit
     const uint32_t *name_tab;    // canonical node name -> node record (svjg_host_tables.h), 16 words (one 64-byte line) per slot
     const uint16_t *name_disp;   // perfect hash of the node names: displacement of every bucket
     uint32_t name_slots, name_buckets;
@@ -219,7 +220,7 @@ SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
     const uint32_t *e = g.name_tab + (uint64_t)slot * 16;
     const uint32_t meta = e[6];
     if (meta == 0xFFFFFFFFu || (meta & 31u) != len - 1u) return NONE32;
-    if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && e[8] == d[6] && e[9] == d[7])
+    if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && (len <= 24u || (e[8] == d[6] && e[9] == d[7])))
         return meta >> 7;
     return NONE32;
 }

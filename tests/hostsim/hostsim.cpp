@@ -20,9 +20,9 @@ static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &has
     v.nodes = g->nodes; v.n_nodes = (uint32_t)g->n_nodes; v.edges = g->edges; v.hits = g->hits;
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
-    v.name_tab = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
+    v.name_tab = nullptr; v.name_ihits = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
     if (kt) {                                                             // the exact path resolves names through the node-name table
-        v.name_tab = kt->names.data(); v.name_disp = kt->disp.data(); v.name_slots = kt->name_slots; v.name_buckets = kt->name_buckets;
+        v.name_tab = kt->names.data(); v.name_ihits = kt->ihits.data(); v.name_disp = kt->disp.data(); v.name_slots = kt->name_slots; v.name_buckets = kt->name_buckets;
         v.name_complete = (kt->names_left_out == 0 && kt->names_skipped == 0) ? 1u : 0u;
     }
     return v;
@@ -57,7 +57,7 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
     uint64_t bad = kt.names_left_out + kt.links_left_out, found = 0;
     for (uint64_t j = 0; j < kt.name_slots; ++j) {
         const uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
-        if (name_ent_empty(e)) { if (e[10] != REC_NO_LINK || e[13] != REC_NO_LINK) ++bad; continue; }
+        if (name_ent_empty(e)) { if (e[8] != REC_NO_LINK || e[10] != REC_NO_LINK || e[12] != REC_NO_LINK || e[14] != REC_NO_LINK) ++bad; continue; }
         ++found;
         uint32_t d[8];
         name_ent_words(e, d);
@@ -73,8 +73,8 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
         const uint32_t ra = nd.row & 0x7FFFFFFFu, rb = g->nodes[id + 1].row & 0x7FFFFFFFu;
         uint32_t live = 0, inl = 0;
         for (uint32_t i = ra; i < rb; ++i) live += (g->edges[i].meta >> 2) != 0;
-        for (int q = 0; q < 2; ++q) {
-            const uint32_t *l = e + 10 + 3 * q;
+        for (uint32_t w = rec_first_link(e); w < 16; w += 2) {
+            const uint32_t *l = e + w;
             if (l[0] == REC_NO_LINK) continue;
             ++inl;
             bool ok = false;
@@ -82,11 +82,16 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
                 const svjg_edge &ed = g->edges[i];
                 if (((ed.right << 2) | (ed.meta & 3u)) != l[0]) continue;
                 const uint32_t nh = ed.meta >> 2;
-                ok = nh == 1 ? (l[1] == ed.h0 && l[2] == LINK_NO_HIT) : nh == 2 ? (l[1] == ed.h0 && l[2] == ed.h1) : (l[1] == (LINK_MANY | ed.h0) && l[2] == nh);
+                if (nh == 1) ok = l[1] == ed.h0;
+                else if (l[1] & REC_MANY) {
+                    const uint32_t *hp = &kt.ihits[l[1] & ~REC_MANY];
+                    ok = hp[0] == nh;
+                    for (uint32_t q = 0; q < nh && ok; ++q) ok = hp[1 + q] == (nh <= 2 ? (q ? ed.h1 : ed.h0) : g->hits[ed.h0 + q]);
+                }
             }
             if (!ok) ++bad;
+            for (uint32_t w2 = rec_first_link(e); w2 < w; w2 += 2) if (e[w2] == l[0]) ++bad;     // no key twice
         }
-        if (e[10] != REC_NO_LINK && e[10] == e[13]) ++bad;
         if ((e[7] & REC_ROW_INLINE) && inl != live) ++bad;
     }
     if (found > g->n_nodes) ++bad;
