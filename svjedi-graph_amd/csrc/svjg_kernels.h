@@ -511,24 +511,27 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // -- the node of this lane: line, index in the line, name --
                 const bool act = lane < n_pass;
                 const uint32_t o = obase + p0 + lane;
-                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, x = 0, oribit = 0, d[8];
+                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, x = 0, oribit = 0, meta = 0, d[8];
                 uint64_t h = 0;
                 bool live = false, probe = false;
                 if (act) {
+                    const uint32_t opv = OP[o], opn = OP[o + 1];        // (independent of the line: one LDS round trip with OL)
                     ln = (uint32_t)OL[o] - lbase;
-                    const uint32_t meta = l_meta[ln];
+                    meta = l_meta[ln];
+                    const uint32_t pend = l_pend[ln];
                     live = (meta >> 24) == ST_OK;
                     lnb = (meta & 0xFFFFu) - p0; lk = (meta >> 16) & 0xFFu; j = lane - lnb;
+                    if (live) {
+                        const uint32_t a0 = opv + 1u;
+                        const uint32_t b0 = (j + 1 < lk) ? opn : pend;
+                        oribit = text[a0 - 1] == '<' ? 1u : 0u;
+                        len = b0 - a0;
+                        probe = len - 1u <= 31u;                         // names of 1..32 bytes; longer ones: exact path
+                        if (probe) { h = name_words(text, a0, len, d); x = name_x32(h); }
+                    }
                 }
-                if (!live) { j = 0; lk = 0; }
-                if (live) {
-                    const uint32_t a0 = (uint32_t)OP[o] + 1u;
-                    const uint32_t b0 = (j + 1 < lk) ? (uint32_t)OP[o + 1] : (uint32_t)l_pend[ln];
-                    oribit = text[a0 - 1] == '<' ? 1u : 0u;
-                    len = b0 - a0;
-                    probe = len - 1u <= 31u;                             // names of 1..32 bytes; longer ones: exact path
-                    if (probe) { h = name_words(text, a0, len, d); x = name_x32(h); }
-                }
+                if (!live) { j = 0; lk = 0; lnb = 0; }
+                const unsigned long long lmask = (lk >= 64u ? ~0ull : ((1ull << lk) - 1ull)) << (lnb & 63u);   // the lanes of this node's line
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's two commonest links --
                 uint32_t dsp = 0;
@@ -542,10 +545,15 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 bool row_inline = false;
                 // id << 7 | flags << 5 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
                 if (probe && name_match(r0, r1, r2, d, len) && r1.z != 0xFFFFFFFFu && !(r1.z & 0x60u)) { id = r1.z >> 7; lbp = r1.w & 0x7FFFFFFFu; row_inline = (r1.w >> 31) != 0; }
-                // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact path
-                if (live && (id == NONE32 || lbp >= (1u << 25))) atomicOr(&l_meta[ln], ST_DEFER << 24);   // ST_OK | ST_DEFER == ST_DEFER
-                wave_sync();
-                if (live) live = (l_meta[ln] >> 24) == ST_OK;
+                // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
+                // path (all nodes of a line sit in this pass: a ballot tells every lane of the line)
+                {
+                    const unsigned long long badm = __ballot(live && (id == NONE32 || lbp >= (1u << 25)));
+                    if (live && (badm & lmask)) {
+                        if (j == 0) l_meta[ln] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
+                        live = false;
+                    }
+                }
                 if (!live) { j = 0; lk = 0; id = NONE32; lbp = 0; }
                 tick(4);
                 // -- running path length of the line (inclusive) = wave prefix sum minus what precedes the line's first node --
@@ -559,8 +567,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 {
                     const uint32_t prev = (uint32_t)__shfl_up((int)id, 1);
                     const unsigned long long up = __ballot(live && (j == 0 || id > prev)), dn = __ballot(live && (j == 0 || id < prev));
-                    const unsigned long long lm = (lk >= 64u ? ~0ull : ((1ull << lk) - 1ull)) << (lnb & 63u);
-                    const bool search = live && (up & lm) != lm && (dn & lm) != lm;
+                    const bool search = live && (up & lmask) != lmask && (dn & lmask) != lmask;
                     for (uint32_t dd = 1; __ballot(search && j >= dd); dd += 4) {       // four distances per trip: one wait for four shuffles
                         const uint32_t y0 = (uint32_t)__shfl_up((int)id, dd), y1 = (uint32_t)__shfl_up((int)id, dd + 1);
                         const uint32_t y2 = (uint32_t)__shfl_up((int)id, dd + 2), y3 = (uint32_t)__shfl_up((int)id, dd + 3);
