@@ -54,8 +54,8 @@ namespace svjg {
 //     (ihits[index] = number of hits, then the hits).  Reference-allele links come first.  Nearly every path step is
 //     answered from the record that the node lookup fetched anyway and never touches the link table.
 // LINK TABLE: (left id, left strand, right id, right strand) -> hits, same content as the CSR rows; two-choice (cuckoo)
-// table: every key sits in one of its TWO candidate slots.  The SLOT of a link is hashed from the name digests of its two
-// nodes and the strands (name_x32), not from the ids.
+// table: every key sits in one of its TWO candidate slots.  The SLOTS of a link are hashed from the 64-bit name pre-hashes of
+// its two nodes and the strands (svjg_line.h: link_prehash / link_slots), not from the ids.
 //   entry = 4 words (one 16-byte load): [0] key low, [1] key high, [2] a, [3] b with
 //       1 hit : a = hit, b = LINK_NO_HIT        2 hits: a, b = the hits
 //       more  : a = LINK_MANY | index into hits[], b = number of hits
@@ -71,46 +71,35 @@ inline void name_ent_words(const uint32_t *e, uint32_t d[8]) { for (int w = 0; w
 inline bool nm_len_gt24(uint32_t meta) { return (meta & 31u) + 1u > 24u; }
 inline uint32_t rec_first_link(const uint32_t *e) { return name_ent_len(e) > 24u ? 10u : 8u; }   // word of the first inline link
 
-// xl, xr = name digests (name_x32) of the left / right node, sl, sr = strands (1 = '-')
-inline uint32_t link_prehash_host(uint32_t xl, uint32_t sl, uint32_t xr, uint32_t sr) {
-    return xl * 0x9E3779B1u + (xr ^ (sl * 0x68E31DA4u) ^ (sr * 0xB5297A4Du)) * 0x85EBCA77u;
-}
-// the two candidate slots of a pre-hash (svjg_kernels.h: cuckoo_slots is the device twin)
-inline void cuckoo_slots_host(uint32_t x, uint32_t seed, uint32_t mask, uint32_t &s1, uint32_t &s2) {
-    uint32_t a = x ^ seed;
-    a ^= a >> 15; a *= 0x2C1B3C6Du; a ^= a >> 12;
-    uint32_t b = (x + seed) * 0x85EBCA6Bu;
-    b ^= b >> 13; b *= 0xC2B2AE35u; b ^= b >> 16;
-    s1 = a & mask; s2 = b & mask;
-    if (s2 == s1) s2 = s1 ^ 1u;
-}
-
 struct KernelTables {
     std::vector<uint32_t> names; uint32_t name_slots = 0, name_buckets = 0;
     std::vector<uint16_t> disp;                               // displacement of every bucket of the name hash
     std::vector<uint32_t> ihits;                              // hit lists of inline links with more than one hit: count, hits...
     std::vector<uint32_t> links; uint32_t link_mask = 0, link_seed = 0;
-    uint64_t names_left_out = 0, links_left_out = 0;
+    uint64_t names_left_out = 0, links_left_out = 0, links_unplaced = 0;   // links_unplaced: their left nodes are flagged for the exact path
     uint32_t names_skipped = 0;                               // node names the table cannot hold (> 32 bytes, id too large)
-    std::vector<uint32_t> node_pre; std::vector<uint8_t> node_has;   // per node: name digest, "is in the name table" (table checks)
+    std::vector<uint64_t> node_pre; std::vector<uint8_t> node_has;   // per node: name pre-hash, "is in the name table" (table checks)
     std::vector<uint32_t> node_slot;                          // per node: its record (table checks)
 };
 
 // Two-choice placement by random-walk eviction.  pre[i] = pre-hash of key i; returns owner[slot] = key index or -1.
 // Keys that cannot be placed under any of a few seeds are dropped (counted in left_out).
-inline std::vector<int64_t> cuckoo_place(const std::vector<uint32_t> &pre, uint32_t mask, uint32_t &seed_out, uint64_t &left_out) {
+inline std::vector<int64_t> cuckoo_place(const std::vector<uint64_t> &pre, uint32_t mask, uint32_t &seed_out, uint64_t &left_out,
+                                         std::vector<uint32_t> *left_keys = nullptr) {
     std::vector<int64_t> best;
+    std::vector<uint32_t> best_keys;
     uint64_t best_left = ~0ull;
     for (uint32_t seed = 0x5bd1e995u, attempt = 0; attempt < 8; ++attempt, seed = seed * 0x9E3779B1u + 0x7F4A7C15u) {
         std::vector<int64_t> owner((size_t)mask + 1, -1);
         uint64_t left = 0, rng = 0x9E3779B97F4A7C15ull ^ seed;
+        std::vector<uint32_t> keys_out;
         for (size_t i = 0; i < pre.size(); ++i) {
             int64_t cur = (int64_t)i;
             uint32_t avoid = 0xFFFFFFFFu;
             bool placed = false;
             for (int kick = 0; kick < 512; ++kick) {
                 uint32_t s1, s2;
-                cuckoo_slots_host(pre[(size_t)cur], seed, mask, s1, s2);
+                link_slots(pre[(size_t)cur], seed, mask, s1, s2);
                 if (owner[s1] < 0) { owner[s1] = cur; placed = true; break; }
                 if (owner[s2] < 0) { owner[s2] = cur; placed = true; break; }
                 rng = rng * 6364136223846793005ull + 1442695040888963407ull;
@@ -119,12 +108,13 @@ inline std::vector<int64_t> cuckoo_place(const std::vector<uint32_t> &pre, uint3
                 std::swap(cur, owner[victim]);
                 avoid = victim;
             }
-            if (!placed) ++left;                              // `cur` (whoever was evicted last) stays out
+            if (!placed) { ++left; keys_out.push_back((uint32_t)cur); }   // `cur` (whoever was evicted last) stays out
         }
-        if (left < best_left) { best_left = left; best.swap(owner); seed_out = seed; }
+        if (left < best_left) { best_left = left; best.swap(owner); best_keys.swap(keys_out); seed_out = seed; }
         if (best_left == 0) break;
     }
     left_out = best_left;
+    if (left_keys) left_keys->swap(best_keys);
     return best;
 }
 
@@ -166,7 +156,7 @@ inline bool chd_place(const std::vector<uint64_t> &h, uint32_t n_slots, uint32_t
 
 inline KernelTables build_kernel_tables(const svjg_graph &g) {
     KernelTables kt;
-    std::vector<uint32_t> node_pre((size_t)g.n_nodes, 0);    // name digest of every node the name table holds
+    std::vector<uint64_t> node_pre((size_t)g.n_nodes, 0);    // name pre-hash of every node the name table holds
     std::vector<uint8_t> node_has((size_t)g.n_nodes, 0);
     std::vector<uint32_t> node_slot((size_t)g.n_nodes, 0);
     {
@@ -227,7 +217,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             e[6] = src[8]; e[7] = src[9];
             if (nm_len_gt24(src[8])) { e[8] = src[6]; e[9] = src[7]; }
             const uint32_t node = key_node[k];
-            node_pre[node] = name_x32(hs[k]); node_has[node] = 1; node_slot[node] = slot_of[k];
+            node_pre[node] = hs[k]; node_has[node] = 1; node_slot[node] = slot_of[k];
             // inline links: up to two rows of the node, those whose hits are all reference-allele first
             const uint32_t a = g.nodes[node].row & 0x7FFFFFFFu, b = g.nodes[node + 1].row & 0x7FFFFFFFu;
             std::vector<uint32_t> rows;
@@ -259,14 +249,15 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             if (n_live <= cap && rows.size() == n_live) e[7] |= REC_ROW_INLINE;
         }
     }
-    // a link that cannot be placed would be a silent miss in the kernel: grow the table until every link sits in one of its
-    // two slots (links_left_out stays > 0 only if that fails; the library then routes everything through the exact path)
+    // A link that cannot be placed (never seen with 64-bit pre-hashes at load <= 0.4) would be a silent miss in the
+    // kernel: its left node is flagged hazard-prone instead, which sends the lines that touch it to the exact path.  links_left_out counts links lost for good (never seen: the library then uses the exact path only).
     uint64_t lsz = 16;
     while (lsz < 5 * g.n_edges / 2 + 2) lsz *= 2;
-    for (int grow = 0; grow < 4; ++grow, lsz *= 2) {
+    {
         kt.links.assign(lsz * LINK_ENT_WORDS, 0xFFFFFFFFu);
         kt.link_mask = (uint32_t)lsz - 1;
-        std::vector<uint32_t> ent, pre;                       // 4 words per candidate
+        std::vector<uint32_t> ent, left_node;                 // 4 words per candidate
+        std::vector<uint64_t> pre;
         for (uint64_t n = 0; n < g.n_nodes; ++n) {
             uint32_t a = g.nodes[n].row & 0x7FFFFFFFu, b = g.nodes[n + 1].row & 0x7FFFFFFFu;
             for (uint32_t i = a; i < b; ++i) {
@@ -278,15 +269,19 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
                 if (nh == 1) { ent.push_back(ed.h0); ent.push_back(LINK_NO_HIT); }
                 else if (nh == 2) { ent.push_back(ed.h0); ent.push_back(ed.h1); }
                 else { ent.push_back(LINK_MANY | ed.h0); ent.push_back(nh); }
-                pre.push_back(link_prehash_host(node_pre[n], ed.meta & 1u, node_pre[ed.right], (ed.meta >> 1) & 1u));
+                pre.push_back(link_prehash(node_pre[n], ed.meta & 1u, node_pre[ed.right], (ed.meta >> 1) & 1u));
+                left_node.push_back((uint32_t)n);
             }
         }
-        std::vector<int64_t> owner = cuckoo_place(pre, kt.link_mask, kt.link_seed, kt.links_left_out);
+        std::vector<uint32_t> unplaced;
+        uint64_t n_unplaced = 0;
+        std::vector<int64_t> owner = cuckoo_place(pre, kt.link_mask, kt.link_seed, n_unplaced, &unplaced);
         for (uint64_t j = 0; j < lsz; ++j) {
             if (owner[j] < 0) continue;
             for (int w = 0; w < 4; ++w) kt.links[j * LINK_ENT_WORDS + w] = ent[(size_t)owner[j] * 4 + w];
         }
-        if (kt.links_left_out == 0) break;
+        kt.links_unplaced = n_unplaced;
+        for (uint32_t k : unplaced) kt.names[(size_t)node_slot[left_node[k]] * NAME_ENT_WORDS + 6] |= 1u << 5;
     }
     kt.node_pre.swap(node_pre); kt.node_has.swap(node_has); kt.node_slot.swap(node_slot);
     return kt;

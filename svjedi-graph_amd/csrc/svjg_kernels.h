@@ -169,26 +169,11 @@ __device__ inline uint64_t name_words(const uint8_t *text, uint32_t a0, uint32_t
     return h;
 }
 
-// the two candidate slots of a pre-hash in a two-choice table (svjg_host_tables.h: cuckoo_slots_host)
-__device__ inline void cuckoo_slots(uint32_t x, uint32_t seed, uint32_t mask, uint32_t &s1, uint32_t &s2) {
-    uint32_t p = x ^ seed;
-    p ^= p >> 15; p *= 0x2C1B3C6Du; p ^= p >> 12;
-    uint32_t q = (x + seed) * 0x85EBCA6Bu;
-    q ^= q >> 13; q *= 0xC2B2AE35u; q ^= q >> 16;
-    s1 = p & mask; s2 = q & mask;
-    if (s2 == s1) s2 = s1 ^ 1u;
-}
-
 // record of the node-name table (svjg_host_tables.h): r0 = name bytes 0..15, r1 = bytes 16..23 | meta | length in bp,
 // r2.xy = bytes 24..31 (only names longer than 24 bytes look at them)
 __device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[8], uint32_t L) {
     return (r1.z & 31u) == L - 1u && r0.x == d[0] && r0.y == d[1] && r0.z == d[2] && r0.w == d[3] &&
            r1.x == d[4] && r1.y == d[5] && (L <= 24u || (r2.x == d[6] && r2.y == d[7]));
-}
-
-// slot hash of a link from the name digests (name_x32) of its two nodes and their strands (svjg_host_tables.h: link_prehash_host)
-__device__ inline uint32_t link_prehash(uint32_t xl, uint32_t sl, uint32_t xr, uint32_t sr) {
-    return xl * 0x9E3779B1u + (xr ^ (sl * 0x68E31DA4u) ^ (sr * 0xB5297A4Du)) * 0x85EBCA77u;
 }
 
 // Workgroup barrier for data handed over through LDS only.  __syncthreads() also drains the wave's global-memory queue
@@ -511,7 +496,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // -- the node of this lane: line, index in the line, name --
                 const bool act = lane < n_pass;
                 const uint32_t o = obase + p0 + lane;
-                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, x = 0, oribit = 0, meta = 0, d[8];
+                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, oribit = 0, meta = 0, d[8];
                 uint64_t h = 0;
                 bool live = false, probe = false;
                 if (act) {
@@ -527,7 +512,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         oribit = text[a0 - 1] == '<' ? 1u : 0u;
                         len = b0 - a0;
                         probe = len - 1u <= 31u;                         // names of 1..32 bytes; longer ones: exact path
-                        if (probe) { h = name_words(text, a0, len, d); x = name_x32(h); }
+                        if (probe) h = name_words(text, a0, len, d);
                     }
                 }
                 if (!live) { j = 0; lk = 0; lnb = 0; }
@@ -616,10 +601,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
                 if (__ballot(ask)) {
-                    const uint32_t xl = (uint32_t)__shfl((int)x, (int)fl), xr = (uint32_t)__shfl((int)x, (int)(fr & 63u));
+                    const uint64_t hl = __shfl((unsigned long long)h, (int)fl), hr = __shfl((unsigned long long)h, (int)(fr & 63u));
                     if (ask) {
                         uint32_t sa, sb2;
-                        cuckoo_slots(link_prehash(xl, orl, xr, orr), g.link_seed, g.link_mask, sa, sb2);
+                        link_slots(link_prehash(hl, orl, hr, orr), g.link_seed, g.link_mask, sa, sb2);
                         uint4 ek = *(const uint4 *)(g.link_tab + (size_t)sa * 4);
                         const uint4 ek2 = *(const uint4 *)(g.link_tab + (size_t)sb2 * 4);
                         if (!(ek.x == klo && ek.y == khi)) ek = ek2;                          // the other candidate slot
@@ -731,10 +716,14 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
             for (uint32_t o = 0; o < want; o += 16) *(uint4 *)(stage + off + o) = *(const uint4 *)(a.gaf + a0 + o);
         __syncthreads();
         if (have) {
-            const uint8_t *t = staged ? (const uint8_t *)stage + off : a.gaf;
-            const uint64_t s2 = staged ? s - a0 : s;
+            // two instances of the string routine: on a pointer the compiler knows to be LDS (ds_read_u8 per byte) and on
+            // global memory; one generic pointer would turn every byte access into a flat load (~10x slower per line)
             SlowEmit em{&a, a.base_offset + s};
-            int rc = slow_line(a.g, t, s2, s2 + (e - s), em);
+            int rc;
+            if (staged) {
+                typedef const __attribute__((address_space(3))) uint8_t *lds_text;
+                rc = slow_line(a.g, (lds_text)(stage + off), s - a0, s - a0 + (e - s), em);
+            } else rc = slow_line(a.g, a.gaf, s, e, em);
             if (rc) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (unsigned long long)rc);
         }
         __syncthreads();

@@ -62,7 +62,16 @@ SVJG_HD uint32_t name_bucket(uint64_t h, uint32_t n_buckets) { return mulhi32(fm
 SVJG_HD uint32_t name_slot(uint64_t h, uint32_t disp, uint32_t n_slots) {
     return mulhi32(fmix32(((uint32_t)h ^ ((uint32_t)(h >> 32) * 0x9E3779B1u)) + disp * 0x632BE5ABu), n_slots);
 }
-SVJG_HD uint32_t name_x32(uint64_t h) { return (uint32_t)h ^ (uint32_t)(h >> 32); }    // 32-bit digest used to hash links by their two names
+// Link table (two-choice): the slots of a link follow from the 64-bit name pre-hashes of its two nodes and the strands
+// (1 = '-'), so a lookup needs no node ids; with 64 bits no three links share their pair of slots.
+SVJG_HD uint64_t link_prehash(uint64_t hl, uint32_t sl, uint64_t hr, uint32_t sr) {
+    return hl * 0x9E3779B97F4A7C15ull + (hr + sl * 0x68E31DA4B5297A4Dull + sr * 0xD6E8FEB86659FD93ull) * 0xC2B2AE3D27D4EB4Full;
+}
+SVJG_HD void link_slots(uint64_t v, uint32_t seed, uint32_t mask, uint32_t &s1, uint32_t &s2) {
+    s1 = fmix32((uint32_t)v ^ seed) & mask;
+    s2 = fmix32((uint32_t)(v >> 32) + seed * 0x85EBCA6Bu) & mask;
+    if (s2 == s1) s2 = s1 ^ 1u;
+}
 
 SVJG_HD bool py_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 

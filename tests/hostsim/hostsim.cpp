@@ -64,7 +64,7 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
         const uint64_t h = name_prehash(d, name_ent_len(e));
         if (j != name_slot(h, kt.disp[name_bucket(h, kt.name_buckets)], kt.name_slots)) ++bad;   // the kernel's one probe lands here
         const uint32_t id = name_ent_id(e);
-        if (!kt.node_has[id] || kt.node_slot[id] != j || kt.node_pre[id] != name_x32(h)) ++bad;
+        if (!kt.node_has[id] || kt.node_slot[id] != j || kt.node_pre[id] != h) ++bad;
         const svjg_node &nd = g->nodes[id];
         uint32_t kind = (uint32_t)(nd.key >> 15) & 1u, pos = (uint32_t)(nd.key >> 16);
         if ((e[7] & ~REC_ROW_INLINE) != (kind ? nd.aux : nd.aux - pos + 1) && !(e[6] & 0x40u)) ++bad;
@@ -102,10 +102,13 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
             uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
             uint32_t s1, s2;
             if (!kt.node_has[n] || !kt.node_has[ed.right]) continue;          // such lines take the exact path
-            cuckoo_slots_host(link_prehash_host(kt.node_pre[n], ed.meta & 1u, kt.node_pre[ed.right], (ed.meta >> 1) & 1u), kt.link_seed, kt.link_mask, s1, s2);
+            link_slots(link_prehash(kt.node_pre[n], ed.meta & 1u, kt.node_pre[ed.right], (ed.meta >> 1) & 1u), kt.link_seed, kt.link_mask, s1, s2);
             const uint32_t *e = &kt.links[(uint64_t)s1 * LINK_ENT_WORDS];
             if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) e = &kt.links[(uint64_t)s2 * LINK_ENT_WORDS];
-            if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) { ++bad; continue; }
+            if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) {
+                if (!(kt.names[(size_t)kt.node_slot[n] * NAME_ENT_WORDS + 6] & (1u << 5))) ++bad;        // unplaced link: its left node must be flagged for the exact path
+                continue;
+            }
             const uint32_t nh = ed.meta >> 2;
             if (nh == 1 ? (e[2] != ed.h0 || e[3] != LINK_NO_HIT) : nh == 2 ? (e[2] != ed.h0 || e[3] != ed.h1) : (e[2] != (LINK_MANY | ed.h0) || e[3] != nh)) ++bad;
             ++n_links;
@@ -114,4 +117,13 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
     for (uint64_t j = 0; j <= kt.link_mask; ++j) occupied += !(kt.links[j * LINK_ENT_WORDS] == 0xFFFFFFFFu && kt.links[j * LINK_ENT_WORDS + 1] == 0xFFFFFFFFu);
     if (occupied != n_links) ++bad;
     return bad;
+}
+
+// table statistics (harness only): names left out / skipped, links left out, slots, buckets
+extern "C" void hostsim_table_stats(const svjg_graph *g, uint64_t *out) {
+    KernelTables kt = build_kernel_tables(*g);
+    out[0] = kt.names_left_out; out[1] = kt.names_skipped; out[2] = kt.links_left_out + (kt.links_unplaced << 32); out[3] = kt.name_slots; out[4] = kt.name_buckets;
+    out[5] = kt.link_mask + 1ull; out[6] = kt.ihits.size();
+    uint64_t mx = 0; for (uint16_t d : kt.disp) if (d > mx) mx = d;
+    out[7] = mx;
 }

@@ -52,3 +52,13 @@ def check_tables(graph):
     lib, capi = _lib()
     cg = capi.cgraph_of(graph)
     return lib.hostsim_check_tables(ctypes.byref(cg))
+
+
+def table_stats(graph):
+    """(names left out, names skipped, links left out, name slots, name buckets, link slots, inline hit words, max displacement)"""
+    lib, capi = _lib()
+    cg = capi.cgraph_of(graph)
+    out = (ctypes.c_uint64 * 8)()
+    lib.hostsim_table_stats.restype = None
+    lib.hostsim_table_stats(ctypes.byref(cg), out)
+    return tuple(int(x) for x in out)
