@@ -120,8 +120,11 @@ def genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support=3, err=0.
 
 def run(json_path, vcf_path, out_path, min_support=3, err=0.00005, device=0):
     """predict-genotype.py main(): counts come from the informative-alignment JSON."""
-    from . import capi
-    keys, counts = capi.count_informative_json(json_path)       # len() of the two lists of every key (:219-226)
+    from . import capi, filter as flt
+    got = flt.read_handoff(json_path)                            # left by our filter-alignments.py for exactly this file, else None
+    if got is None:
+        got = capi.count_informative_json(json_path)             # len() of the two lists of every key (:219-226)
+    keys, counts = got
     slot_of = {}
     for i, k in enumerate(keys):
         slot_of[k] = i                                           # a repeated key: the last one wins, like json.load

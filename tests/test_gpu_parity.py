@@ -316,3 +316,39 @@ def test_long_lines_widen_the_look_ahead(ctx, tmp_path):
         assert deferred[0] > n_lines // 100 and deferred[-1] < deferred[0] // 2
     finally:
         c2.close()
+
+
+def test_sharded_and_chunked_ingest_is_the_same_file(golden, tmp_path, monkeypatch):
+    """The drop-in filter cuts the GAF into one byte range per GPU and streams each range in chunks: two shards on one
+    GPU and 64 KB chunks must give the same counts and the same _informative_aln.json, byte for byte, as one piece."""
+    import synth
+    from svjg import capi, filter as flt
+    from svjg.graph import Graph
+    pre = str(tmp_path / "s")
+    synth.generate(pre, 30000, 800, 3, "mixed", 77)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    c1, r1, d1 = flt.classify_sharded(g, pre + ".gaf", devices=[0])
+    capi.write_informative_json(pre + "_1.json", d1, r1, g.sv_ids)
+    monkeypatch.setattr(flt, "CHUNK_BYTES", 1 << 16)
+    c2, r2, d2 = flt.classify_sharded(g, pre + ".gaf", devices=[0, 0, 0])
+    capi.write_informative_json(pre + "_2.json", d2, r2, g.sv_ids)
+    assert np.array_equal(c1, c2) and c1.sum() > 0 and len(r1) == len(r2)
+    assert open(pre + "_1.json", "rb").read() == open(pre + "_2.json", "rb").read()
+    monkeypatch.setenv("SVJG_DEVICES", "0,0")
+    assert flt.pick_devices(1 << 40) == [0, 0]
+    # the scripts end to end, with the counts hand-off and without it: the same VCF
+    from svjg import genotype
+    flt.run(pre + ".gaf", pre + ".gfa", pre)
+    assert flt.read_handoff(pre + "_informative_aln.json") is not None
+    genotype.run(pre + "_informative_aln.json", pre + ".vcf", pre + "_a.vcf")
+    monkeypatch.setenv("SVJG_NO_HANDOFF", "1")
+    genotype.run(pre + "_informative_aln.json", pre + ".vcf", pre + "_b.vcf")
+    assert open(pre + "_a.vcf").read() == open(pre + "_b.vcf").read()
+    assert open(pre + "_informative_aln.json", "rb").read() == open(pre + "_1.json", "rb").read()
+    # an input the reference dies on: the error of the first bad line in file order, whatever shard it is in
+    bad = open(pre + ".gaf", "rb").read().split(b"\n")
+    bad[len(bad) // 2] = b"x\t1\t2"
+    open(pre + "_bad.gaf", "wb").write(b"\n".join(bad))
+    monkeypatch.delenv("SVJG_NO_HANDOFF")
+    with pytest.raises(ValueError):
+        flt.classify_sharded(g, pre + "_bad.gaf", devices=[0, 0])
