@@ -5,8 +5,12 @@
 // from the device's hit records: for every SV key (sorted by code point = UTF-8 byte order) the two lists of
 // alignment texts in file order, where a text is the line as Python's text mode delivers it (terminator
 // translated to "\n", absent at EOF) cut before the first "cg:Z:" (filter-alignments.py:166), escaped like
-// json's ensure_ascii=True.  Multi-threaded by key ranges, streamed to the file in order.
+// json's ensure_ascii=True.  Multi-threaded by key ranges; every thread writes its own ranges at their final offsets.
 #include "../../include/svjg.h"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -125,58 +129,75 @@ extern "C" int svjg_write_informative_json(const char *path, const char *gaf, ui
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return strcmp(sv_ids[a], sv_ids[b]) < 0; });
 
     Job job{(const uint8_t *)gaf, n_bytes, recs.data(), begin.data(), sv_ids, order.data(), order.size()};
-    FILE *fp = fopen(path, "wb");
-    if (!fp) return SVJG_E_NOMEM;
-    if (order.empty()) { fputs("{}", fp); return fclose(fp) ? SVJG_E_NOMEM : 0; }
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return SVJG_E_NOMEM;
+    auto put = [&](const char *p, size_t n, uint64_t at) {                 // pwrite all of it
+        while (n) {
+            ssize_t w = pwrite(fd, p, n, (off_t)at);
+            if (w <= 0) return false;
+            p += w; n -= (size_t)w; at += (uint64_t)w;
+        }
+        return true;
+    };
+    if (order.empty()) { bool ok = put("{}", 2, 0); return (close(fd) || !ok) ? SVJG_E_NOMEM : 0; }
 
-    const uint64_t CH = 256;                                   // keys per task
-    const uint64_t n_tasks = (order.size() + CH - 1) / CH;
-    int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    // tasks = runs of keys with about REC_PER_TASK hit records (a few MB of text each).  Workers render tasks into memory
+    // in parallel; a task's file offset is known as soon as all earlier tasks are rendered, and the worker that rendered it
+    // writes it there itself (pwrite): both the rendering and the copy into the page cache run on all threads.
+    const uint64_t REC_PER_TASK = 16384;
+    std::vector<uint64_t> task_lo{0};
+    { uint64_t acc = 0;
+      for (uint64_t ki = 0; ki < order.size(); ++ki) {
+          acc += begin[order[ki] + 1] - begin[order[ki]];
+          if (acc >= REC_PER_TASK && ki + 1 < order.size()) { task_lo.push_back(ki + 1); acc = 0; }
+      }
+      task_lo.push_back(order.size()); }
+    const uint64_t n_tasks = task_lo.size() - 1;
+    int T = n_threads > 0 ? n_threads : (int)std::min(64u, std::thread::hardware_concurrency());
     if (T < 1) T = 1;
     if ((uint64_t)T > n_tasks) T = (int)n_tasks;
-    std::vector<std::string> out(n_tasks);
+    std::vector<uint64_t> off(n_tasks + 1, 0);                 // off[t] = file offset of task t, valid once t <= known
+    std::vector<uint64_t> size(n_tasks, 0);
     std::vector<char> done(n_tasks, 0);
+    off[0] = 1;                                                // behind the opening brace
     std::atomic<uint64_t> next{0};
-    std::atomic<int> bad{0};
+    std::atomic<int> bad{0};                                   // 1 = text is not valid UTF-8, 2 = write error
     std::mutex mu; std::condition_variable cv;
-    uint64_t written = 0;                                      // tasks flushed so far (guards memory: workers stay <= 4T ahead)
+    uint64_t known = 0;                                        // tasks 0 .. known-1 are rendered (workers stay <= 4T ahead: bounds memory)
     auto worker = [&]() {
-        std::string tmp;
+        std::string tmp, s;
         for (;;) {
-            uint64_t t = next.fetch_add(1);
+            const uint64_t t = next.fetch_add(1);
             if (t >= n_tasks) return;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return t < written + 4 * (uint64_t)T || bad.load(); }); }
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return t < known + 4 * (uint64_t)T || bad.load(); }); }
             if (bad.load()) return;
-            // every line of every group sorted by file order
-            std::string s;
-            for (uint64_t ki = t * CH; ki < std::min<uint64_t>((t + 1) * CH, order.size()); ++ki) {
+            s.clear();
+            for (uint64_t ki = task_lo[t]; ki < task_lo[t + 1]; ++ki) {
                 const uint32_t slot = order[ki];
+                // every line of every group sorted by file order
                 std::sort(recs.begin() + begin[slot], recs.begin() + begin[slot + 1],
                           [](const svjg_hitrec &a, const svjg_hitrec &b) { return a.line_start < b.line_start; });
                 if (!render_key(job, ki, s, tmp)) { bad.store(1); break; }
             }
-            { std::lock_guard<std::mutex> lk(mu); out[t].swap(s); done[t] = 1; }
-            cv.notify_all();
+            uint64_t at;
+            { std::unique_lock<std::mutex> lk(mu);
+              size[t] = s.size(); done[t] = 1;
+              while (known < n_tasks && done[known]) { off[known + 1] = off[known] + size[known]; ++known; }
+              cv.notify_all();
+              cv.wait(lk, [&] { return known >= t || bad.load(); });
+              at = off[t]; }
+            if (bad.load()) { cv.notify_all(); return; }
+            if (!put(s.data(), s.size(), at)) { bad.store(2); cv.notify_all(); return; }
         }
     };
-    std::vector<std::thread> th;
-    for (int i = 0; i < T; ++i) th.emplace_back(worker);
     int rc = 0;
-    fputc('{', fp);
-    for (uint64_t t = 0; t < n_tasks && !rc; ++t) {
-        std::string s;
-        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done[t] || bad.load(); });
-          if (!done[t]) { rc = SVJG_E_INPUT; break; }
-          s.swap(out[t]); }
-        if (fwrite(s.data(), 1, s.size(), fp) != s.size()) rc = SVJG_E_NOMEM;
-        { std::lock_guard<std::mutex> lk(mu); written = t + 1; }
-        cv.notify_all();
-    }
-    if (rc) { bad.store(1); cv.notify_all(); }
+    if (!put("{", 1, 0)) rc = SVJG_E_NOMEM;
+    std::vector<std::thread> th;
+    if (!rc) for (int i = 0; i < T; ++i) th.emplace_back(worker);
     for (auto &x : th) x.join();
-    if (!rc && bad.load()) rc = SVJG_E_INPUT;
-    if (!rc) fputs("\n}", fp);
-    if (fclose(fp) && !rc) rc = SVJG_E_NOMEM;
+    if (!rc && bad.load()) rc = bad.load() == 1 ? SVJG_E_INPUT : SVJG_E_NOMEM;
+    if (!rc && !put("\n}", 2, off[n_tasks])) rc = SVJG_E_NOMEM;
+    if (close(fd) && !rc) rc = SVJG_E_NOMEM;
     return rc;
 }
 
@@ -185,10 +206,6 @@ extern "C" int svjg_write_informative_json(const char *path, const char *gaf, ui
 // svjg_count_informative_json scans the JSON text once (any valid JSON of that shape, not only json.dumps' layout)
 // and returns the keys (unescaped, UTF-8, NUL separated) and the two list lengths per key.
 // ---------------------------------------------------------------------------------------------------------------
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
 
 namespace {
 
