@@ -158,18 +158,24 @@ class Graph:
         n_e = len(qs)
         edges_a = np.zeros(max(n_e, 1), dtype=EDGE_DT)
         over = []
-        rows = np.zeros(n_nodes + 1, dtype=np.int64)
-        for i, (q, hv) in enumerate(zip(qs, merged)):
+        left, right, meta, h0, h1 = [], [], [], [], []      # columns as Python lists, converted once (no per-element numpy stores)
+        for q, hv in zip(qs, merged):
             a, sl, b, sr = q
-            rows[a + 1] += 1
-            edges_a["right"][i] = b
-            edges_a["meta"][i] = int(sl) | (int(sr) << 1) | (len(hv) << 2)
+            left.append(a); right.append(b)
+            meta.append(int(sl) | (int(sr) << 1) | (len(hv) << 2))
             if len(hv) <= 2:
-                edges_a["h0"][i] = hv[0]
-                edges_a["h1"][i] = hv[1] if len(hv) > 1 else 0
+                h0.append(hv[0]); h1.append(hv[1] if len(hv) > 1 else 0)
             else:
-                edges_a["h0"][i] = len(over)
+                h0.append(len(over)); h1.append(0)
                 over.extend(hv)
+        if n_e:
+            edges_a["right"][:n_e] = np.array(right, dtype=np.uint32)
+            edges_a["meta"][:n_e] = np.array(meta, dtype=np.uint32)
+            edges_a["h0"][:n_e] = np.array(h0, dtype=np.uint32)
+            edges_a["h1"][:n_e] = np.array(h1, dtype=np.uint32)
+        rows = np.zeros(n_nodes + 1, dtype=np.int64)
+        if n_e:
+            rows[1:] = np.bincount(np.array(left, dtype=np.int64), minlength=n_nodes)
         rows = np.cumsum(rows)
         nodes["row"] = rows.astype(np.uint32)
         self.edges = edges_a
