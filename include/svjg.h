@@ -168,6 +168,18 @@ int svjg_write_informative_json(const char *path, const char *gaf, uint64_t n_by
 int svjg_count_informative_json(const char *path, char **keys_out, uint64_t *keys_len, uint64_t **counts_out, uint64_t *n_keys);
 void svjg_host_free(void *p);
 
+/* ---- native loader of the graph inputs (libsvjg_host.so, no GPU involved) ---------------------------------------
+ * Fast path of svjedi-graph_amd/svjg/graph.py for the files construct-graph.py writes: <prefix>_svs_edges.json
+ * (filter-alignments.py:95-98) and the alt-node S-lines of the GFA (:103-113) -> the svjg_graph tables above.
+ * Returns SVJG_E_UNSUPPORTED for anything it does not recognise (escapes / non-ASCII in strings, duplicate keys, odd
+ * node names, ...): the caller then uses the Python loader, which holds the semantics and raises what it raises. */
+#define SVJG_E_UNSUPPORTED (-11)
+typedef struct svjg_hostgraph svjg_hostgraph;
+int  svjg_graph_load(const char *edges_json_path, const char *gfa_path, svjg_hostgraph **out);
+const svjg_graph *svjg_graph_view(const svjg_hostgraph *g);           /* d_over = 100, flags = 0: the caller may copy and adjust */
+int  svjg_graph_info(const svjg_hostgraph *g, const char **sv_ids_blob, uint64_t *sv_ids_len, uint32_t *n_hazard);   /* sv_ids: NUL-terminated, slot order */
+void svjg_graph_free(svjg_hostgraph *g);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the kernels of the last classify / genotype ---- */
 int svjg_last_kernel_ms(svjg_ctx *ctx, float *classify_main_ms, float *classify_slow_ms, float *genotype_ms);
 int svjg_sync(svjg_ctx *ctx);

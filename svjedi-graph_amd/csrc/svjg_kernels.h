@@ -37,6 +37,10 @@ constexpr uint32_t KMAX = 64;                    // path nodes per alignment han
 #define SVJG_LRW 32
 #endif
 constexpr uint32_t LRW = SVJG_LRW;               // lines per wave and round
+#ifndef SVJG_NWAVE_R
+#define SVJG_NWAVE_R (SVJG_WG / 64)
+#endif
+constexpr uint32_t NWAVE_R = SVJG_NWAVE_R;       // waves of a workgroup that share out the stripe's lines (all of them take part in phases A and B)
 static_assert(LRW <= 64 && KMAX <= 64, "round geometry: a line's nodes fit one wave pass");
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         tick(2);
 
         // ---- rounds: this wave's share of the stripe's lines -----------------------------------------------
-        const uint32_t per = (n_own + NWAVE - 1) / NWAVE;
+        const uint32_t per = (n_own + NWAVE_R - 1) / NWAVE_R;
         const uint32_t l_lo = wave * per < n_own ? wave * per : n_own, l_hi = l_lo + per < n_own ? l_lo + per : n_own;
         for (uint32_t lbase = (a.diag & 1u) ? l_hi : l_lo, taken = 0; lbase < l_hi; lbase += taken) {   // wave-uniform trip count
             const uint32_t cnt = l_hi - lbase < LRW ? l_hi - lbase : LRW;

@@ -72,7 +72,8 @@ _SIGS = {
     "svjg_sync": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
-EXPORTS = tuple(_SIGS) + ("svjg_write_informative_json", "svjg_count_informative_json", "svjg_host_free")
+EXPORTS = tuple(_SIGS) + ("svjg_write_informative_json", "svjg_count_informative_json", "svjg_host_free",
+                          "svjg_graph_load", "svjg_graph_view", "svjg_graph_info", "svjg_graph_free")
 _lib = None
 _host_lib = None
 
@@ -92,8 +93,49 @@ def load_host_library():
                                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
         lib.svjg_host_free.restype = None
         lib.svjg_host_free.argtypes = [ctypes.c_void_p]
+        lib.svjg_graph_load.restype = ctypes.c_int
+        lib.svjg_graph_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.svjg_graph_view.restype = ctypes.POINTER(CGraph)
+        lib.svjg_graph_view.argtypes = [ctypes.c_void_p]
+        lib.svjg_graph_info.restype = ctypes.c_int
+        lib.svjg_graph_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+        lib.svjg_graph_free.restype = None
+        lib.svjg_graph_free.argtypes = [ctypes.c_void_p]
         _host_lib = lib
     return _host_lib
+
+
+def graph_load_native(edges_json, gfa):
+    """Tables of a svjg.graph.Graph from the native loader, or None when it leaves the input to the Python loader.
+    -> dict(nodes, edges, hits, n_edges, n_hits, chrom_names (bytes), chrom_off, chrom_lo, sv_ids (list), n_hazard)"""
+    lib = load_host_library()
+    h = ctypes.c_void_p()
+    rc = lib.svjg_graph_load(os.fsencode(edges_json), os.fsencode(gfa), ctypes.byref(h))
+    if rc == -11:
+        return None
+    if rc:
+        raise OSError(f"cannot read {edges_json} / {gfa}")
+    try:
+        v = lib.svjg_graph_view(h).contents
+        from .graph import NODE_DT, EDGE_DT
+
+        def arr(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer(ctypes.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy()
+        n_chrom = v.n_chrom
+        chrom_off = arr(v.chrom_off, n_chrom + 1, np.uint32)
+        blob, blen, nhz = ctypes.c_void_p(), ctypes.c_uint64(0), ctypes.c_uint32(0)
+        lib.svjg_graph_info(h, ctypes.byref(blob), ctypes.byref(blen), ctypes.byref(nhz))
+        sv = ctypes.string_at(blob, blen.value).decode("ascii").split("\0")[:-1] if blen.value else []
+        return dict(
+            nodes=arr(v.nodes, v.n_nodes + 1, NODE_DT), n_nodes=int(v.n_nodes),
+            edges=arr(v.edges, max(1, v.n_edges), EDGE_DT), n_edges=int(v.n_edges),
+            hits=arr(v.hits, max(1, v.n_hits), np.uint32), n_hits=int(v.n_hits),
+            chrom_names=ctypes.string_at(v.chrom_names, int(chrom_off[-1]) + 4), chrom_off=chrom_off,
+            chrom_lo=arr(v.chrom_node_lo, n_chrom + 1, np.uint32), sv_ids=sv, n_hazard=int(nhz.value))
+    finally:
+        lib.svjg_graph_free(h)
 
 
 def count_informative_json(path):

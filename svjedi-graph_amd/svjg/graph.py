@@ -9,6 +9,7 @@ forward and reversed dictionary entries pre-merged, chromosome dictionary, count
 No classification happens here; this is table construction only.
 """
 import json
+import os
 
 import numpy as np
 
@@ -116,15 +117,7 @@ class Graph:
         self.chrom_off[1:] = np.cumsum([len(b) for b in cb])
         node_chrom = (nodes["key"][:n_nodes] >> np.uint64(48)).astype(np.int64)
         self.chrom_lo = np.searchsorted(node_chrom, np.arange(len(cb) + 1)).astype(np.uint32)
-        hsize = 8
-        while hsize < 2 * len(cb) + 2:
-            hsize *= 2
-        self.chrom_hash = np.zeros(hsize, dtype=np.uint32)
-        for i, b in enumerate(cb):
-            j = fnv1a32(b) & (hsize - 1)
-            while self.chrom_hash[j]:
-                j = (j + 1) & (hsize - 1)
-            self.chrom_hash[j] = i + 1
+        self.chrom_hash = self._chrom_hash(cb)
         # ---- directed link table: T'[q] = d[q] ++ d[reverse(q)] ----------------------------------------
         table = {}
         for l, sl, r, sr, ents in parsed_keys:
@@ -216,8 +209,52 @@ class Graph:
                             out.add(n)
         return out
 
+    def __getattr__(self, name):
+        if name == "node_names":                # natively loaded graph: spelled out on first use (tests, tools)
+            ck = self.nodes["key"][: self.n_nodes]
+            out = []
+            for k, aux in zip(ck.tolist(), self.nodes["aux"][: self.n_nodes].tolist()):
+                c, pos, kind, cnt = k >> 48, (k >> 16) & 0xFFFFFFFF, (k >> 15) & 1, k & 0x7FFF
+                out.append(f"{self.chroms[c]}:{pos}.{cnt}" if kind else f"{self.chroms[c]}:{pos}-{aux}")
+            self.node_names = out
+            return out
+        raise AttributeError(name)
+
     @classmethod
-    def from_files(cls, edges_json, gfa, **kw):
+    def from_files(cls, edges_json, gfa, d_over=100, all_slow=False, native=None):
+        """native: None = the native loader (libsvjg_host.so: svjg_graph_load) when it recognises the files, else this
+        module; False = this module only (it defines the semantics); True = native or GraphFormatError."""
+        if native is not False and not os.environ.get("SVJG_PY_GRAPH"):
+            from . import capi
+            t = capi.graph_load_native(edges_json, gfa)
+            if t is not None:
+                g = cls.__new__(cls)
+                g.d_over = d_over
+                g.flags = GRAPH_ALL_SLOW if all_slow else 0
+                for k in ("nodes", "n_nodes", "edges", "n_edges", "hits", "n_hits", "chrom_names", "chrom_off", "chrom_lo", "sv_ids", "n_hazard"):
+                    setattr(g, k, t[k])
+                off = g.chrom_off.tolist()
+                cb = [g.chrom_names[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+                g.chroms = [b.decode("ascii") for b in cb]
+                g.chrom_hash = cls._chrom_hash(cb)
+                g.slot_of = {sv: i for i, sv in enumerate(g.sv_ids)}
+                g.n_slots = len(g.sv_ids)
+                return g
+            if native:
+                raise GraphFormatError("the native loader does not recognise these files")
         with open(edges_json, "r") as fh:
             edges = json.load(fh)
-        return cls(edges, load_alt_node_len(gfa), **kw)
+        return cls(edges, load_alt_node_len(gfa), d_over=d_over, all_slow=all_slow)
+
+    @staticmethod
+    def _chrom_hash(cb):
+        hsize = 8
+        while hsize < 2 * len(cb) + 2:
+            hsize *= 2
+        tab = np.zeros(hsize, dtype=np.uint32)
+        for i, b in enumerate(cb):
+            j = fnv1a32(b) & (hsize - 1)
+            while tab[j]:
+                j = (j + 1) & (hsize - 1)
+            tab[j] = i + 1
+        return tab

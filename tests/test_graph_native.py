@@ -1,0 +1,90 @@
+"""The native graph loader (libsvjg_host.so: svjg_graph_load) is the fast path of svjg/graph.py: on every input it
+accepts it must build exactly the tables the Python loader builds, and it must leave everything else to Python."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from svjg.graph import Graph
+
+FIELDS = ("nodes", "edges", "hits", "chrom_off", "chrom_lo", "chrom_hash")
+SCALARS = ("n_nodes", "n_edges", "n_hits", "n_slots", "n_hazard", "chrom_names", "chroms", "sv_ids", "slot_of", "d_over", "flags")
+
+
+def _same(a, b):
+    for f in FIELDS:
+        x, y = getattr(a, f), getattr(b, f)
+        assert x.dtype == y.dtype and x.shape == y.shape and x.tobytes() == y.tobytes(), f
+    for f in SCALARS:
+        assert getattr(a, f) == getattr(b, f), f
+    assert a.node_names == b.node_names
+
+
+@pytest.mark.parametrize("case", ["quirks", "testdir"])
+def test_golden_graphs(golden, case):
+    ej, gfa = {"quirks": ("quirks/q_svs_edges.json", "quirks/q.gfa"), "testdir": ("testdir/test_svs_edges.json", "testdir/test.gfa")}[case]
+    py = Graph.from_files(f"{golden}/{ej}", f"{golden}/{gfa}", native=False)
+    nat = Graph.from_files(f"{golden}/{ej}", f"{golden}/{gfa}", native=True)
+    _same(py, nat)
+    assert nat.n_hazard == py.n_hazard
+
+
+@pytest.mark.parametrize("mix,n_sv,n_chrom,seed", [("mixed", 3000, 3, 5), ("del", 500, 1, 9), ("mixed", 1200, 12, 11)])
+def test_synthetic_graphs(tmp_path, mix, n_sv, n_chrom, seed):
+    import synth
+    pre = str(tmp_path / "g")
+    synth.generate(pre, 0, n_sv, n_chrom, mix, seed, write_gaf=False)
+    _same(Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", native=False, all_slow=True),
+          Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", native=True, all_slow=True))
+
+
+def test_layouts_and_empty(tmp_path):
+    """compact JSON, an empty value list, an empty table; a graph with hazard names ('1' / '11', '.1' / '.10')."""
+    d = {"1:1-100@+@1:101-200@+": [["1:DEL-100-150", 0], ["1:INS-100-1", 0], ["1:INS-100-2", 0]],
+         "11:1-100@+@11:101-200@-": [["11:INV-100-200", 1]], "1:101-200@-@1:1-100@-": [["1:X", 1]],
+         "1:100.1@+@1:101-200@+": [["1:INS-100-1", 1]], "1:100.10@+@1:101-200@+": [["1:INS-100-10", 1]], "2:5-9@+@2:10-20@+": []}
+    gfa = "H\tVN:Z:1.0\nS\t1:100.1\tACGTACGT\nS\t1:100.10\tACG\textra\nS\t1:1-100\t*\nL\t1:1-100\t+\t1:101-200\t+\t0M\n"
+    open(tmp_path / "g.gfa", "w").write(gfa)
+    for name, text in (("a", json.dumps(d)), ("b", json.dumps(d, sort_keys=True, indent=4)), ("c", "{}"), ("d", " {\n} \n")):
+        p = str(tmp_path / f"{name}_svs_edges.json")
+        open(p, "w").write(text)
+        _same(Graph.from_files(p, str(tmp_path / "g.gfa"), native=False), Graph.from_files(p, str(tmp_path / "g.gfa"), native=True))
+    g = Graph.from_files(str(tmp_path / "a_svs_edges.json"), str(tmp_path / "g.gfa"), native=True)
+    assert g.n_hazard > 0 and g.n_hits == 8          # two merged queries of four hits each
+
+
+def test_irregular_inputs_are_left_to_python(tmp_path):
+    from svjg import capi
+    gfa = str(tmp_path / "g.gfa")
+    open(gfa, "w").write("S\t1:5.1\tACGT\n")
+    ok = '{"1:1-4@+@1:5-9@+": [["1:DEL-4-9", 0]]}'
+    cases = {
+        "escape": '{"1:1-4@+@1:5-9@+": [["1:DEL\\u002d4-9", 0]]}',
+        "unicode": '{"1:1-4@+@1:5-9@+": [["é:DEL-4-9", 0]]}',
+        "duplicate": '{"1:1-4@+@1:5-9@+": [["a", 0]], "1:1-4@+@1:5-9@+": [["b", 0]]}',
+        "allele2": '{"1:1-4@+@1:5-9@+": [["a", 2]]}',
+        "allele_true": '{"1:1-4@+@1:5-9@+": [["a", true]]}',
+        "allele_float": '{"1:1-4@+@1:5-9@+": [["a", 0.0]]}',
+        "leading_zero": '{"1:01-4@+@1:5-9@+": [["a", 0]]}',
+        "no_colon": '{"x@+@1:5-9@+": [["a", 0]]}',
+        "bad_strand": '{"1:1-4@*@1:5-9@+": [["a", 0]]}',
+        "five_parts": '{"1:1-4@+@1:5-9@+@x": [["a", 0]]}',
+        "end_before_start": '{"1:9-4@+@1:5-9@+": [["a", 0]]}',
+        "same_coordinate": '{"1:1-4@+@1:1-9@+": [["a", 0]]}',
+        "trailing": ok + " x",
+        "not_a_dict": "[]",
+    }
+    for name, text in cases.items():
+        p = str(tmp_path / f"{name}.json")
+        open(p, "w", encoding="utf-8").write(text)
+        assert capi.graph_load_native(p, gfa) is None, name
+    p = str(tmp_path / "ok.json")
+    open(p, "w").write(ok)
+    assert capi.graph_load_native(p, gfa) is not None
+    for name, g in {"cr": "S\t1:5.1\tACGT\r\n", "two_columns": "S\t1:5.1\n", "empty_sequence": "S\t1:5.1\t\n", "utf8": "S\t1:5.1\tACGé\n"}.items():
+        q = str(tmp_path / f"{name}.gfa")
+        open(q, "w", encoding="utf-8", newline="").write(g)
+        assert capi.graph_load_native(p, q) is None, name
+    with pytest.raises(OSError):
+        capi.graph_load_native(str(tmp_path / "missing.json"), gfa)
