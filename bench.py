@@ -99,7 +99,7 @@ def main():
         ctx.classify_resident(base_offset=0, want_hits=False)
         if group is not None:
             group.allreduce_counts()
-        return ctx.genotype(rows.sv_type, rows.slot, rows.ok, 3, 0.00005)
+        return ctx.genotype(rows.sv_type, rows.slot, rows.ok, 3, 0.00005, reuse_outputs=True)
 
     for _ in range(args.warmup):
         step()

@@ -41,6 +41,7 @@ struct svjg_ctx {
     dd *d_logfact = nullptr;  uint32_t logfact_n = 0;  dd *d_bsum = nullptr;
     unsigned int *d_maxn = nullptr;
     void *d_rows = nullptr;  uint64_t rows_cap = 0;
+    void *h_rows = nullptr;  uint64_t h_rows_cap = 0;   // pinned twin of d_rows
     // timing of the last calls
     float ms_main = 0, ms_slow = 0, ms_geno = 0;
     // rccl
@@ -113,6 +114,7 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     free_graph(c);
     hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
     hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows);
+    if (c->h_rows) hipHostFree(c->h_rows);
     for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -387,53 +389,63 @@ extern "C" int svjg_genotype(svjg_ctx *c, const uint8_t *sv_type, const uint32_t
     HIPCHK(c, hipSetDevice(c->device));
     for (uint64_t r = 0; r < n_rows; ++r)
         if (slot[r] != NONE32 && slot[r] >= c->n_slots) { c->err = "slot out of range"; return SVJG_E_ARG; }
-    // one device block: in = type[1] ok[1] slot[4] ; out = gt[1] done[1] raw[8] pl[24]
-    const uint64_t per_row = 1 + 1 + 4 + 1 + 1 + 8 + 24;
-    int rc = ensure(c, &c->d_rows, &c->rows_cap, n_rows * per_row + 256, 1, false);
+    // one device block and its pinned host twin: [ pl 24 | raw 8 | gt 1 | done 1 ] n rows of output, max_n, then
+    // [ slot 4 | type 1 | ok 1 ] n rows of input -> ONE copy in and ONE copy out per call whatever the number of arrays
+    const uint64_t out_bytes = n_rows * 34, maxn_off = (out_bytes + 7) & ~7ull, in_off = maxn_off + 8, in_bytes = n_rows * 6;
+    const uint64_t total = in_off + in_bytes + 64;
+    int rc = ensure(c, &c->d_rows, &c->rows_cap, total, 1, false);
     if (rc) return rc;
-    uint8_t *base = (uint8_t *)c->d_rows;
-    int64_t *d_pl = (int64_t *)base;                       base += n_rows * 24;
-    uint32_t *d_raw = (uint32_t *)base;                    base += n_rows * 8;
-    uint32_t *d_slot = (uint32_t *)base;                   base += n_rows * 4;
-    uint8_t *d_type = base;                                base += n_rows;
-    uint8_t *d_ok = base;                                  base += n_rows;
-    uint8_t *d_gt = base;                                  base += n_rows;
-    uint8_t *d_done = base;
-    HIPCHK(c, hipMemcpyAsync(d_slot, slot, n_rows * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_type, sv_type, n_rows, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_ok, ok, n_rows, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_maxn, 0, sizeof(unsigned int), c->stream));
+    if (total > c->h_rows_cap) {
+        if (c->h_rows) hipHostFree(c->h_rows);
+        c->h_rows = nullptr; c->h_rows_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_rows, total, hipHostMallocDefault));
+        c->h_rows_cap = total;
+    }
+    uint8_t *base = (uint8_t *)c->d_rows, *hb = (uint8_t *)c->h_rows;
+    int64_t *d_pl = (int64_t *)base;
+    uint32_t *d_raw = (uint32_t *)(base + n_rows * 24);
+    uint8_t *d_gt = base + n_rows * 32, *d_done = base + n_rows * 33;
+    unsigned int *d_maxn = (unsigned int *)(base + maxn_off);
+    uint32_t *d_slot = (uint32_t *)(base + in_off);
+    uint8_t *d_type = base + in_off + n_rows * 4, *d_ok = base + in_off + n_rows * 5;
+    memcpy(hb + in_off, slot, n_rows * 4); memcpy(hb + in_off + n_rows * 4, sv_type, n_rows); memcpy(hb + in_off + n_rows * 5, ok, n_rows);
+    HIPCHK(c, hipMemcpyAsync(base + in_off, hb + in_off, in_bytes, hipMemcpyHostToDevice, c->stream));
     GenoArgs a{};
     a.counts = c->d_counts; a.sv_type = d_type; a.slot = d_slot; a.ok = d_ok; a.n_rows = n_rows; a.min_support = min_support;
     a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
-    a.gt = d_gt; a.pl = d_pl; a.raw = d_raw; a.genotyped = d_done; a.max_n = c->d_maxn;
+    a.gt = d_gt; a.pl = d_pl; a.raw = d_raw; a.genotyped = d_done; a.max_n = d_maxn;
     const uint32_t grid = (uint32_t)((n_rows + TPB - 1) / TPB);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    hipLaunchKernelGGL(k_geno_maxn, dim3(grid), dim3(TPB), 0, c->stream, a);
-    unsigned int max_n = 0;
-    HIPCHK(c, hipMemcpyAsync(&max_n, c->d_maxn, sizeof max_n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (max_n + 1 > c->logfact_n) {
-        uint32_t want = max_n + 1 + 1024;
-        want = (want + LF_BLOCK - 1) / LF_BLOCK * LF_BLOCK;
-        hipFree(c->d_logfact); hipFree(c->d_bsum); c->d_logfact = nullptr; c->d_bsum = nullptr; c->logfact_n = 0;
-        HIPCHK(c, hipMalloc((void **)&c->d_logfact, (uint64_t)want * sizeof(dd)));
-        HIPCHK(c, hipMalloc((void **)&c->d_bsum, (uint64_t)(want / LF_BLOCK) * sizeof(dd)));
-        hipLaunchKernelGGL(k_logfact_local, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
-        hipLaunchKernelGGL(k_logfact_bsum, dim3(1), dim3(64), 0, c->stream, c->d_bsum, want / LF_BLOCK);
-        hipLaunchKernelGGL(k_logfact_add, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
+    // One pass with the log10(i!) table at hand; the kernel reports the largest n = ref + alt it met beyond the table, and
+    // only then (first call, or a deeper sample than ever before) the table is rebuilt and the pass repeated.
+    uint32_t grow_to = 65536;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (c->logfact_n == 0) {
+            uint32_t want = (grow_to + LF_BLOCK - 1) / LF_BLOCK * LF_BLOCK;
+            hipFree(c->d_logfact); hipFree(c->d_bsum); c->d_logfact = nullptr; c->d_bsum = nullptr;
+            HIPCHK(c, hipMalloc((void **)&c->d_logfact, (uint64_t)want * sizeof(dd)));
+            HIPCHK(c, hipMalloc((void **)&c->d_bsum, (uint64_t)(want / LF_BLOCK) * sizeof(dd)));
+            hipLaunchKernelGGL(k_logfact_local, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
+            hipLaunchKernelGGL(k_logfact_bsum, dim3(1), dim3(64), 0, c->stream, c->d_bsum, want / LF_BLOCK);
+            hipLaunchKernelGGL(k_logfact_add, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
+            HIPCHK(c, hipGetLastError());
+            c->logfact_n = want;
+        }
+        a.logfact = c->d_logfact; a.logfact_n = c->logfact_n;
+        HIPCHK(c, hipMemsetAsync(d_maxn, 0, 8, c->stream));
+        hipLaunchKernelGGL(k_genotype, dim3(grid), dim3(TPB), 0, c->stream, a);
         HIPCHK(c, hipGetLastError());
-        c->logfact_n = want;
+        if (attempt == 0) HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+        HIPCHK(c, hipMemcpyAsync(hb, base, maxn_off + 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const unsigned int max_n = *(const unsigned int *)(hb + maxn_off);
+        if (max_n == 0) break;                               // every row found its binomial term
+        if (attempt == 1) { c->err = "log10(i!) table could not be sized"; return SVJG_E_HIP; }
+        grow_to = max_n + 1 + 1024;
+        c->logfact_n = 0;                                    // rebuild, sized by max_n
     }
-    a.logfact = c->d_logfact; a.logfact_n = c->logfact_n;
-    hipLaunchKernelGGL(k_genotype, dim3(grid), dim3(TPB), 0, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    HIPCHK(c, hipMemcpyAsync(pl, d_pl, n_rows * 24, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(raw, d_raw, n_rows * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(gt, d_gt, n_rows, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(genotyped, d_done, n_rows, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(pl, hb, n_rows * 24); memcpy(raw, hb + n_rows * 24, n_rows * 8);
+    memcpy(gt, hb + n_rows * 32, n_rows); memcpy(genotyped, hb + n_rows * 33, n_rows);
     HIPCHK(c, hipEventElapsedTime(&c->ms_geno, c->ev[4], c->ev[5]));
     return 0;
 }

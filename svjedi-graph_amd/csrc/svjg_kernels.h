@@ -857,6 +857,7 @@ __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
     uint32_t n = r1 + r2;
     dd comb{0.0, 0.0};
     if (n < a.logfact_n) comb = dd_add(dd_add(a.logfact[n], dd_neg(a.logfact[n - r1])), dd_neg(a.logfact[r1]));
+    else atomicMax(a.max_n, n);                          // the log10(i!) table is too short: the host grows it and runs the pass again
     comb = dd{comb.hi, 0.0};                             // the reference rounds log10(comb) to a double first (:313)
     dd ls[3] = {l0, l1, l2};
 #pragma unroll

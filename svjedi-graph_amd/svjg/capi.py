@@ -278,15 +278,23 @@ class Context:
     def allreduce_counts(self):
         self._chk(self.lib.svjg_allreduce_counts(self.h))
 
-    def genotype(self, sv_type, slot, ok, min_support, err):
+    def genotype(self, sv_type, slot, ok, min_support, err, reuse_outputs=False):
+        """reuse_outputs: hand back the same four arrays on every call (they are overwritten by the next call): a loop that
+        genotypes again and again then does not pay for fresh pages each time."""
         n = len(sv_type)
         sv_type = np.ascontiguousarray(sv_type, dtype=np.uint8)
         slot = np.ascontiguousarray(slot, dtype=np.uint32)
         ok = np.ascontiguousarray(ok, dtype=np.uint8)
-        gt = np.zeros(n, dtype=np.uint8)
-        pl = np.zeros((n, 3), dtype=np.int64)
-        raw = np.zeros((n, 2), dtype=np.uint32)
-        done = np.zeros(n, dtype=np.uint8)
+        cached = getattr(self, "_geno_out", None)
+        if reuse_outputs and cached is not None and len(cached[0]) == n:
+            gt, pl, raw, done = cached
+        else:
+            gt = np.empty(n, dtype=np.uint8)
+            pl = np.empty((n, 3), dtype=np.int64)
+            raw = np.empty((n, 2), dtype=np.uint32)
+            done = np.empty(n, dtype=np.uint8)
+            if reuse_outputs:
+                self._geno_out = (gt, pl, raw, done)
         self._chk(self.lib.svjg_genotype(self.h, sv_type.ctypes.data, slot.ctypes.data, ok.ctypes.data, n, min_support,
                                          float(err), gt.ctypes.data, pl.ctypes.data, raw.ctypes.data, done.ctypes.data))
         return gt, pl, raw, done
