@@ -1,7 +1,7 @@
 // HIP kernels of libsvjg_hip.so (gfx950 / MI355X, wave64).  No MFMA anywhere: this is byte / integer
 // work bounded by HBM reads.
 //
-//   k_classify_main  persistent workgroups over 32 KB stripes of GAF text (see the comment in front of the kernel):
+//   k_classify_main  persistent workgroups over 16 KB stripes of GAF text (see the comment in front of the kernel):
 //                      coalesced HBM -> register -> LDS staging, SWAR byte classes, rank-indexed lists of line
 //                      starts / tabs / orientation marks, then loop-free per-line, per-node and per-link phases with
 //                      node-name and link hash tables, packed 64-bit (ref | alt << 32) atomics into the per-SV count vector
@@ -15,19 +15,19 @@
 namespace svjg {
 
 #ifndef SVJG_WG
-#define SVJG_WG 512
+#define SVJG_WG 256
 #endif
-constexpr uint32_t WG = SVJG_WG;                 // classify kernel: 8 waves per workgroup, two workgroups per CU (LDS / register bound) = 16 waves / CU
+constexpr uint32_t WG = SVJG_WG;                 // classify kernel: 4 waves per workgroup, four workgroups per CU (123 VGPRs -> 16 waves / CU; 31 KB of LDS each)
 constexpr uint32_t NWAVE = WG / 64;
 constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
 constexpr uint32_t PIECES = 4;                   // 16-byte pieces of text per lane and stripe
 constexpr uint32_t SPAN = PIECES * 16;           // bytes of byte classification per lane: one 64-bit mask per byte class
-constexpr uint32_t TEXT = SPAN * WG;             // 32 KB staged in LDS
+constexpr uint32_t TEXT = SPAN * WG;             // 16 KB staged in LDS
 // A stripe = the bytes of text whose lines one workgroup iteration owns = TEXT minus a look-ahead that lets lines
 // starting near its end be complete.  The look-ahead is a launch parameter (ClassifyArgs::chunk = TEXT - look-ahead): the
 // host starts at LOOK_MIN and doubles it, up to LOOK_MAX, when a batch had many lines cut off by the staged text (they
 // go to the exact path, which is correct but slow), so short-line files do not pay for long-line ones.
-constexpr uint32_t LOOK_MIN = 1024, LOOK_MAX = 16384;
+constexpr uint32_t LOOK_MIN = 1024, LOOK_MAX = TEXT / 2;
 // Phase B turns the staged text into rank-indexed lists (all positions are offsets into the staged text):
 constexpr uint32_t MAXL = TEXT / 64;                 // line starts per stripe (a stripe with more goes to the exact path as a whole)
 constexpr uint32_t CAP_T = TEXT / 8;                // tab positions per stripe
