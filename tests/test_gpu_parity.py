@@ -352,3 +352,52 @@ def test_sharded_and_chunked_ingest_is_the_same_file(golden, tmp_path, monkeypat
     monkeypatch.delenv("SVJG_NO_HANDOFF")
     with pytest.raises(ValueError):
         flt.classify_sharded(g, pre + "_bad.gaf", devices=[0, 0])
+
+
+def test_fuzz_cases(ctx, golden):
+    """The 500 mutated GAF fragments of golden/fuzz (outcomes recorded from the reference itself): every fragment alone,
+    then all the accepted ones in one file (the counts add up), then each fatal one behind a run of good lines."""
+    import base64
+    from svjg.graph import Graph
+    from tests.test_fuzz_golden import documented_divergence
+    t = f"{golden}/testdir"
+    g = Graph.from_files(f"{t}/test_svs_edges.json", f"{t}/test.gfa")
+    cases = json.load(open(f"{golden}/fuzz/fuzz.json"))["cases"]
+    ctx.load_graph(g)
+    total, good, n_dev = {}, [], 0
+    def skip(c, raw):
+        # DESIGN.md §8: Unicode digits in decimal columns; a malformed id:f: tag (the main kernel does not read tags)
+        return documented_divergence({"raw": raw}) or (c["rc"] and c["error"] == "ValueError" and b"id:f:" in raw)
+
+    for i, c in enumerate(cases):
+        raw = base64.b64decode(c["gaf"])
+        if skip(c, raw):
+            continue
+        ctx.reset_counts()
+        try:
+            ctx.classify(np.frombuffer(raw, dtype=np.uint8))
+            if ctx.stats()["non_ascii"]:
+                raw.decode("utf-8")                    # the host's check (svjg/filter.py), as the reference's text-mode read
+            got = ("ok", _counts_dict(g, ctx.counts()))
+        except Exception as e:
+            got = ("died", type(e).__name__)
+        want = ("ok", c["counts"]) if c["rc"] == 0 else ("died", c["error"])
+        assert got == want, (i, raw)
+        if c["rc"] == 0:
+            n_dev += ctx.stats()["n_deferred"]
+            good.append(raw if raw.endswith((b"\n", b"\r")) else raw + b"\n")
+            for k, v in c["counts"].items():
+                a = total.setdefault(k, [0, 0]); a[0] += v[0]; a[1] += v[1]
+    assert n_dev < len(good)                           # most fragments stay in the main kernel
+    ctx.reset_counts()
+    ctx.classify(np.frombuffer(b"".join(good) * 7, dtype=np.uint8))
+    assert _counts_dict(g, ctx.counts()) == {k: [7 * v[0], 7 * v[1]] for k, v in total.items()}
+    pad = b"".join(good[:40])
+    for i, c in enumerate(cases):
+        raw = base64.b64decode(c["gaf"])
+        if c["rc"] == 0 or c["error"] == "UnicodeDecodeError" or skip(c, raw):
+            continue
+        ctx.reset_counts()
+        with pytest.raises(Exception) as ei:
+            ctx.classify(np.frombuffer(pad + raw + (b"" if raw.endswith((b"\n", b"\r")) else b"\n") + pad, dtype=np.uint8))
+        assert type(ei.value).__name__ == c["error"], (i, raw)
