@@ -13,6 +13,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -117,6 +118,8 @@ extern "C" int svjg_write_informative_json(const char *path, const char *gaf, ui
                                            uint64_t n_recs, const char *const *sv_ids, uint32_t n_slots, int n_threads)
 {
     if (!path || (n_bytes && !gaf) || (n_recs && !recs_in) || (n_slots && !sv_ids)) return SVJG_E_ARG;
+    const bool verbose = getenv("SVJG_VERBOSE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
     // group by slot (counting sort), then file order inside each group
     std::vector<uint64_t> begin((size_t)n_slots + 1, 0);
     for (uint64_t i = 0; i < n_recs; ++i) { if (recs_in[i].slot >= n_slots) return SVJG_E_ARG; begin[recs_in[i].slot + 1]++; }
@@ -192,12 +195,18 @@ extern "C" int svjg_write_informative_json(const char *path, const char *gaf, ui
     };
     int rc = 0;
     if (!put("{", 1, 0)) rc = SVJG_E_NOMEM;
+    const auto t_mid = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
     if (!rc) for (int i = 0; i < T; ++i) th.emplace_back(worker);
     for (auto &x : th) x.join();
     if (!rc && bad.load()) rc = bad.load() == 1 ? SVJG_E_INPUT : SVJG_E_NOMEM;
     if (!rc && !put("\n}", 2, off[n_tasks])) rc = SVJG_E_NOMEM;
     if (close(fd) && !rc) rc = SVJG_E_NOMEM;
+    if (verbose) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[svjg] json writer: group + sort %.2f s, render + write %.2f s (%d threads, %llu tasks)\n",
+                std::chrono::duration<double>(t_mid - t_start).count(), std::chrono::duration<double>(t_end - t_mid).count(), T, (unsigned long long)n_tasks);
+    }
     return rc;
 }
 

@@ -163,6 +163,7 @@ def write_informative_json(path, gaf, recs, sv_ids, n_threads=0):
     """<prefix>_informative_aln.json from hit records (filter-alignments.py:174-175)."""
     lib = load_host_library()
     a = _as_u8(gaf)
+    n_threads = n_threads or int(os.environ.get("SVJG_JSON_THREADS", "0"))
     recs = np.ascontiguousarray(recs, dtype=HITREC_DT)
     keys = (ctypes.c_char_p * max(1, len(sv_ids)))(*[s.encode("utf-8") for s in sv_ids])
     rc = lib.svjg_write_informative_json(os.fsencode(path), a.ctypes.data if a.size else None, a.size,

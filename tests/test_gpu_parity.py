@@ -401,3 +401,22 @@ def test_fuzz_cases(ctx, golden):
         with pytest.raises(Exception) as ei:
             ctx.classify(np.frombuffer(pad + raw + (b"" if raw.endswith((b"\n", b"\r")) else b"\n") + pad, dtype=np.uint8))
         assert type(ei.value).__name__ == c["error"], (i, raw)
+
+
+def test_stripes_the_lists_cannot_hold(ctx, tmp_path):
+    """Stripes with more tabs or orientation marks than the per-stripe lists of the main kernel hold are handed to the
+    exact path as a whole: lines with hundreds of tags, a tag full of '<' '>', both mixed with ordinary lines."""
+    pre, gaf, g, orc = _synth_case(tmp_path, 3000, 300, 2, "mixed", 123)
+    lines = gaf.tobytes().split(b"\n")[:-1]
+    many_tags = b"".join(b"\tx%d:i:%d" % (i % 10, i) for i in range(400))
+    marks = b"\tzz:Z:" + b"<>" * 1500
+    out = []
+    for i, l in enumerate(lines):
+        out.append(l + (many_tags if i % 7 == 3 else marks if i % 11 == 5 else b""))
+    data = b"\n".join(out) + b"\n"
+    want, _, n_lines = orc.filter(data, want_hits=False)
+    ctx.load_graph(g)
+    ctx.classify(np.frombuffer(data, dtype=np.uint8))
+    assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
+    st = ctx.stats()
+    assert st["n_lines"] == n_lines and st["n_deferred"] > 100
