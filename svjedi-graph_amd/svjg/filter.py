@@ -42,6 +42,15 @@ def read_gaf(path):
     return np.memmap(path, dtype=np.uint8, mode="r")
 
 
+def check_utf8(data):
+    """UnicodeDecodeError like the reference's text-mode read, without copying the whole file: 64 MB at a time."""
+    import codecs
+    dec = codecs.getincrementaldecoder("utf-8")()
+    n = int(data.size)
+    for a in range(0, n, 1 << 26):
+        dec.decode(bytes(data[a:a + (1 << 26)]), final=a + (1 << 26) >= n)
+
+
 def _stamp(t, what):
     """stage timers on stderr when SVJG_VERBOSE is set (measurement only)"""
     if os.environ.get("SVJG_VERBOSE"):
@@ -93,7 +102,7 @@ def classify_file(ctx, graph, gaf_path, want_hits=True):
         if b > a:
             ctx.classify(data[a:b], base_offset=a, want_hits=want_hits)
     if ctx.stats()["non_ascii"]:
-        bytes(data).decode("utf-8")               # UnicodeDecodeError like the reference's text-mode read
+        check_utf8(data)
     return ctx.counts(), (ctx.hits() if want_hits else None), data
 
 
@@ -120,7 +129,7 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
             raise err
     _stamp(t, f"tables -> device, upload + classify on {len(devs)} GPU(s)")
     if any(o[2]["non_ascii"] for o in out):
-        bytes(data).decode("utf-8")               # UnicodeDecodeError like the reference's text-mode read
+        check_utf8(data)
     total = np.zeros((graph.n_slots, 2), dtype=np.uint64)
     for o in out:
         total += o[0]
