@@ -282,7 +282,8 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
             c->total_deferred += n_def;
             // many lines ran past the staged text (long lines): widen the look-ahead for the following batches
             const uint64_t cut = c->h_st.n_incomplete - before.n_incomplete, lines = c->h_st.n_lines - before.n_lines;
-            if (cut * 256 > lines && c->look < LOOK_MAX) c->look *= 2;
+            // (up to 2 KB already when one line in 4096 was cut: the exact path has milliseconds of latency; beyond, one in 256)
+            if (c->look < LOOK_MAX && (cut * 256 > lines || (c->look < 2048 && cut * 4096 > lines))) c->look *= 2;
             break;
         }
         // roll back and retry with worst-case buffers

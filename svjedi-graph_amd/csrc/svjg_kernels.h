@@ -25,9 +25,12 @@ constexpr uint32_t SPAN = PIECES * 16;           // bytes of byte classification
 constexpr uint32_t TEXT = SPAN * WG;             // 16 KB staged in LDS
 // A stripe = the bytes of text whose lines one workgroup iteration owns = TEXT minus a look-ahead that lets lines
 // starting near its end be complete.  The look-ahead is a launch parameter (ClassifyArgs::chunk = TEXT - look-ahead): the
-// host starts at LOOK_MIN and doubles it, up to LOOK_MAX, when a batch had many lines cut off by the staged text (they
-// go to the exact path, which is correct but slow), so short-line files do not pay for long-line ones.
-constexpr uint32_t LOOK_MIN = 1024, LOOK_MAX = TEXT / 2;
+// host starts at LOOK_MIN and doubles it, up to LOOK_MAX, when a batch had lines cut off by the staged text (they go
+// to the exact path, which is correct but slow), so short-line files do not pay for long-line ones.
+#ifndef SVJG_LOOK_MIN
+#define SVJG_LOOK_MIN 512
+#endif
+constexpr uint32_t LOOK_MIN = SVJG_LOOK_MIN, LOOK_MAX = TEXT / 2;
 // Phase B turns the staged text into rank-indexed lists (all positions are offsets into the staged text):
 constexpr uint32_t MAXL = TEXT / 64;                 // line starts per stripe (a stripe with more goes to the exact path as a whole)
 constexpr uint32_t CAP_T = TEXT / 8;                // tab positions per stripe
