@@ -59,10 +59,9 @@ constexpr uint32_t L_LT = L_LS + (MAXL + 8) * 2;                           // u1
 constexpr uint32_t L_LO = L_LT + (MAXL + 8) * 2;                           // u16[MAXL + 8]    orientation marks in front of line #l
 constexpr uint32_t L_MISC = L_LO + (MAXL + 8) * 2;                         // u32[32]: [1] stripe holds a byte >= 0x80, [8 + w] / [16 + w] scan totals of wave w
 constexpr uint32_t L_WAVE = L_MISC + 128;
-constexpr uint32_t W_TS = 0;                                               // u32[LRW]  path start column
-constexpr uint32_t W_TE = W_TS + LRW * 4;                                  // u32[LRW]
-constexpr uint32_t W_TLEN = W_TE + LRW * 4;                                // u32[LRW]
-constexpr uint32_t W_META = W_TLEN + LRW * 4;                              // u32[LRW]  first mark of the line (relative to the round) | k << 16 | status << 24
+constexpr uint32_t W_NEEDL = 0;                                            // u32[LRW]  path length a link's left side must reach (Ts + d_over)
+constexpr uint32_t W_NEEDR = W_NEEDL + LRW * 4;                            // u32[LRW]  ... and its right side (d_over + Tlen - Te - 1)
+constexpr uint32_t W_META = W_NEEDR + LRW * 4;                             // u32[LRW]  first mark of the line (relative to the round) | k << 16 | status << 24
 constexpr uint32_t W_PEND = W_META + LRW * 4;                              // u16[LRW]  tab after the path column
 constexpr uint32_t WAVE_BYTES = (W_PEND + LRW * 2 + 15) / 16 * 16;
 constexpr uint32_t LDS_MAIN = L_WAVE + NWAVE * WAVE_BYTES;
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t *wb = lds + L_WAVE + wave * WAVE_BYTES;                    // this wave's private arrays
-    uint32_t *l_ts = (uint32_t *)(wb + W_TS), *l_te = (uint32_t *)(wb + W_TE), *l_tlen = (uint32_t *)(wb + W_TLEN);
+    uint32_t *l_need_l = (uint32_t *)(wb + W_NEEDL), *l_need_r = (uint32_t *)(wb + W_NEEDR);
     uint32_t *l_meta = (uint32_t *)(wb + W_META);
     uint16_t *l_pend = (uint16_t *)(wb + W_PEND);
 
@@ -475,9 +474,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (ok) ok = (uint32_t)OP[o0] == t4 + 1 && (uint32_t)OP[o0 + k - 1] < t5;
                         if (ok) {
                             status = k >= 2 ? ST_OK : ST_NOHIT;
-                            l_tlen[li] = field_val(text, t5 + 1, t6 - t5 - 1);
-                            l_ts[li] = field_val(text, t6 + 1, t7 - t6 - 1);
-                            l_te[li] = field_val(text, t7 + 1, t8 - t7 - 1);
+                            // check_bkpt_overlap (filter-alignments.py:258-273) for a link of this line reads
+                            //   sum(len up to the left node) - Ts >= d_over  and  sum(len from the right node) - (Tlen - Te - 1) >= d_over:
+                            // the two right-hand sides are fixed per line (clamped to 32 bits: the sums stay below 2^31)
+                            const long long tlen = field_val(text, t5 + 1, t6 - t5 - 1), ts = field_val(text, t6 + 1, t7 - t6 - 1), te = field_val(text, t7 + 1, t8 - t7 - 1);
+                            const long long need_l = ts + (long long)g.d_over, need_r = (long long)g.d_over + tlen - te - 1;
+                            l_need_l[li] = need_l > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)need_l;
+                            l_need_r[li] = need_r < 0 ? 0u : need_r > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)need_r;
                             l_pend[li] = (uint16_t)t5;
                         }
                     }
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // -- the node of this lane: line, index in the line, name --
                 const bool act = lane < n_pass;
                 const uint32_t o = obase + p0 + lane;
-                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, oribit = 0, meta = 0, d[8];
+                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, oribit = 0, meta = 0, need_l = 0, need_r = 0, d[8];
                 uint64_t h = 0;
                 bool live = false, probe = false;
                 if (act) {
@@ -511,6 +514,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     ln = (uint32_t)OL[o] - lbase;
                     meta = l_meta[ln];
                     const uint32_t pend = l_pend[ln];
+                    need_l = l_need_l[ln]; need_r = l_need_r[ln];
                     live = (meta >> 24) == ST_OK;
                     lnb = (meta & 0xFFFFu) - p0; lk = (meta >> 16) & 0xFFu; j = lane - lnb;
                     if (live) {
@@ -580,10 +584,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 bool go = false;
                 uint32_t klo = 0, khi = 0;
                 if (live && j + 1 < lk) {
-                    const long long left = (long long)pre_l - (long long)l_ts[ln];
-                    const long long pre_excl_r = fr > lnb ? (long long)pre_rx : 0;
-                    const long long right = (long long)tot - pre_excl_r - ((long long)l_tlen[ln] - (long long)l_te[ln] - 1);
-                    go = left >= (long long)g.d_over && right >= (long long)g.d_over;
+                    go = pre_l >= need_l && tot - (fr > lnb ? pre_rx : 0u) >= need_r;
                     klo = (idr << 1) | orr; khi = (idl << 1) | orl;
                 }
                 // the link is looked for among the (up to four) that sit in the left node's record; the link table is asked only
