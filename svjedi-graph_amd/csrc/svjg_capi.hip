@@ -31,6 +31,7 @@ struct svjg_ctx {
     uint8_t *d_gaf = nullptr;  uint64_t gaf_cap = 0, gaf_bytes = 0;  bool have_gaf = false;
     // outputs
     uint64_t *d_deferred = nullptr;  uint64_t deferred_cap = 0;
+    uint64_t *d_cut = nullptr;       uint64_t cut_cap = 0;
     svjg_hitrec *d_recs = nullptr;   uint64_t rec_cap = 0;
     DevStatus *d_st = nullptr;
     unsigned long long *d_dbg = nullptr;
@@ -112,7 +113,7 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     free_graph(c);
-    hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
+    hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_cut); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
     hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows);
     if (c->h_rows) hipHostFree(c->h_rows);
     for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
@@ -130,7 +131,7 @@ static int upload(svjg_ctx *c, T **dst, const T *src, uint64_t n, uint64_t extra
 static int reset_status(svjg_ctx *c, bool all) {
     DevStatus s = c->h_st;
     if (all) { memset(&s, 0, sizeof s); c->total_deferred = 0; }
-    s.n_deferred = 0; s.overflow = 0;
+    s.n_deferred = 0; s.overflow = 0; s.n_cut = 0;
     if (all) s.err = ~0ull;
     c->h_st = s;
     HIPCHK(c, hipMemcpyAsync(c->d_st, &c->h_st, sizeof s, hipMemcpyHostToDevice, c->stream));
@@ -243,7 +244,7 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         a.gaf = c->d_gaf; a.n_bytes = n; a.base_offset = base_offset; a.g = c->gv;
         a.all_slow = all_slow; a.want_hits = want_hits != 0;
         { const char *lk = getenv("SVJG_LOOK"); if (lk) { uint32_t v = (uint32_t)atoi(lk) & ~15u; if (v >= 256 && v <= LOOK_MAX) c->look = v; } }   // measurement knob
-        a.chunk = TEXT - c->look;
+        a.chunk = TEXT - c->look; a.starts = nullptr;
         a.n_chunks = (uint32_t)((n + a.chunk - 1) / a.chunk);
         { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob for profiling only
         a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
@@ -261,6 +262,21 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         uint64_t n_def = c->h_st.n_deferred;
+        // lines cut off by the staged text of their stripe: a second launch of the same kernel, one stripe per such line
+        // (the line then has the whole staged text to itself); what still does not fit goes to the exact path
+        const uint64_t n_cut = c->h_st.n_incomplete - before.n_incomplete;
+        if (n_cut && !all_slow && !c->h_st.overflow) {
+            if ((rc = ensure(c, (void **)&c->d_cut, &c->cut_cap, n_cut + 64, sizeof(uint64_t), false))) return rc;
+            hipLaunchKernelGGL(k_pick_cut, dim3((uint32_t)((n_def + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->d_deferred, n_def, c->d_cut, &c->d_st->n_cut);
+            ClassifyArgs a2 = a;
+            a2.starts = c->d_cut; a2.n_chunks = (uint32_t)n_cut;
+            hipLaunchKernelGGL(k_classify_main, dim3(a2.n_chunks < full ? a2.n_chunks : full), dim3(WG), lds, c->stream, a2);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+            HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            n_def = c->h_st.n_deferred;
+        }
         if (a.diag & 16u) {
             unsigned long long d[8];
             HIPCHK(c, hipMemcpy(d, c->d_dbg, sizeof d, hipMemcpyDeviceToHost));
@@ -279,11 +295,11 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         }
         HIPCHK(c, hipEventElapsedTime(&c->ms_main, c->ev[0], c->ev[1]));
         if (!c->h_st.overflow) {
-            c->total_deferred += n_def;
+            c->total_deferred += n_def - n_cut;                       // lines that took the exact path (cut lines went through the second launch)
             // many lines ran past the staged text (long lines): widen the look-ahead for the following batches
             const uint64_t cut = c->h_st.n_incomplete - before.n_incomplete, lines = c->h_st.n_lines - before.n_lines;
-            // (up to 2 KB already when one line in 4096 was cut: the exact path has milliseconds of latency; beyond, one in 256)
-            if (c->look < LOOK_MAX && (cut * 256 > lines || (c->look < 2048 && cut * 4096 > lines))) c->look *= 2;
+            // (a cut line costs a stripe of its own in the second launch: worth a wider look-ahead from one line in 256 on)
+            if (c->look < LOOK_MAX && cut * 256 > lines) c->look *= 2;
             break;
         }
         // roll back and retry with worst-case buffers

@@ -57,7 +57,7 @@ constexpr uint32_t L_OL = L_OP + (CAP_O + 8) * 2;                          // u1
 constexpr uint32_t L_LS = L_OL + (CAP_O + 8) * 2;                          // u16[MAXL + 8]    start of line #l ; [n] = 0xFFFF
 constexpr uint32_t L_LT = L_LS + (MAXL + 8) * 2;                           // u16[MAXL + 8]    tabs in front of line #l
 constexpr uint32_t L_LO = L_LT + (MAXL + 8) * 2;                           // u16[MAXL + 8]    orientation marks in front of line #l
-constexpr uint32_t L_MISC = L_LO + (MAXL + 8) * 2;                         // u32[32]: [1] stripe holds a byte >= 0x80, [8 + w] / [16 + w] scan totals of wave w
+constexpr uint32_t L_MISC = L_LO + (MAXL + 8) * 2;                         // u32[32]: [1] stripe holds a byte >= 0x80, [2] line starts in front of the owned range, [8 + w] / [16 + w] scan totals of wave w
 constexpr uint32_t L_WAVE = L_MISC + 128;
 constexpr uint32_t W_NEEDL = 0;                                            // u32[LRW]  path length a link's left side must reach (Ts + d_over)
 constexpr uint32_t W_NEEDR = W_NEEDL + LRW * 4;                            // u32[LRW]  ... and its right side (d_over + Tlen - Te - 1)
@@ -74,6 +74,7 @@ struct DevStatus {
     unsigned long long n_recs;           // hit records appended
     unsigned long long err;              // min over (file offset << 3 | exception class); ~0 = none
     unsigned long long n_incomplete;     // lines deferred because they run past the staged text
+    unsigned long long n_cut;            // k_pick_cut: entries of the second launch's list
     unsigned int non_ascii;
     unsigned int overflow;               // bit 0: deferred list, bit 1: hit-record buffer
 };
@@ -87,6 +88,8 @@ struct ClassifyArgs {
     uint32_t want_hits;
     uint32_t n_chunks;
     uint32_t chunk;                      // stripe stride in bytes (multiple of 16, TEXT - look-ahead)
+    const uint64_t *starts;              // second launch only: n_chunks line starts; every stripe begins at one of them and owns that ONE line
+                                         // (lines the first launch found cut off by its staged text: here they have the whole TEXT to themselves)
     uint32_t diag;                       // measurement only (SVJG_DIAG): 1 stop after B, 2 stop after R2, 4 no node lookup, 8 no atomics
     unsigned long long *counts;          // [n_slots] ref | alt << 32
     uint64_t *deferred;  uint64_t deferred_cap;
@@ -155,6 +158,7 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *slot, uint32_t 
 }
 
 enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round
+constexpr unsigned long long DEFER_CUT = 1ull << 63;                    // deferred-list entry: the line was cut off by the staged text
 
 // Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the 64-bit pre-hash of the node-name table
 // (svjg_line.h: name_prehash).
@@ -323,8 +327,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     // stripe prefetch registers
     uint4 pf[PIECES];
     uint32_t pf_head = '\n';                                           // byte right before the stripe (decides whether it starts a line)
+    const bool list_mode = a.starts != nullptr;
+    auto stripe_start = [&](uint32_t chunk) -> uint64_t {              // where the stripe's staged text begins (16-byte aligned)
+        const uint32_t c = chunk < a.n_chunks ? chunk : a.n_chunks - 1;
+        return list_mode ? (a.starts[c] & ~15ull) : (uint64_t)c * a.chunk;
+    };
     auto prefetch = [&](uint32_t chunk) {                            // no bounds tests: the buffer is zero padded by TEXT + 64 bytes
-        const uint64_t c0 = (uint64_t)(chunk < a.n_chunks ? chunk : a.n_chunks - 1) * a.chunk;
+        const uint64_t c0 = stripe_start(chunk);
         const uint4 *src = (const uint4 *)(a.gaf + c0) + tid;
 #pragma unroll
         for (uint32_t i = 0; i < PIECES; ++i) pf[i] = src[i * WG];
@@ -335,9 +344,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     lds_barrier();
 
     for (uint32_t chunk = blockIdx.x; chunk < a.n_chunks; chunk += gridDim.x) {
-        const uint64_t c0 = (uint64_t)chunk * a.chunk;
+        const uint64_t c0 = stripe_start(chunk);
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (uint64_t)TEXT) ? (a.n_bytes - c0) : (uint64_t)TEXT);   // valid bytes staged
-        const uint32_t own_lim = V < a.chunk ? V : a.chunk;                  // lines starting below this offset belong to the stripe
+        // lines starting in [own_lo, own_lim) belong to the stripe: everything below the stride, or (second launch) the one listed line
+        const uint32_t own_lo = list_mode ? (uint32_t)(a.starts[chunk] & 15ull) : 0u;
+        const uint32_t own_lim = list_mode ? own_lo + 1u : (V < a.chunk ? V : a.chunk);
         const bool at_eof = c0 + V == a.n_bytes;
 
         // ---- A: registers -> LDS, then start the next stripe's HBM loads ---------------------------------
@@ -361,10 +372,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         else classify_span<false>(a, text, ndbm, tid, c0, V, NL, TAB, ORI);
         uint32_t head = 0;                                               // does the stripe begin at a line start?
         if (tid == 0) head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
-        // a terminator at sp + b starts a line at sp + b + 1; the stripe owns it if that is below own_lim
+        // a terminator at sp + b starts a line at sp + b + 1; the stripe owns it if that lies in [own_lo, own_lim)
         const uint32_t keep = own_lim > sp + 1 ? (own_lim - sp - 1 < 64u ? own_lim - sp - 1 : 64u) : 0u;
-        const unsigned long long OWN = NL & (keep >= 64u ? ~0ull : ((1ull << keep) - 1ull));
-        const uint32_t cA = ((uint32_t)__popcll(NL) + head) | (((uint32_t)__popcll(OWN) + (head & (uint32_t)(0 < own_lim))) << 16);
+        const uint32_t skip = own_lo > sp + 1 ? (own_lo - sp - 1 < 64u ? own_lo - sp - 1 : 64u) : 0u;
+        const unsigned long long below_lo = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
+        const unsigned long long OWN = NL & (keep >= 64u ? ~0ull : ((1ull << keep) - 1ull)) & ~below_lo;
+        const uint32_t head_own = head & (uint32_t)(own_lo == 0 && 0 < own_lim);
+        if (tid == 0) misc[2] = (head & (uint32_t)(0 < own_lo)) + (uint32_t)__popcll(NL & below_lo);   // (own_lo < 16: only this lane can see such starts)
+        const uint32_t cA = ((uint32_t)__popcll(NL) + head) | (((uint32_t)__popcll(OWN) + head_own) << 16);
         const uint32_t cB = (uint32_t)__popcll(TAB) | ((uint32_t)__popcll(ORI) << 16);
         uint32_t wA, wB;
         const uint32_t exA = wave_excl_scan(cA, wA), exB = wave_excl_scan(cB, wB);
@@ -385,19 +400,19 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
 
         if (a.all_slow || n_s > MAXL || tot_tab > CAP_T || tot_ori > CAP_O) {
             // the lists cannot hold this stripe (or the caller wants the exact path): every owned line is deferred as it is
-            const uint32_t mine = (uint32_t)__popcll(OWN) + ((tid == 0) ? (head & (uint32_t)(0 < own_lim)) : 0u);
+            const uint32_t mine = (uint32_t)__popcll(OWN) + head_own;
             uint32_t wt;
             const uint32_t ex = wave_excl_scan(mine, wt);
             unsigned long long dbase = 0;
             if (wt) {
                 if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)wt);
                 dbase = __shfl(dbase, 0) + ex;
-                if (tid == 0 && head && 0 < own_lim) { if (dbase < a.deferred_cap) a.deferred[dbase] = c0; else atomicOr(&a.st->overflow, 1u); ++dbase; }
+                if (head_own) { if (dbase < a.deferred_cap) a.deferred[dbase] = c0; else atomicOr(&a.st->overflow, 1u); ++dbase; }
                 for (unsigned long long m = OWN; m; m &= m - 1, ++dbase) {
                     if (dbase < a.deferred_cap) a.deferred[dbase] = c0 + sp + (uint32_t)__builtin_ctzll(m) + 1u; else atomicOr(&a.st->overflow, 1u);
                 }
             }
-            if (tid == 0) wave_lines += n_own;
+            if (tid == 0 && !list_mode) wave_lines += n_own;
             lds_barrier();
             continue;
         }
@@ -430,8 +445,8 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         tick(2);
 
         // ---- rounds: this wave's share of the stripe's lines -----------------------------------------------
-        const uint32_t per = (n_own + NWAVE_R - 1) / NWAVE_R;
-        const uint32_t l_lo = wave * per < n_own ? wave * per : n_own, l_hi = l_lo + per < n_own ? l_lo + per : n_own;
+        const uint32_t per = (n_own + NWAVE_R - 1) / NWAVE_R, l_first = misc[2];
+        const uint32_t l_lo = l_first + (wave * per < n_own ? wave * per : n_own), l_hi = l_lo + per < l_first + n_own ? l_lo + per : l_first + n_own;
         for (uint32_t lbase = (a.diag & 1u) ? l_hi : l_lo, taken = 0; lbase < l_hi; lbase += taken) {   // wave-uniform trip count
             const uint32_t cnt = l_hi - lbase < LRW ? l_hi - lbase : LRW;
             const uint32_t obase = LO[lbase];
@@ -651,7 +666,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 uint32_t lr = lane;
                 asm volatile("" : "+v"(lr));
                 const bool defer = lane < taken && (l_meta[lr] >> 24) == ST_DEFER;
-                const unsigned long long cb = __ballot(cut && lane < taken);
+                const unsigned long long cb = __ballot(cut && lane < taken && !list_mode);
                 if (cb && lane == 0) atomicAdd(&a.st->n_incomplete, (unsigned long long)__popcll(cb));
                 unsigned long long db = __ballot(defer);
                 if (db) {
@@ -660,13 +675,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     dbase = __shfl(dbase, 0);
                     if (defer) {
                         unsigned long long idx = dbase + __popcll(db & ((1ull << lane) - 1ull));
-                        if (idx < a.deferred_cap) a.deferred[idx] = c0 + s; else atomicOr(&a.st->overflow, 1u);
+                        // a line cut off by the staged text gets a second chance with a stripe of its own (DEFER_CUT) before the exact path
+                        if (idx < a.deferred_cap) a.deferred[idx] = (c0 + s) | ((cut && !list_mode) ? DEFER_CUT : 0ull); else atomicOr(&a.st->overflow, 1u);
                     }
                 }
             }
             wave_sync();                                                 // round state is reused
         }
-        wave_lines += l_hi - l_lo;
+        if (!list_mode) wave_lines += l_hi - l_lo;
         lds_barrier();                                                 // text, bitmap and lists are overwritten by the next stripe
         tick(7);
     }
@@ -675,6 +691,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     if ((a.diag & 16u) && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc[i]);
 #endif
+}
+
+// starts of the lines the first launch found cut off by its staged text -> a list of their own for the second launch
+__global__ __launch_bounds__(TPB) void k_pick_cut(const uint64_t *deferred, uint64_t n_def, uint64_t *out, unsigned long long *n_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n_def && (deferred[i] & DEFER_CUT)) out[atomicAdd(n_out, 1ull)] = deferred[i] & ~DEFER_CUT;
 }
 
 struct SlowEmit {
@@ -701,7 +723,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
     __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
     const uint32_t lane = threadIdx.x;
     for (uint64_t b0 = (uint64_t)blockIdx.x * SLOW_TPB; b0 < n_def; b0 += (uint64_t)gridDim.x * SLOW_TPB) {
-        const bool have = b0 + lane < n_def;
+        const bool have = b0 + lane < n_def && !(a.deferred[b0 + lane] & DEFER_CUT);   // (cut lines went through the second launch)
         uint64_t s = 0, e = 0;
         if (have) {
             s = a.deferred[b0 + lane];

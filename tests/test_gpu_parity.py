@@ -289,33 +289,36 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
         orc.filter(inf["gaf"].tobytes() + dense, want_hits=False)
 
 
-def test_long_lines_widen_the_look_ahead(ctx, tmp_path):
-    """Every line carries a 3 KB tag: many lines run past the staged text of their stripe and take the exact path; the
-    library widens the look-ahead for the next batch.  Counts are the oracle's both times."""
+def test_lines_longer_than_the_look_ahead(ctx, tmp_path):
+    """Every line carries a 3 KB tag: many lines run past the staged text of their stripe.  They get a stripe of their own in
+    a second launch of the main kernel instead of the exact path (and the library widens the look-ahead for the next
+    batch).  Lines longer than the whole staged text still take the exact path.  Counts are the oracle's every time."""
     import synth
     from svjg.graph import Graph
     pre = str(tmp_path / "c")
     inf = synth.generate(pre, 3000, 300, 2, "mixed", 41, write_gaf=False, return_gaf=True)
     g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
     orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    lines = inf["gaf"].tobytes().split(b"\n")[:-1]
     pad = b"\tzz:Z:" + b"ACGT" * 750
-    data = b"".join(l + pad + b"\n" for l in inf["gaf"].tobytes().split(b"\n")[:-1])
-    want, _, n_lines = orc.filter(data, want_hits=False)
-    arr = np.frombuffer(data, dtype=np.uint8)
+    data = b"".join(l + pad + b"\n" for l in lines)
+    huge = b"".join(l + (b"\tzz:Z:" + b"ACGT" * 6000 if i % 97 == 0 else pad if i % 3 else b"") + b"\n" for i, l in enumerate(lines))
     from svjg import capi
-    c2 = capi.Context(0)                       # a fresh context: the look-ahead is per context and only grows
-    try:
-        c2.load_graph(g)
-        deferred = []
-        for _ in range(4):
-            c2.reset_counts()
-            before = c2.stats()["n_deferred"]
-            c2.classify(arr)
-            assert _counts_dict(g, c2.counts()) == _oracle_dict(orc, want)
-            deferred.append(c2.stats()["n_deferred"] - before)
-        assert deferred[0] > n_lines // 100 and deferred[-1] < deferred[0] // 2
-    finally:
-        c2.close()
+    for text, n_exact in ((data, 0), (huge, len(lines) // 97 + 1)):
+        want, _, n_lines = orc.filter(text, want_hits=False)
+        arr = np.frombuffer(text, dtype=np.uint8)
+        c2 = capi.Context(0)                       # a fresh context: the look-ahead is per context and only grows
+        try:
+            c2.load_graph(g)
+            for _ in range(3):
+                c2.reset_counts()
+                c2.classify(arr, want_hits=True)
+                assert _counts_dict(g, c2.counts()) == _oracle_dict(orc, want)
+                st = c2.stats()
+                assert st["n_lines"] == n_lines and st["n_deferred"] == n_exact
+                assert st["n_hitrecs"] == int(want.sum())
+        finally:
+            c2.close()
 
 
 def test_sharded_and_chunked_ingest_is_the_same_file(golden, tmp_path, monkeypatch):
