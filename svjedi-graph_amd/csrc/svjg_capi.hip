@@ -285,8 +285,14 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         c->ms_slow = 0;
         if (n_def && !(c->h_st.overflow & 1u)) {
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-            const uint64_t want_blocks = (n_def + SLOW_TPB - 1) / SLOW_TPB, max_blocks = (uint64_t)c->n_cu * 4;     // 32 KB of LDS each: four per CU
-            hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)(want_blocks < max_blocks ? want_blocks : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def);
+            const uint64_t max_blocks = (uint64_t)c->n_cu * 4;              // 32 KB of LDS each: four per CU
+            if (n_def - n_cut <= 16 * max_blocks) {
+                // few lines: one wave per line (latency of a line O(k) instead of O(k^2) name resolutions)
+                hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)(n_def < max_blocks ? n_def : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def);
+            } else {
+                const uint64_t want_blocks = (n_def + SLOW_TPB - 1) / SLOW_TPB;
+                hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)(want_blocks < max_blocks ? want_blocks : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def);
+            }
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
             HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));

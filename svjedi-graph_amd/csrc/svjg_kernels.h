@@ -760,6 +760,50 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
     }
 }
 
+// The exact path for a few lines: one WAVE per deferred line.  Every lane runs the per-line part of slow_line (same
+// control flow in all lanes), lane l then takes the path nodes and links l (mod 64): a line's latency falls from
+// O(k^2) to O(k) name resolutions, and a handful of deferred lines no longer cost milliseconds.  An error is the one the
+// reference would meet first (smallest position in its sequence of steps).
+__global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a, uint64_t n_def) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t b = blockIdx.x; b < n_def; b += gridDim.x) {
+        const uint64_t s = a.deferred[b];
+        if (s & DEFER_CUT) continue;                                     // (cut lines went through the second launch)
+        // the terminator: 64 aligned 16-byte blocks per step
+        const uint64_t a0 = s & ~15ull;
+        uint64_t e = ~0ull;
+        for (uint64_t p0 = a0; e == ~0ull; p0 += 1024) {                 // the buffer is zero padded far beyond n_bytes
+            const uint64_t p = p0 + lane * 16;
+            const uint4 v = *(const uint4 *)(a.gaf + (p < a.n_bytes + 16 ? p : a0));
+            uint32_t m = eq_mask16(v, 0x0A0A0A0Au) | eq_mask16(v, 0x0D0D0D0Du);
+            if (p + 16 > a.n_bytes) m |= p >= a.n_bytes ? 0xFFFFu : (0xFFFFu << (a.n_bytes - p)) & 0xFFFFu;   // the text ends here
+            if (p < s) m &= 0xFFFFu << (s - p);
+            const unsigned long long hit = __ballot(m != 0);
+            if (hit) {
+                const int first = __builtin_ctzll(hit);
+                e = p0 + (uint64_t)first * 16 + (uint64_t)__builtin_ctz((uint32_t)__shfl((int)m, first));
+            }
+        }
+        const uint64_t span = (e - a0 + 15) & ~15ull;                     // bytes of the aligned blocks that hold the line
+        const bool staged = span <= SLOW_LDS;
+        if (staged) for (uint64_t o = (uint64_t)lane * 16; o < span; o += 1024) *(uint4 *)(stage + o) = *(const uint4 *)(a.gaf + a0 + o);
+        __syncthreads();
+        SlowEmit em{&a, a.base_offset + s};
+        uint64_t order = 0;
+        int rc;
+        if (staged) {
+            typedef const __attribute__((address_space(3))) uint8_t *lds_text;
+            rc = slow_line(a.g, (lds_text)stage, s - a0, s - a0 + (e - s), em, lane, 64u, &order);
+        } else rc = slow_line(a.g, a.gaf, s, e, em, lane, 64u, &order);
+        unsigned long long key = rc ? ((order << 3) | (unsigned long long)rc) : ~0ull;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) { const unsigned long long y = __shfl_xor(key, d); key = y < key ? y : key; }
+        if (lane == 0 && key != ~0ull) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (key & 7ull));
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // genotype likelihoods
 // ---------------------------------------------------------------------------------------------------

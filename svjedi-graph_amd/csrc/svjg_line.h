@@ -311,8 +311,12 @@ SVJG_HD int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &stran
 
 // One line, content t[s, e).  emit(slot, allele) is called once per appended alignment text.
 // Returns 0 or the SVJG_EXC_* class the reference would die with.
+// lane / nlanes: several lanes may share one line: everyone runs the per-line part (same result everywhere), lane l takes the
+// path nodes j = l (mod nlanes) of the strand walk and the links i = l (mod nlanes); *order then tells where in the
+// reference's sequence of steps the returned error sits, so that the caller can keep the one the reference meets first.
 template <class P, class Emit>
-SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emit) {
+SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emit, uint32_t lane = 0, uint32_t nlanes = 1, uint64_t *order = nullptr) {
+    if (order) *order = 0;
     while (e > s && py_space(t[e - 1])) --e;
     uint64_t fs[12], fe[12]; uint32_t nf = 0;
     { uint64_t st = s;
@@ -336,18 +340,32 @@ SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emi
     uint32_t k = 0;
     { NameRef nm{0, 0}; uint64_t pos = ps; while (next_node(t, pe, oriented, pos, nm)) ++k; }
     if (k < 2) return 0;
-    { NameRef nm{0, 0}; uint64_t pos = ps;                         // get_aln_links walks every node first
-      while (next_node(t, pe, oriented, pos, nm)) { uint32_t st = 0; int rc = strand_of(t, ps, pe, nm, st); if (rc) return rc; } }
+    // (cooperating lanes must do their shares in the SAME loop iterations, or a wave would run them one after the other:
+    //  lane l walks to node l first and then advances nlanes nodes per iteration)
+    { NameRef nm{0, 0}; uint64_t pos = ps; bool more = true;       // get_aln_links walks every node first
+      for (uint32_t j = 0; j < lane && more; ++j) more = next_node(t, pe, oriented, pos, nm);
+      for (uint32_t j = lane; more && next_node(t, pe, oriented, pos, nm); j += nlanes) {
+          uint32_t st = 0; int rc = strand_of(t, ps, pe, nm, st);
+          if (rc) { if (order) *order = (1ull << 32) | j; return rc; }
+          NameRef skip{0, 0};
+          for (uint32_t q = 1; q < nlanes && more; ++q) more = next_node(t, pe, oriented, pos, skip);
+      } }
     int64_t Tlen = v[6], Ts = v[7], Te = v[8];
     NameRef L{0, 0}, R{0, 0};
     uint64_t posL = ps;
-    next_node(t, pe, oriented, posL, L);
-    for (uint32_t i = 0; i + 1 < k; ++i, L = R) {
+    bool more = true;
+    for (uint32_t j = 0; j <= lane && more; ++j) more = next_node(t, pe, oriented, posL, L);      // L = node number `lane`
+    for (uint32_t i = lane; more && i + 1 < k; i += nlanes) {
         uint32_t sl = 0, sr = 0;
-        next_node(t, pe, oriented, posL, R);
-        strand_of(t, ps, pe, L, sl);
+        next_node(t, pe, oriented, posL, R);                       // R = node i + 1
+        NameRef Lcur = L;
+        // the lane's next link starts nlanes nodes further on (nlanes == 1: at R)
+        L = R;
+        for (uint32_t q = 1; q < nlanes && more; ++q) more = next_node(t, pe, oriented, posL, L);
+        if (order) *order = (2ull << 32) | i;                      // (where an error of this link sits)
+        strand_of(t, ps, pe, Lcur, sl);
         strand_of(t, ps, pe, R, sr);
-        uint32_t lid = resolve_name(g, t, L, nullptr), rid = resolve_name(g, t, R, nullptr);
+        uint32_t lid = resolve_name(g, t, Lcur, nullptr), rid = resolve_name(g, t, R, nullptr);
         if (lid == NONE32 || rid == NONE32) continue;
         uint32_t ei = edge_find(g, lid, sl, rid, sr);
         if (ei == NONE32) continue;
@@ -356,7 +374,7 @@ SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emi
         if (!nh) continue;
         // list.index of both names (:269-271), then the node lengths up to / from there, in the reference's order
         uint32_t il = 0, ir = 0; NameRef nm{0, 0}; uint64_t pos = ps;
-        for (;; ++il) { next_node(t, pe, oriented, pos, nm); if (nm.e - nm.s == L.e - L.s && bytes_eq(t, nm.s, L.s, L.e - L.s)) break; }
+        for (;; ++il) { next_node(t, pe, oriented, pos, nm); if (nm.e - nm.s == Lcur.e - Lcur.s && bytes_eq(t, nm.s, Lcur.s, Lcur.e - Lcur.s)) break; }
         pos = ps;
         for (;; ++ir) { next_node(t, pe, oriented, pos, nm); if (nm.e - nm.s == R.e - R.s && bytes_eq(t, nm.s, R.s, R.e - R.s)) break; }
         int64_t left = 0, right = 0, l1;

@@ -30,13 +30,15 @@ def _lib():
     return lib, capi
 
 
-def classify(graph, gaf, tables=True):
+def classify(graph, gaf, tables=True, wave=False):
     """Every line through svjg::slow_line (the exact path the kernels defer to).  tables=False: node names are resolved
     through the sorted node table only (what the device does for names the node-name hash table cannot hold)."""
     lib, capi = _lib()
     cg = capi.cgraph_of(graph)
     if not tables:
         cg.flags |= 2
+    if wave:
+        cg.flags |= 4                # every line by 64 cooperating lanes (the decomposition of k_classify_slow_wave)
     buf = np.frombuffer(gaf, dtype=np.uint8) if not isinstance(gaf, np.ndarray) else gaf
     counts = np.zeros((max(graph.n_slots, 1), 2), dtype=np.uint32)
     nl, eo = ctypes.c_uint64(0), ctypes.c_uint64(0)

@@ -58,10 +58,10 @@ def test_c_oracle_and_exact_device_routine(fuzz):
         except Exception as e:
             got = ("died", type(e).__name__)
         assert got == _want(c), ("C oracle", i, c["raw"])
-        for tables in (True, False):
+        for tables, wave in ((True, False), (False, False), (True, True)):
             try:
-                cnt, _ = sim.classify(g, c["raw"], tables)
+                cnt, _ = sim.classify(g, c["raw"], tables, wave)
                 got = ("ok", {g.sv_ids[j]: [int(cnt[j, 0]), int(cnt[j, 1])] for j in range(g.n_slots) if cnt[j].sum()})
             except Exception as e:
                 got = ("died", type(e).__name__)
-            assert got == _want(c), ("slow_line", tables, i, c["raw"])
+            assert got == _want(c), ("slow_line", tables, wave, i, c["raw"])
