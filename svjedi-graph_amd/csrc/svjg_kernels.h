@@ -760,12 +760,17 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
     }
 }
 
-// The exact path for a few lines: one WAVE per deferred line.  Every lane runs the per-line part of slow_line (same
-// control flow in all lanes), lane l then takes the path nodes and links l (mod 64): a line's latency falls from
-// O(k^2) to O(k) name resolutions, and a handful of deferred lines no longer cost milliseconds.  An error is the one the
-// reference would meet first (smallest position in its sequence of steps).
+// The exact path for a few lines: one WAVE per deferred line.  Every lane runs the per-line part (same control flow in
+// all lanes); then lane l takes the path nodes l (mod 64) — strand, id, length or the exception get_node_len raises, kept
+// per node in LDS — and after a barrier the links l (mod 64), which only add up what phase 1 left: O(k / 64) name
+// resolutions per lane where one lane per line needs O(k^2).  An error is the one the reference would meet first
+// (smallest position in its sequence of steps).
+constexpr uint32_t SLOW_NODES = 1024;                                  // path nodes the per-node scratch of one line holds
 __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a, uint64_t n_def) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
+    __shared__ int64_t n_len[SLOW_NODES];
+    __shared__ uint32_t n_id[SLOW_NODES];
+    __shared__ uint8_t n_rc[SLOW_NODES], n_strand[SLOW_NODES];
     const uint32_t lane = threadIdx.x;
     for (uint64_t b = blockIdx.x; b < n_def; b += gridDim.x) {
         const uint64_t s = a.deferred[b];
@@ -791,15 +796,28 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
         __syncthreads();
         SlowEmit em{&a, a.base_offset + s};
         uint64_t order = 0;
-        int rc;
+        int rc = 0;
+        auto wave_min = [&](int r, uint64_t ord) {                     // the error the reference meets first, or 0 (same value in every lane)
+            unsigned long long key = r ? ((ord << 3) | (unsigned long long)r) : ~0ull;
+#pragma unroll
+            for (int d = 32; d; d >>= 1) { const unsigned long long y = __shfl_xor(key, d); key = y < key ? y : key; }
+            return key == ~0ull ? 0 : (int)(key & 7ull);
+        };
         if (staged) {
             typedef const __attribute__((address_space(3))) uint8_t *lds_text;
-            rc = slow_line(a.g, (lds_text)stage, s - a0, s - a0 + (e - s), em, lane, 64u, &order);
-        } else rc = slow_line(a.g, a.gaf, s, e, em, lane, 64u, &order);
-        unsigned long long key = rc ? ((order << 3) | (unsigned long long)rc) : ~0ull;
-#pragma unroll
-        for (int d = 32; d; d >>= 1) { const unsigned long long y = __shfl_xor(key, d); key = y < key ? y : key; }
-        if (lane == 0 && key != ~0ull) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (key & 7ull));
+            const lds_text t = (lds_text)stage;
+            SlowLine ln;
+            rc = slow_prologue(t, s - a0, s - a0 + (e - s), ln);        // per-line part: the same in every lane
+            if (!rc && ln.k >= 2) {
+                if (ln.k <= SLOW_NODES) {
+                    NodeScratch ns{n_id, n_len, n_rc, n_strand, SLOW_NODES};
+                    rc = wave_min(slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order), order);
+                    __syncthreads();
+                    if (!rc) rc = wave_min(slow_wave_phase2(a.g, ln, ns, em, lane, 64u, &order), order);
+                } else rc = wave_min(slow_line(a.g, t, s - a0, s - a0 + (e - s), em, lane, 64u, &order), order);   // a path of more nodes than the scratch holds
+            }
+        } else rc = wave_min(slow_line(a.g, a.gaf, s, e, em, lane, 64u, &order), order);
+        if (lane == 0 && rc) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (unsigned long long)rc);
         __syncthreads();
     }
 }

@@ -309,14 +309,13 @@ SVJG_HD int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &stran
     return SVJG_EXC_INDEX_ERROR;                                  // unreachable: the name is part of the path
 }
 
-// One line, content t[s, e).  emit(slot, allele) is called once per appended alignment text.
-// Returns 0 or the SVJG_EXC_* class the reference would die with.
-// lane / nlanes: several lanes may share one line: everyone runs the per-line part (same result everywhere), lane l takes the
-// path nodes j = l (mod nlanes) of the strand walk and the links i = l (mod nlanes); *order then tells where in the
-// reference's sequence of steps the returned error sits, so that the caller can keep the one the reference meets first.
-template <class P, class Emit>
-SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emit, uint32_t lane = 0, uint32_t nlanes = 1, uint64_t *order = nullptr) {
-    if (order) *order = 0;
+// The per-line part of the exact routine (filter-alignments.py:184-198 read_gaf_line, :351-373 extract_nodes): columns,
+// the nine int() columns, the id:f: tag, the path column and its node count.  0 or the exception class.
+struct SlowLine { uint64_t ps, pe; bool oriented; uint32_t k; int64_t Tlen, Ts, Te; };
+
+template <class P>
+SVJG_HD int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
+    o.k = 0;
     while (e > s && py_space(t[e - 1])) --e;
     uint64_t fs[12], fe[12]; uint32_t nf = 0;
     { uint64_t st = s;
@@ -334,11 +333,73 @@ SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emi
           while (b < e && t[b] != '\t') ++b;
           if (!py_float_ok(t, a, b)) return SVJG_EXC_VALUE_ERROR;
       } else if (v[10] == 0) return SVJG_EXC_ZERO_DIVISION; }
-    uint64_t ps = fs[5], pe = fe[5];
-    if (pe == ps) return SVJG_EXC_INDEX_ERROR;                     // p[0]
-    bool oriented = t[ps] == '<' || t[ps] == '>';
-    uint32_t k = 0;
-    { NameRef nm{0, 0}; uint64_t pos = ps; while (next_node(t, pe, oriented, pos, nm)) ++k; }
+    o.ps = fs[5]; o.pe = fe[5];
+    if (o.pe == o.ps) return SVJG_EXC_INDEX_ERROR;                 // p[0]
+    o.oriented = t[o.ps] == '<' || t[o.ps] == '>';
+    { NameRef nm{0, 0}; uint64_t pos = o.ps; while (next_node(t, o.pe, o.oriented, pos, nm)) ++o.k; }
+    o.Tlen = v[6]; o.Ts = v[7]; o.Te = v[8];
+    return 0;
+}
+
+// ---- the exact routine shared out over the lanes of a wave, node lengths computed ONCE per line ------------------------
+// Per-node scratch (LDS in k_classify_slow_wave, plain arrays in tests/hostsim): what the reference recomputes for every
+// link is kept per node.  phase 1: lane l takes the nodes l (mod nlanes): strand of the name (str.split quirk), node id,
+// get_node_len or the exception it raises.  phase 2 (after a barrier): lane l takes the links l (mod nlanes).
+struct NodeScratch { uint32_t *id; int64_t *len; uint8_t *rc; uint8_t *strand; uint32_t cap; };
+
+template <class P>
+SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeScratch &ns, uint32_t lane, uint32_t nlanes, uint64_t *order) {
+    NameRef nm{0, 0}; uint64_t pos = ln.ps; bool more = true;
+    for (uint32_t j = 0; j < lane && more; ++j) more = next_node(t, ln.pe, ln.oriented, pos, nm);
+    for (uint32_t j = lane; more && next_node(t, ln.pe, ln.oriented, pos, nm); j += nlanes) {
+        uint32_t st = 0;
+        int rc = strand_of(t, ln.ps, ln.pe, nm, st);                 // get_aln_links walks every node first (:203-209)
+        if (rc) { *order = (1ull << 32) | j; return rc; }
+        int64_t l1 = 0;
+        ns.strand[j] = (uint8_t)st;
+        ns.id[j] = resolve_name(g, t, nm, nullptr);
+        ns.rc[j] = (uint8_t)generic_node_len(g, t, nm, l1);
+        ns.len[j] = l1;
+        NameRef skip{0, 0};
+        for (uint32_t q = 1; q < nlanes && more; ++q) more = next_node(t, ln.pe, ln.oriented, pos, skip);
+    }
+    return 0;
+}
+
+template <class Emit>
+SVJG_HD int slow_wave_phase2(const GraphView &g, const SlowLine &ln, const NodeScratch &ns, Emit &emit, uint32_t lane, uint32_t nlanes, uint64_t *order) {
+    for (uint32_t i = lane; i + 1 < ln.k; i += nlanes) {
+        const uint32_t lid = ns.id[i], rid = ns.id[i + 1];
+        if (lid == NONE32 || rid == NONE32) continue;
+        const uint32_t ei = edge_find(g, lid, ns.strand[i], rid, ns.strand[i + 1]);
+        if (ei == NONE32) continue;
+        const svjg_edge ed = g.edges[ei];
+        const uint32_t nh = ed.meta >> 2;
+        if (!nh) continue;
+        // list.index of both names (:269-271): a name that resolves has one spelling, so equal names <=> equal ids
+        uint32_t il = 0, ir = 0;
+        while (ns.id[il] != lid) ++il;
+        while (ns.id[ir] != rid) ++ir;
+        int64_t left = 0, right = 0;
+        for (uint32_t j = 0; j <= il; ++j) { if (ns.rc[j]) { *order = (2ull << 32) | i; return ns.rc[j]; } left += ns.len[j]; }
+        for (uint32_t j = ir; j < ln.k; ++j) { if (ns.rc[j]) { *order = (2ull << 32) | i; return ns.rc[j]; } right += ns.len[j]; }
+        if (left - ln.Ts >= (int64_t)g.d_over && right - (ln.Tlen - ln.Te - 1) >= (int64_t)g.d_over)
+            for (uint32_t j = 0; j < nh; ++j) { uint32_t hv = edge_hit(g, ed, j); emit(hv >> 1, hv & 1u); }
+    }
+    return 0;
+}
+
+// One line, content t[s, e).  emit(slot, allele) is called once per appended alignment text.
+// Returns 0 or the SVJG_EXC_* class the reference would die with.
+// lane / nlanes: several lanes may share one line: everyone runs the per-line part (same result everywhere), lane l takes the
+// path nodes j = l (mod nlanes) of the strand walk and the links i = l (mod nlanes); *order then tells where in the
+// reference's sequence of steps the returned error sits, so that the caller can keep the one the reference meets first.
+template <class P, class Emit>
+SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emit, uint32_t lane = 0, uint32_t nlanes = 1, uint64_t *order = nullptr) {
+    if (order) *order = 0;
+    SlowLine ln;
+    { int rc = slow_prologue(t, s, e, ln); if (rc) return rc; }
+    const uint64_t ps = ln.ps, pe = ln.pe; const bool oriented = ln.oriented; const uint32_t k = ln.k;
     if (k < 2) return 0;
     // (cooperating lanes must do their shares in the SAME loop iterations, or a wave would run them one after the other:
     //  lane l walks to node l first and then advances nlanes nodes per iteration)
@@ -350,7 +411,7 @@ SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emi
           NameRef skip{0, 0};
           for (uint32_t q = 1; q < nlanes && more; ++q) more = next_node(t, pe, oriented, pos, skip);
       } }
-    int64_t Tlen = v[6], Ts = v[7], Te = v[8];
+    const int64_t Tlen = ln.Tlen, Ts = ln.Ts, Te = ln.Te;
     NameRef L{0, 0}, R{0, 0};
     uint64_t posL = ps;
     bool more = true;

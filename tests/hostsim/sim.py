@@ -38,7 +38,7 @@ def classify(graph, gaf, tables=True, wave=False):
     if not tables:
         cg.flags |= 2
     if wave:
-        cg.flags |= 4                # every line by 64 cooperating lanes (the decomposition of k_classify_slow_wave)
+        cg.flags |= 8 if wave == 2 else 4   # every line by 64 cooperating lanes: 2 = the two-phase routine of k_classify_slow_wave, 1 = its fallback for very long paths
     buf = np.frombuffer(gaf, dtype=np.uint8) if not isinstance(gaf, np.ndarray) else gaf
     counts = np.zeros((max(graph.n_slots, 1), 2), dtype=np.uint32)
     nl, eo = ctypes.c_uint64(0), ctypes.c_uint64(0)

@@ -20,20 +20,20 @@ def _as_dict(graph, counts):
     return {graph.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(graph.n_slots) if counts[i].sum()}
 
 
-@pytest.mark.parametrize("tables", [True, False], ids=["name_table", "sorted_table"])
+@pytest.mark.parametrize("tables,wave", [(True, 0), (False, 0), (True, 1), (True, 2)], ids=["name_table", "sorted_table", "wave_lanes", "wave_two_phase"])
 @pytest.mark.parametrize("name", QUIRKS)
-def test_quirks(golden, name, tables):
+def test_quirks(golden, name, tables, wave):
     q = f"{golden}/quirks"
     man = json.load(open(f"{q}/manifest.json"))[name]
     g = Graph.from_files(f"{q}/q_svs_edges.json", f"{q}/q.gfa")
     raw = open(f"{q}/{name}.gaf", "rb").read()
     if man["rc"] == 0:
-        counts, n_lines = sim.classify(g, raw, tables)
+        counts, n_lines = sim.classify(g, raw, tables, wave)
         ref = json.load(open(f"{q}/{name}.ref.json"))
         assert _as_dict(g, counts) == {k: [len(v[0]), len(v[1])] for k, v in ref.items()}
     else:
         with pytest.raises(Exception) as ei:
-            sim.classify(g, raw, tables)
+            sim.classify(g, raw, tables, wave)
         assert type(ei.value).__name__ == man["error"]
 
 
