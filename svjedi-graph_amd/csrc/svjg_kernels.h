@@ -307,6 +307,10 @@ __device__ inline bool bits_clear(const uint32_t *bm, uint32_t a, uint32_t n) {
 #define SVJG_P_LOAD 3        /* node pass until its table loads are issued */
 #define SVJG_P_REST 2        /* rest of the node pass */
 #endif
+#ifndef SVJG_P_A
+#define SVJG_P_A 1          /* registers -> LDS, next stripe's loads issued (in front of the first barrier) */
+#endif
+constexpr int P_A = SVJG_P_A;
 constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST = SVJG_P_REST;
 __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         lds_barrier();
         const bool ascii = misc[1] == 0;                                 // workgroup-uniform: the cheaper SWAR classes apply
         prefetch(chunk + gridDim.x);
+        __builtin_amdgcn_s_setprio(0);
         tick(0);
 
         // ---- B1: byte classes, counts, workgroup prefix sum ------------------------------------------------
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             }
             wave_sync();                                                 // round state is reused
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(P_A);
         if (!list_mode) wave_lines += l_hi - l_lo;
         lds_barrier();                                                 // text, bitmap and lists are overwritten by the next stripe
         tick(7);
