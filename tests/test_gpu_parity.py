@@ -423,3 +423,34 @@ def test_stripes_the_lists_cannot_hold(ctx, tmp_path):
     assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
     st = ctx.stats()
     assert st["n_lines"] == n_lines and st["n_deferred"] > 100
+
+
+def test_c2_full_size_files_equal_the_reference(tmp_path):
+    """BASELINE configs[1] at full size (1 M alignments x 10 k DEL SVs) through the two drop-in scripts: the 1 GB
+    _informative_aln.json and the _genotype.vcf have the sha256 of the files the reference itself wrote for the same
+    generated inputs (golden/synth/c2_full.json, recorded in the build container together with the reference's run time)."""
+    import synth
+    from svjg import filter as flt, genotype
+    import shutil
+    import tempfile
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth", "c2_full.json")))
+    work = tempfile.mkdtemp(prefix="svjg_c2_", dir="/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path))   # 1.2 GB of files: memory-backed if possible
+    pre = os.path.join(work, "c2")
+    n_aln, n_sv, n_chrom, mix, seed = synth.CONFIGS["c2"]
+    synth.generate(pre, n_aln, n_sv, n_chrom, mix, seed)
+    flt.run(pre + ".gaf", pre + ".gfa", pre)
+
+    def sha(path):
+        h = hashlib.sha256()
+        with open(path, "rb") as fh:
+            for b in iter(lambda: fh.read(1 << 24), b""):
+                h.update(b)
+        return h.hexdigest()
+    assert os.path.getsize(pre + "_informative_aln.json") == want["json_bytes"]
+    assert sha(pre + "_informative_aln.json") == want["sha256_json"]
+    n = genotype.run(pre + "_informative_aln.json", pre + ".vcf", pre + "_genotype.vcf")
+    assert f"Genotyped svs: {n}\n" == want["genotype_stdout"]
+    try:
+        assert sha(pre + "_genotype.vcf") == want["sha256_vcf"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
