@@ -190,6 +190,11 @@ def cpu_baseline(pre, gaf, graph, gpu_counts, rows):
     exp = {sv: (int(want[i, 0]), int(want[i, 1])) for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
     got = {graph.sv_ids[i]: (int(g[i, 0]), int(g[i, 1])) for i in range(graph.n_slots) if g[i].sum()}
     base["parity_on_sample"] = "bit-exact" if exp == got else "MISMATCH"
+    try:                                                         # the reference itself cannot travel; its rate was measured in the build container
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "synth", "c2_full.json")))
+        base["reference_python"] = {"alignments_per_s": ref["alignments_per_s"], "where": ref["host"], "config": ref["config"]}
+    except (OSError, ValueError, KeyError):
+        pass
     # genotype leg: pure-Python restatement on a sample of rows
     D = {graph.sv_ids[i]: [["x"] * int(gpu_counts[i, 0]), ["y"] * int(gpu_counts[i, 1])]
          for i in range(graph.n_slots) if gpu_counts[i].sum()}
