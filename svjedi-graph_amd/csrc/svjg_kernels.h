@@ -278,8 +278,9 @@ __device__ inline uint32_t field_val(const uint8_t *text, uint32_t a, uint32_t n
     // the first n8 bytes move to the top of the 64-bit (hi:lo): what follows the column drops out, leading bytes are zero digits
     const unsigned long long x = (((unsigned long long)hi0 << 32) | lo0) << ((8 * (8 - n8)) & 63u);
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    const uint32_t pl = (lo * 10u + (lo >> 8)) & 0x00FF00FFu, ph = (hi * 10u + (hi >> 8)) & 0x00FF00FFu;
-    uint32_t r = ((pl & 0xFFu) * 100u + (pl >> 16)) * 10000u + (ph & 0xFFu) * 100u + (ph >> 16);
+    // digit pairs by shift-and-add (x * 10 = (x << 3) + (x << 1)), the rest with 24-bit multiplies (full rate; v_mul_lo_u32 is not)
+    const uint32_t pl = (((lo << 3) + (lo << 1)) + (lo >> 8)) & 0x00FF00FFu, ph = (((hi << 3) + (hi << 1)) + (hi >> 8)) & 0x00FF00FFu;
+    uint32_t r = __umul24(__umul24(pl & 0xFFu, 100u) + (pl >> 16), 10000u) + __umul24(ph & 0xFFu, 100u) + (ph >> 16);
     if (n == 9) r = r * 10u + ((uint32_t)text[a + 8] & 0xFu);
     return r;
 }
