@@ -313,6 +313,12 @@ __device__ inline bool bits_clear(const uint32_t *bm, uint32_t a, uint32_t n) {
 #endif
 constexpr int P_A = SVJG_P_A;
 constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST = SVJG_P_REST;
+// the ablation knobs (ClassifyArgs::diag) exist only in -DSVJG_ABLATE builds (tools/ablate.sh): the shipped kernel does not test them
+#ifdef SVJG_ABLATE
+#define DIAG(bit) ((a.diag & (bit)) != 0)
+#else
+#define DIAG(bit) false
+#endif
 __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *text = lds + L_TEXT;
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         // ---- rounds: this wave's share of the stripe's lines -----------------------------------------------
         const uint32_t per = (n_own + NWAVE_R - 1) / NWAVE_R, l_first = misc[2];
         const uint32_t l_lo = l_first + (wave * per < n_own ? wave * per : n_own), l_hi = l_lo + per < l_first + n_own ? l_lo + per : l_first + n_own;
-        for (uint32_t lbase = (a.diag & 1u) ? l_hi : l_lo, taken = 0; lbase < l_hi; lbase += taken) {   // wave-uniform trip count
+        for (uint32_t lbase = DIAG(1u) ? l_hi : l_lo, taken = 0; lbase < l_hi; lbase += taken) {   // wave-uniform trip count
             const uint32_t cnt = l_hi - lbase < LRW ? l_hi - lbase : LRW;
             const uint32_t obase = LO[lbase];
             // ---- R1: one line per lane --------------------------------------------------------------
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             if (lane < LRW) l_meta[li] = rel | (k << 16) | (status << 24);
             wave_sync();
             tick(3);
-            if (a.diag & 2u) continue;                                   // measurement only: stop after R1
+            if (DIAG(2u)) continue;                                      // measurement only: stop after R1
             // ---- node passes: up to 64 consecutive marks that cover whole lines; one mark (path node) per lane ----------------
             for (uint32_t i0 = 0; i0 < cnt;) {
                 const uint32_t p0 = (uint32_t)__shfl((int)rel, (int)i0);
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 }
                 for (uint32_t jj = 0; jj < nh; ++jj) {
                     const uint32_t hv = hp ? hp[jj] : (jj == 0 ? h0 : h1);
-                    if (!(a.diag & 8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
+                    if (!DIAG(8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
                     if (a.want_hits) {
                         if (rbase + jj < a.rec_cap) {
                             svjg_hitrec r; r.line_start = a.base_offset + c0 + LS[lbase + ln]; r.slot = hv >> 1;
