@@ -323,8 +323,8 @@ extern "C" int svjg_count_informative_json(const char *path, char **keys_out, ui
     *keys_out = (char *)malloc(keys.size() + 1);
     *counts_out = (uint64_t *)malloc((cnt.size() + 1) * sizeof(uint64_t));
     if (!*keys_out || !*counts_out) { free(*keys_out); free(*counts_out); return SVJG_E_NOMEM; }
-    memcpy(*keys_out, keys.data(), keys.size());
-    memcpy(*counts_out, cnt.data(), cnt.size() * sizeof(uint64_t));
+    if (!keys.empty()) memcpy(*keys_out, keys.data(), keys.size());
+    if (!cnt.empty()) memcpy(*counts_out, cnt.data(), cnt.size() * sizeof(uint64_t));
     *keys_len = keys.size(); *n_keys = cnt.size() / 2;
     return 0;
 }

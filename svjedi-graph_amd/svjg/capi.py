@@ -151,7 +151,10 @@ def count_informative_json(path):
     try:
         blob = ctypes.string_at(kp, kl.value)
         keys = [k.decode("utf-8") for k in blob.split(b"\0")[:-1]] if kl.value else []
-        cnt = np.ctypeslib.as_array(ctypes.cast(cp, ctypes.POINTER(ctypes.c_uint64)), shape=(max(1, nk.value) * 2,)).copy()[: nk.value * 2]
+        if nk.value:
+            cnt = np.ctypeslib.as_array(ctypes.cast(cp, ctypes.POINTER(ctypes.c_uint64)), shape=(nk.value * 2,)).copy()
+        else:
+            cnt = np.zeros(0, dtype=np.uint64)                      # (nothing to read: the buffer may be empty)
     finally:
         lib.svjg_host_free(kp); lib.svjg_host_free(cp)
     if (cnt >= 2 ** 32).any():
