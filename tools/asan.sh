@@ -1,0 +1,18 @@
+#!/bin/bash
+# CPU sanitizer pass (AddressSanitizer + UBSan) over everything that compiles for the host: libsvjg_host.so (JSON writer /
+# reader, graph loader) and the device routines of the exact path + the table builders in the test harness
+# (tests/hostsim).  GPU sanitizers are not available on the GPU pool; run this in the build container from the repo root.
+set -e
+ASAN=$(gcc -print-file-name=libasan.so)
+cp svjedi-graph_amd/csrc/libsvjg_host.so /tmp/svjg_host_keep.so
+[ -f tests/hostsim/_hostsim.so ] && cp tests/hostsim/_hostsim.so /tmp/svjg_hostsim_keep.so
+restore() { cp /tmp/svjg_host_keep.so svjedi-graph_amd/csrc/libsvjg_host.so; [ -f /tmp/svjg_hostsim_keep.so ] && cp /tmp/svjg_hostsim_keep.so tests/hostsim/_hostsim.so; touch tests/hostsim/_hostsim.so; }
+trap restore EXIT
+SAN="-O1 -g -std=c++17 -Wall -shared -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer"
+g++ $SAN -pthread -o svjedi-graph_amd/csrc/libsvjg_host.so svjedi-graph_amd/csrc/svjg_json.cpp svjedi-graph_amd/csrc/svjg_graphload.cpp
+g++ $SAN -o tests/hostsim/_hostsim.so tests/hostsim/hostsim.cpp
+touch tests/hostsim/_hostsim.so
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$ASAN python -m pytest -q -p no:cacheprovider \
+    tests/test_json_writer.py tests/test_graph_native.py tests/test_handoff.py tests/test_fuzz_golden.py tests/test_hostsim_parity.py 2>&1 | tee /tmp/svjg_asan.log | tail -3
+if grep -q "ERROR: AddressSanitizer\|runtime error" /tmp/svjg_asan.log; then echo "sanitizer findings: see /tmp/svjg_asan.log"; exit 1; fi
+echo "sanitizers: clean"
