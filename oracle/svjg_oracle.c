@@ -16,7 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { ORC_OK = 0, ORC_VALUE_ERROR = 1, ORC_INDEX_ERROR = 2, ORC_KEY_ERROR = 3, ORC_ZERO_DIVISION = 4, ORC_HIT_OVERFLOW = 9 };
+enum { ORC_OK = 0, ORC_VALUE_ERROR = 1, ORC_INDEX_ERROR = 2, ORC_KEY_ERROR = 3, ORC_ZERO_DIVISION = 4, ORC_HIT_OVERFLOW = 9, ORC_NOMEM = 9 };
 
 typedef struct { uint32_t sv, allele; } entry_t;
 typedef struct { char *key; uint32_t klen; entry_t *ent; uint32_t n, cap; } edge_t;
@@ -200,7 +200,6 @@ static int node_len(oracle_t *o, const char *nm, size_t n, int64_t *out) {
     *out = e - s + 1; return ORC_OK;
 }
 
-#define MAXN 4096
 
 typedef struct { const char *p; uint32_t n; char strand; } nm_t;
 
@@ -229,20 +228,22 @@ static int do_line(oracle_t *o, const char *ln, size_t n, uint64_t li, uint64_t 
     const char *path = f[5]; size_t pn = fl[5];
     int64_t Tlen = v[6], Ts = v[7], Te = v[8];
     if (pn == 0) return ORC_INDEX_ERROR;                              /* p[0] */
-    static nm_t nm[MAXN]; int k = 0;
+    static nm_t *nm = NULL; static int nm_cap = 0; int k = 0;       /* grows with the longest path seen (no limit on the node count) */
+#define NM_PUSH(P, N) do { if (k == nm_cap) { nm_cap = nm_cap ? nm_cap * 2 : 4096; nm = (nm_t *)realloc(nm, (size_t)nm_cap * sizeof(nm_t)); if (!nm) return ORC_NOMEM; } \
+                           nm[k].p = (P); nm[k].n = (uint32_t)(N); ++k; } while (0)
     if (path[0] != '<' && path[0] != '>') {
         /* GFA-style path (:369-371): comma pieces minus their last character */
         size_t st = 0;
         for (size_t i = 0; i <= pn; ++i)
             if (i == pn || path[i] == ',') {
-                if (i > st) { if (k >= MAXN) return ORC_VALUE_ERROR; nm[k].p = path + st; nm[k].n = (uint32_t)(i - st - 1); ++k; }
+                if (i > st) NM_PUSH(path + st, i - st - 1);
                 st = i + 1;
             }
     } else {
         size_t st = 0;
         for (size_t i = 0; i <= pn; ++i)
             if (i == pn || path[i] == '<' || path[i] == '>') {
-                if (i > st) { if (k >= MAXN) return ORC_VALUE_ERROR; nm[k].p = path + st; nm[k].n = (uint32_t)(i - st); ++k; }
+                if (i > st) NM_PUSH(path + st, i - st);
                 st = i + 1;
             }
     }
@@ -253,10 +254,14 @@ static int do_line(oracle_t *o, const char *ln, size_t n, uint64_t li, uint64_t 
         if (q == path) return ORC_INDEX_ERROR;                        /* ""[-1] */
         nm[i].strand = (q[-1] == '>') ? '+' : '-';
     }
-    static char key[2][8192];
+    static char *key[2] = {NULL, NULL}; static size_t key_cap = 0;    /* grows with the longest pair of names seen */
     for (int i = 0; i + 1 < k; ++i) {
         const nm_t *L = &nm[i], *R = &nm[i + 1];
-        if ((size_t)L->n + R->n + 8 > sizeof key[0]) return ORC_VALUE_ERROR;
+        if ((size_t)L->n + R->n + 8 > key_cap) {
+            key_cap = ((size_t)L->n + R->n + 8) * 2;
+            key[0] = (char *)realloc(key[0], key_cap); key[1] = (char *)realloc(key[1], key_cap);
+            if (!key[0] || !key[1]) return ORC_NOMEM;
+        }
         size_t kl[2];
         { char *q = key[0]; memcpy(q, L->p, L->n); q += L->n; *q++ = '@'; *q++ = L->strand; *q++ = '@';
           memcpy(q, R->p, R->n); q += R->n; *q++ = '@'; *q++ = R->strand; kl[0] = (size_t)(q - key[0]); }
