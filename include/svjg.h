@@ -29,6 +29,7 @@ extern "C" {
 #define SVJG_E_ARG         (-3)   /* bad argument / call order */
 #define SVJG_E_NOMEM       (-4)
 #define SVJG_E_RCCL        (-5)
+#define SVJG_E_IO          (-6)   /* the GAF file could not be opened / read (svjg_gaf_upload_file) */
 /* The input made the reference raise (it would exit 1, svjedi-graph.py:117-118).  svjg_input_error()
  * tells which Python exception and at which byte offset of the GAF. */
 #define SVJG_E_INPUT       (-10)
@@ -123,10 +124,16 @@ int svjg_load_graph(svjg_ctx *ctx, const svjg_graph *g);
  * svjg_gaf_upload copies a GAF byte buffer to HBM (the PCIe leg); svjg_classify_resident runs the kernels
  * over the resident buffer and ADDS to the per-SV counts; svjg_classify = upload + classify_resident.
  * `base_offset` is added to the line offsets reported in hit records / input errors (for chunked files).
- * Lines end at \n, \r\n or a lone \r and the last line may be unterminated, as in Python's text mode. */
+ * Lines end at \n, \r\n or a lone \r and the last line may be unterminated, as in Python's text mode.
+ * The _file forms take the bytes [offset, offset + n_bytes) of the file itself (the `for line in aln_file` of
+ * filter-alignments.py:123-126 without a host copy of the text): feeder threads pread() pieces into pinned buffers
+ * that go to HBM while the next pieces are read; svjg_classify_file uses `offset` as base_offset.  Buffers of 64 MB
+ * and more given to svjg_gaf_upload take the same staged route (memcpy instead of pread). */
 int svjg_gaf_upload(svjg_ctx *ctx, const char *gaf, uint64_t n_bytes);
+int svjg_gaf_upload_file(svjg_ctx *ctx, const char *path, uint64_t offset, uint64_t n_bytes);
 int svjg_classify_resident(svjg_ctx *ctx, uint64_t base_offset, int want_hits);
 int svjg_classify(svjg_ctx *ctx, const char *gaf, uint64_t n_bytes, uint64_t base_offset, int want_hits);
+int svjg_classify_file(svjg_ctx *ctx, const char *path, uint64_t offset, uint64_t n_bytes, int want_hits);
 int svjg_reset_counts(svjg_ctx *ctx);
 int svjg_get_stats(svjg_ctx *ctx, svjg_stats *out);
 int svjg_input_error(svjg_ctx *ctx, int *exc_class, uint64_t *line_offset);

@@ -3,16 +3,26 @@
 #include "svjg_kernels.h"
 #include "svjg_host_tables.h"
 #include <rccl/rccl.h>
+#include <errno.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace svjg;
 
 static thread_local std::string g_init_error;
+
+// ingest geometry: text of at least STAGE_MIN bytes goes to HBM through pinned buffers filled by STAGE_THREADS host
+// threads (page cache / mapped file -> pinned piece -> asynchronous copy on the thread's stream; the next piece is
+// filled while the previous one is on the bus)
+constexpr int STAGE_THREADS = 4;
+constexpr uint64_t STAGE_PIECE = 8ull << 20, STAGE_MIN = 64ull << 20;
 
 struct svjg_ctx {
     int device = 0;
@@ -29,6 +39,10 @@ struct svjg_ctx {
     unsigned long long *d_counts = nullptr, *d_snap = nullptr;
     // text
     uint8_t *d_gaf = nullptr;  uint64_t gaf_cap = 0, gaf_bytes = 0;  bool have_gaf = false;
+    // ingest: pinned staging buffers, two per feeder thread, each feeder with a copy stream of its own
+    char *h_stage[STAGE_THREADS * 2] = {};
+    hipStream_t stage_stream[STAGE_THREADS] = {};
+    hipEvent_t stage_ev[STAGE_THREADS * 2] = {};
     // outputs
     uint64_t *d_deferred = nullptr;  uint64_t deferred_cap = 0;
     uint64_t *d_cut = nullptr;       uint64_t cut_cap = 0;
@@ -116,6 +130,9 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_cut); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
     hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows);
     if (c->h_rows) hipHostFree(c->h_rows);
+    for (auto &b : c->h_stage) if (b) hipHostFree(b);
+    for (auto &ev : c->stage_ev) if (ev) hipEventDestroy(ev);
+    for (auto &st : c->stage_stream) if (st) hipStreamDestroy(st);
     for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -195,22 +212,96 @@ extern "C" int svjg_reset_counts(svjg_ctx *c) {
     return 0;
 }
 
-extern "C" int svjg_gaf_upload(svjg_ctx *c, const char *gaf, uint64_t n) {
-    if (!c || (n && !gaf)) return SVJG_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    uint64_t need = ((n + 15) & ~15ull) + TEXT + 64;
+// room for n bytes of text plus the zero padding the kernels read past the end without bounds tests
+static int gaf_reserve(svjg_ctx *c, uint64_t n, uint64_t *need_out) {
+    const uint64_t need = ((n + 15) & ~15ull) + TEXT + 64;
     if (need > c->gaf_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         hipFree(c->d_gaf); c->d_gaf = nullptr; c->gaf_cap = 0;
         HIPCHK(c, hipMalloc((void **)&c->d_gaf, need));
         c->gaf_cap = need;
     }
-    if (n) HIPCHK(c, hipMemcpyAsync(c->d_gaf, gaf, n, hipMemcpyHostToDevice, c->stream));
+    *need_out = need;
+    return 0;
+}
+
+// n bytes -> d_gaf through the pinned staging buffers.  Source: fd >= 0 ? pread(fd, ..., offset + i) : src + i.
+static int staged_upload(svjg_ctx *c, const char *src, int fd, uint64_t offset, uint64_t n) {
+    for (int i = 0; i < STAGE_THREADS * 2; ++i) {
+        if (!c->h_stage[i]) HIPCHK(c, hipHostMalloc((void **)&c->h_stage[i], STAGE_PIECE, hipHostMallocDefault));
+        if (!c->stage_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+    }
+    for (int t = 0; t < STAGE_THREADS; ++t)
+        if (!c->stage_stream[t]) HIPCHK(c, hipStreamCreateWithFlags(&c->stage_stream[t], hipStreamNonBlocking));
+    const uint64_t n_pieces = (n + STAGE_PIECE - 1) / STAGE_PIECE;
+    std::string errs[STAGE_THREADS];
+    int rcs[STAGE_THREADS] = {};
+    auto feeder = [&](int t) {
+        auto fail = [&](int rc, const std::string &m) { rcs[t] = rc; errs[t] = m; };
+        if (hipSetDevice(c->device) != hipSuccess) return fail(SVJG_E_HIP, "hipSetDevice in an ingest thread");
+        bool used[2] = {false, false};
+        uint64_t k = 0;
+        for (uint64_t p = (uint64_t)t; p < n_pieces && !rcs[t]; p += STAGE_THREADS, ++k) {
+            const int b = t * 2 + (int)(k & 1);
+            const uint64_t a = p * STAGE_PIECE, len = n - a < STAGE_PIECE ? n - a : STAGE_PIECE;
+            if (used[k & 1] && hipEventSynchronize(c->stage_ev[b]) != hipSuccess) return fail(SVJG_E_HIP, "hipEventSynchronize (ingest)");
+            if (fd >= 0) {
+                for (uint64_t got = 0; got < len;) {
+                    const ssize_t r = pread(fd, c->h_stage[b] + got, len - got, (off_t)(offset + a + got));
+                    if (r <= 0) return fail(SVJG_E_IO, r == 0 ? "the GAF file is shorter than announced" : std::string("pread: ") + strerror(errno));
+                    got += (uint64_t)r;
+                }
+            } else memcpy(c->h_stage[b], src + a, len);
+            if (hipMemcpyAsync(c->d_gaf + a, c->h_stage[b], len, hipMemcpyHostToDevice, c->stage_stream[t]) != hipSuccess ||
+                hipEventRecord(c->stage_ev[b], c->stage_stream[t]) != hipSuccess) return fail(SVJG_E_HIP, "hipMemcpyAsync (ingest)");
+            used[k & 1] = true;
+        }
+        if (hipStreamSynchronize(c->stage_stream[t]) != hipSuccess) fail(SVJG_E_HIP, "hipStreamSynchronize (ingest)");
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < STAGE_THREADS; ++t) th.emplace_back(feeder, t);
+    feeder(0);
+    for (auto &x : th) x.join();
+    for (int t = 0; t < STAGE_THREADS; ++t)
+        if (rcs[t]) { c->err = errs[t]; return rcs[t]; }
+    return 0;
+}
+
+static int gaf_finish(svjg_ctx *c, uint64_t n, uint64_t need) {
     HIPCHK(c, hipMemsetAsync(c->d_gaf + n, 0, need - n, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->gaf_bytes = n;
     c->have_gaf = true;
     return 0;
+}
+
+extern "C" int svjg_gaf_upload(svjg_ctx *c, const char *gaf, uint64_t n) {
+    if (!c || (n && !gaf)) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t need;
+    int rc = gaf_reserve(c, n, &need);
+    if (rc) return rc;
+    c->have_gaf = false;
+    if (n >= STAGE_MIN) { if ((rc = staged_upload(c, gaf, -1, 0, n))) return rc; }
+    else if (n) HIPCHK(c, hipMemcpyAsync(c->d_gaf, gaf, n, hipMemcpyHostToDevice, c->stream));
+    return gaf_finish(c, n, need);
+}
+
+extern "C" int svjg_gaf_upload_file(svjg_ctx *c, const char *path, uint64_t offset, uint64_t n) {
+    if (!c || !path) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t need;
+    int rc = gaf_reserve(c, n, &need);
+    if (rc) return rc;
+    c->have_gaf = false;
+    if (n) {
+        const int fd = open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) { c->err = std::string("open ") + path + ": " + strerror(errno); return SVJG_E_IO; }
+        rc = staged_upload(c, nullptr, fd, offset, n);
+        close(fd);
+        if (rc) return rc;
+    }
+    return gaf_finish(c, n, need);
 }
 
 static int ensure(svjg_ctx *c, void **p, uint64_t *cap, uint64_t want, size_t elem, bool keep) {
@@ -324,6 +415,12 @@ extern "C" int svjg_classify(svjg_ctx *c, const char *gaf, uint64_t n, uint64_t 
     int rc = svjg_gaf_upload(c, gaf, n);
     if (rc) return rc;
     return svjg_classify_resident(c, base_offset, want_hits);
+}
+
+extern "C" int svjg_classify_file(svjg_ctx *c, const char *path, uint64_t offset, uint64_t n, int want_hits) {
+    int rc = svjg_gaf_upload_file(c, path, offset, n);
+    if (rc) return rc;
+    return svjg_classify_resident(c, offset, want_hits);
 }
 
 extern "C" int svjg_get_stats(svjg_ctx *c, svjg_stats *out) {

@@ -54,6 +54,8 @@ _SIGS = {
     "svjg_gaf_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "svjg_classify_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
     "svjg_classify": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
+    "svjg_gaf_upload_file": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
+    "svjg_classify_file": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
     "svjg_reset_counts": (ctypes.c_int, [ctypes.c_void_p]),
     "svjg_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CStats)]),
     "svjg_input_error": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
@@ -250,6 +252,14 @@ class Context:
     def classify(self, gaf, base_offset=0, want_hits=False):
         a = _as_u8(gaf)
         self._chk(self.lib.svjg_classify(self.h, a.ctypes.data if a.size else None, a.size, base_offset, int(want_hits)))
+
+    def classify_file(self, path, offset, n_bytes, want_hits=False):
+        """bytes [offset, offset + n_bytes) of the file, read by the library's feeder threads (no host copy here); a read
+        error surfaces as OSError like the reference's own open()/read would"""
+        rc = self.lib.svjg_classify_file(self.h, os.fsencode(path), offset, n_bytes, int(want_hits))
+        if rc == -6:
+            raise OSError(self.lib.svjg_last_error(self.h).decode())
+        self._chk(rc)
 
     def reset_counts(self):
         self._chk(self.lib.svjg_reset_counts(self.h))

@@ -73,8 +73,10 @@ def pick_devices(n_bytes, device=None):
     return list(range(max(1, min(n_vis, n_bytes // MIN_BYTES_PER_DEVICE))))
 
 
-def _classify_shard(dev, graph, data, lo, hi, want_hits, out, r):
-    """One GPU, its contiguous byte range [lo, hi) of the file, chunk by chunk (cuts at line terminators)."""
+def _classify_shard(dev, graph, data, lo, hi, want_hits, out, r, path=None):
+    """One GPU, its contiguous byte range [lo, hi) of the file, chunk by chunk (cuts at line terminators).  With `path`
+    the library reads the chunk from the file itself (pinned, double-buffered ingest); `data` (the mapped file) is then
+    only looked at around the cut points."""
     try:
         ctx = capi.Context(dev)
         try:
@@ -82,7 +84,9 @@ def _classify_shard(dev, graph, data, lo, hi, want_hits, out, r):
             n_chunks = max(1, -(-(hi - lo) // CHUNK_BYTES))
             cuts = [lo + c for c in shard.cut_points(data[lo:hi], n_chunks)]
             for a, b in zip(cuts[:-1], cuts[1:]):
-                if b > a:
+                if b > a and path is not None:
+                    ctx.classify_file(path, a, b - a, want_hits=want_hits)
+                elif b > a:
                     ctx.classify(data[a:b], base_offset=a, want_hits=want_hits)
             st = ctx.stats()
             out[r] = (ctx.counts().astype(np.uint64), ctx.hits() if want_hits else None, st, None)
@@ -116,9 +120,9 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
     cuts = shard.cut_points(data, len(devs))
     out = [None] * len(devs)
     if len(devs) == 1:
-        _classify_shard(devs[0], graph, data, cuts[0], cuts[1], want_hits, out, 0)
+        _classify_shard(devs[0], graph, data, cuts[0], cuts[1], want_hits, out, 0, gaf_path)
     else:
-        th = [threading.Thread(target=_classify_shard, args=(d, graph, data, cuts[r], cuts[r + 1], want_hits, out, r))
+        th = [threading.Thread(target=_classify_shard, args=(d, graph, data, cuts[r], cuts[r + 1], want_hits, out, r, gaf_path))
               for r, d in enumerate(devs)]
         for x in th:
             x.start()

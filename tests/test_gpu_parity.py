@@ -224,6 +224,25 @@ def test_c2_full_size(ctx, tmp_path):
     ctx.classify(gaf[:cut])
     ctx.classify(gaf[cut:])
     assert np.array_equal(ctx.counts(), whole)
+    # the same two halves read from the file by the library's feeder threads (svjg_classify_file): same counts, and hit
+    # records whose line offsets are file offsets
+    gaf.tofile(pre + ".gaf")
+    ctx.reset_counts()
+    ctx.classify_file(pre + ".gaf", 0, cut, want_hits=True)
+    ctx.classify_file(pre + ".gaf", cut, gaf.size - cut, want_hits=True)
+    assert np.array_equal(ctx.counts(), whole)
+    recs = ctx.hits()
+    assert len(recs) == int(whole.sum()) and int(recs["line_start"].max()) > cut
+    starts = np.unique(recs["line_start"])
+    assert starts[0] == 0 or gaf[starts[0] - 1] == 10
+    assert (gaf[starts[1:] - 1] == 10).all()
+    with pytest.raises(OSError):
+        ctx.classify_file(pre + ".gaf", gaf.size - 100, 4096)            # beyond the end of the file
+    with pytest.raises(OSError):
+        ctx.classify_file(pre + "_nope.gaf", 0, 10)
+    ctx.reset_counts()
+    ctx.classify_file(pre + ".gaf", 0, 0)                                 # nothing to read
+    assert ctx.counts().sum() == 0
     # genotypes
     from svjg import genotype
     ctx.set_counts(whole)
