@@ -7,16 +7,16 @@ for p in (ROOT, os.path.join(ROOT, "svjedi-graph_amd"), os.path.join(ROOT, "tool
 import synth
 from svjg import capi, filter as flt
 from svjg.graph import Graph
-n_aln = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+n_aln = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 tmp = tempfile.mkdtemp(dir="/dev/shm"); pre = os.path.join(tmp, "w")
 synth.generate(pre, n_aln, 100_000, 4, "mixed", 20260517)
 g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
 counts, recs, data = flt.classify_sharded(g, pre + ".gaf", devices=[0])
-for T in (16, 64, 128):
+for T in (8, 16, 64):
     t = time.perf_counter()
     capi.write_informative_json("/dev/null", data, recs, g.sv_ids, n_threads=T)
     print(T, "threads, render only (/dev/null):", round(time.perf_counter() - t, 2), "s", flush=True)
-for T in (24, 64):
+for T in (4, 6, 8, 12, 16, 24, 32, 48):
     t = time.perf_counter()
     capi.write_informative_json(pre + "_o.json", data, recs, g.sv_ids, n_threads=T)
     dt = time.perf_counter() - t
