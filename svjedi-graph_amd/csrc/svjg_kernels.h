@@ -138,6 +138,9 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
     return x;
 }
+// value of the lane below / above (lane 0 / lane 63 keep their own), one DPP move instead of a trip through the LDS crossbar
+__device__ inline uint32_t lane_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
+__device__ inline uint32_t lane_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); }   // wave_shl:1
 __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
     const uint32_t x = wave_incl_scan(v);
     total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
@@ -605,10 +608,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // -- first occurrence of every name in its line (the reference's list.index / str.split quirks).  Ids grow along
                 //    a forward path and fall along a reverse one: such lines cannot revisit a node and need no search --
                 uint32_t f = lane;
+                bool revisits = false;                                   // wave-uniform: some line of the pass had to be searched
                 {
-                    const uint32_t prev = (uint32_t)__shfl_up((int)id, 1);
+                    const uint32_t prev = lane_below(id);
                     const unsigned long long up = __ballot(live && (j == 0 || id > prev)), dn = __ballot(live && (j == 0 || id < prev));
                     const bool search = live && (up & lmask) != lmask && (dn & lmask) != lmask;
+                    revisits = __ballot(search) != 0;
                     for (uint32_t dd = 1; __ballot(search && j >= dd); dd += 4) {       // four distances per trip: one wait for four shuffles
                         const uint32_t y0 = (uint32_t)__shfl_up((int)id, dd), y1 = (uint32_t)__shfl_up((int)id, dd + 1);
                         const uint32_t y2 = (uint32_t)__shfl_up((int)id, dd + 2), y3 = (uint32_t)__shfl_up((int)id, dd + 3);
@@ -621,11 +626,17 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 tick(5);
                 // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
                 //    (str.split / list.index, filter-alignments.py:206, :269-271) --
-                const uint32_t fl = f, fr = (uint32_t)__shfl_down((int)f, 1);
-                const uint32_t pre_l = (uint32_t)__shfl((int)pre, (int)fl);
-                const uint32_t pre_rx = (uint32_t)__shfl((int)pre, (int)((fr - 1u) & 63u));
-                const uint32_t idl = (uint32_t)__shfl((int)id, (int)fl), idr = (uint32_t)__shfl((int)id, (int)(fr & 63u));
-                const uint32_t orl = (uint32_t)__shfl((int)oribit, (int)fl), orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
+                uint32_t fl = lane, fr = lane + 1u, pre_l = pre, pre_rx = pre, idl = id, orl = oribit, idr, orr;
+                if (!revisits) {                                         // every node is its own first occurrence: the right node is the next lane
+                    const uint32_t nx = lane_above((id << 1) | oribit);
+                    idr = nx >> 1; orr = nx & 1u;
+                } else {
+                    fl = f; fr = (uint32_t)__shfl_down((int)f, 1);
+                    pre_l = (uint32_t)__shfl((int)pre, (int)fl);
+                    pre_rx = (uint32_t)__shfl((int)pre, (int)((fr - 1u) & 63u));
+                    idl = (uint32_t)__shfl((int)id, (int)fl); idr = (uint32_t)__shfl((int)id, (int)(fr & 63u));
+                    orl = (uint32_t)__shfl((int)oribit, (int)fl); orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
+                }
                 bool go = false;
                 uint32_t klo = 0, khi = 0;
                 if (live && j + 1 < lk) {
