@@ -241,10 +241,13 @@ template <bool ASCII>
 __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t tid, uint64_t c0, uint32_t V,
                                      unsigned long long &NL, unsigned long long &TAB, unsigned long long &ORI) {
     const uint32_t sp = tid * SPAN;
-    unsigned long long nl64 = 0, tab64 = 0, ori64 = 0, nd64 = 0;
+    // rotated piece order: the 16-byte LDS reads of a wave hit different banks.  The 16-bit masks are collected in loop
+    // order and the four of a class rotated into place at the end (one 64-bit rotate instead of four shifts).
+    const uint32_t rot = (tid >> 2) & 3u;
+    uint32_t nlm[PIECES], tabm[PIECES], orim[PIECES], ndm[PIECES];
 #pragma unroll
     for (uint32_t c = 0; c < PIECES; ++c) {
-        const uint32_t pc = (c + (tid >> 2)) & 3u;                     // rotated piece order: the 16-byte LDS reads of a wave hit different banks
+        const uint32_t pc = (c + rot) & 3u;
         const uint32_t pb = sp + pc * 16;
         const uint4 v = *(const uint4 *)(text + pb);
         uint32_t nl = eq_mask16_t<ASCII>(v, 0x0A0A0A0Au);
@@ -261,11 +264,15 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
                 if (nx != '\n') nl |= 1u << b;
             }
         }
-        if (pb >= V) nl = 0; else if (pb + 16 > V) nl &= (1u << (V - pb)) - 1u;   // ignore anything at or beyond the valid length
-        const uint32_t sh = pc * 16;
-        nl64 |= (unsigned long long)nl << sh; tab64 |= (unsigned long long)tab << sh; ori64 |= (unsigned long long)ori << sh;
-        nd64 |= (unsigned long long)(~(dig | tab) & 0xFFFFu) << sh;
+        nlm[c] = nl; tabm[c] = tab; orim[c] = ori; ndm[c] = ~(dig | tab) & 0xFFFFu;
     }
+    auto place = [&](const uint32_t (&m)[PIECES]) -> unsigned long long {      // piece c of the loop sits at 16-bit position (c + rot) & 3
+        const unsigned long long x = (unsigned long long)(m[0] | (m[1] << 16)) | ((unsigned long long)(m[2] | (m[3] << 16)) << 32);
+        return __builtin_rotateleft64(x, 16u * rot);
+    };
+    unsigned long long nl64 = place(nlm);
+    const unsigned long long tab64 = place(tabm), ori64 = place(orim), nd64 = place(ndm);
+    if (sp + SPAN > V) nl64 &= sp >= V ? 0ull : ((1ull << (V - sp)) - 1ull);   // ignore anything at or beyond the valid length
     *(uint2 *)(ndbm + tid * 2) = make_uint2((uint32_t)nd64, (uint32_t)(nd64 >> 32));
     NL = nl64; TAB = tab64; ORI = ori64;
 }
