@@ -15,9 +15,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -43,6 +46,52 @@ struct Mapped {
 struct Str { const uint8_t *p; uint32_t n; };
 struct StrHash { size_t operator()(const Str &s) const { uint64_t h = 1469598103934665603ull; for (uint32_t i = 0; i < s.n; ++i) h = (h ^ s.p[i]) * 1099511628211ull; return (size_t)h; } };
 struct StrEq { bool operator()(const Str &a, const Str &b) const { return a.n == b.n && !memcmp(a.p, b.p, a.n); } };
+
+// Str -> uint32 with open addressing (the tables hold millions of names: a node-based std::unordered_map spends its time in
+// malloc and pointer chasing).  Keys keep their insertion order in `keys`.
+struct StrMap {
+    std::vector<Str> keys; std::vector<uint32_t> vals;
+    std::vector<uint32_t> slot, tag;                                  // slot[i] = index into keys + 1 (0 = empty), tag[i] = hash bits
+    size_t mask = 0;
+    static uint64_t hash(const Str &s) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ s.n;
+        const uint8_t *p = s.p; uint32_t n = s.n;
+        for (; n >= 8; p += 8, n -= 8) { uint64_t w; memcpy(&w, p, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+        if (n) { uint64_t w = 0; memcpy(&w, p, n); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+        h *= 0xC4CEB9FE1A85EC53ull;
+        return h ^ (h >> 29);
+    }
+    void grow() {
+        const size_t cap = mask ? (mask + 1) * 2 : 1024;
+        slot.assign(cap, 0); tag.assign(cap, 0); mask = cap - 1;
+        for (size_t k = 0; k < keys.size(); ++k) {
+            const uint64_t h = hash(keys[k]);
+            size_t i = (size_t)h & mask;
+            while (slot[i]) i = (i + 1) & mask;
+            slot[i] = (uint32_t)k + 1; tag[i] = (uint32_t)(h >> 32);
+        }
+    }
+    uint32_t *find(const Str &s) {
+        if (!mask) return nullptr;
+        const uint64_t h = hash(s);
+        for (size_t i = (size_t)h & mask; slot[i]; i = (i + 1) & mask)
+            if (tag[i] == (uint32_t)(h >> 32)) { const Str &k = keys[slot[i] - 1]; if (k.n == s.n && !memcmp(k.p, s.p, s.n)) return &vals[slot[i] - 1]; }
+        return nullptr;
+    }
+    // the value of s, inserted as v if s is new; `fresh` tells which
+    uint32_t &put(const Str &s, uint32_t v, bool *fresh = nullptr) {
+        if (uint32_t *q = find(s)) { if (fresh) *fresh = false; return *q; }
+        if ((keys.size() + 1) * 2 > mask + 1) grow();
+        const uint64_t h = hash(s);
+        size_t i = (size_t)h & mask;
+        while (slot[i]) i = (i + 1) & mask;
+        keys.push_back(s); vals.push_back(v);
+        slot[i] = (uint32_t)keys.size(); tag[i] = (uint32_t)(h >> 32);
+        if (fresh) *fresh = true;
+        return vals.back();
+    }
+    size_t size() const { return keys.size(); }
+};
 
 inline bool py_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 
@@ -76,22 +125,30 @@ inline bool parse_name(Str nm, NodeInfo &o) {
     return true;
 }
 
-struct JsonKey { Str l, r; uint8_t sl, sr; uint32_t ent_lo, ent_hi; };   // entries [ent_lo, ent_hi) of `ents`
+struct JsonKey { Str k, l, r; uint8_t sl, sr; uint32_t ent_lo, ent_hi; uint32_t li, ri; };   // li, ri: index of the two names in `info`   // entries [ent_lo, ent_hi) of `ents`
 struct Ent { Str sv; uint8_t allele; };
 
 struct Parser {
     const uint8_t *p, *e;
-    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; }
+    void ws() {                                                       // (json.dumps(indent=4) output is half blanks: eight at a time)
+        for (;;) {
+            while (p + 8 <= e) { uint64_t w; memcpy(&w, p, 8); if (w != 0x2020202020202020ull) break; p += 8; }
+            if (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p; else return;
+        }
+    }
     bool eat(char c) { ws(); if (p < e && *p == (uint8_t)c) { ++p; return true; } return false; }
     // plain string: printable ASCII without '"' and '\\'
     bool str(Str &s) {
         ws();
         if (p >= e || *p != '"') return false;
         const uint8_t *b = ++p;
-        while (p < e && *p != '"') { if (*p == '\\' || *p < 0x20 || *p >= 0x7F) return false; ++p; }
-        if (p >= e) return false;
-        s = Str{b, (uint32_t)(p - b)};
-        ++p;
+        const uint8_t *q = (const uint8_t *)memchr(b, '"', (size_t)(e - b));
+        if (!q) return false;
+        uint8_t bad = 0;
+        for (const uint8_t *c = b; c < q; ++c) bad |= (uint8_t)((*c == '\\') | (*c < 0x20) | (*c >= 0x7F));
+        if (bad) return false;
+        s = Str{b, (uint32_t)(q - b)};
+        p = q + 1;
         return true;
     }
 };
@@ -123,54 +180,72 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
     *out = nullptr;
     Mapped js, gf;
     if (!js.open_(edges_json) || !gf.open_(gfa_path)) return SVJG_E_NOMEM;
+    const bool verbose = getenv("SVJG_VERBOSE") != nullptr;          // stage timers on stderr (measurement only)
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[svjg] graph loader, %s: %.2f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
 
     // ---- alt node name -> len(sequence) from the GFA (filter-alignments.py:105-113) ---------------------------------------
-    std::unordered_map<Str, uint32_t, StrHash, StrEq> alt_len;
-    if (gf.n && memchr(gf.p, '\r', gf.n)) return SVJG_E_UNSUPPORTED;          // Python's universal newlines would cut lines there
-    {
-        const uint8_t *p = gf.p, *e = gf.p + gf.n;
-        while (p < e) {
-            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
-            const uint8_t *le = nl ? nl : e;
-            if (*p == 'S') {
-                const uint8_t *t1 = (const uint8_t *)memchr(p, '\t', (size_t)(le - p));
-                if (!t1) return SVJG_E_UNSUPPORTED;
-                const uint8_t *t2 = (const uint8_t *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1));
-                if (!t2) return SVJG_E_UNSUPPORTED;
-                Str name{t1 + 1, (uint32_t)(t2 - t1 - 1)};
-                int colon = -1;
-                for (int i = (int)name.n - 1; i >= 0; --i) if (name.p[i] == ':') { colon = i; break; }
-                bool dot = false;
-                for (uint32_t i = (uint32_t)(colon + 1); i < name.n; ++i) dot |= name.p[i] == '.';
-                if (dot) {
-                    const uint8_t *re = le;                                   // line.rstrip()
-                    while (re > p && py_ws(re[-1])) --re;
-                    if (re <= t2) return SVJG_E_UNSUPPORTED;                  // third column gone: IndexError in the reference
-                    const uint8_t *t3 = (const uint8_t *)memchr(t2 + 1, '\t', (size_t)(re - t2 - 1));
-                    const uint8_t *se = t3 ? t3 : re;
-                    for (const uint8_t *q = p; q < se; ++q) if (*q >= 0x80) return SVJG_E_UNSUPPORTED;
-                    if ((uint64_t)(se - t2 - 1) >= 0xFFFFFFFFull) return SVJG_E_UNSUPPORTED;
-                    alt_len[name] = (uint32_t)(se - t2 - 1);
+    StrMap alt_len;
+    // (on a thread of its own, beside the parse of the edge table)
+    auto scan_gfa = [&]() -> int {
+        if (gf.n && memchr(gf.p, '\r', gf.n)) return SVJG_E_UNSUPPORTED;          // Python's universal newlines would cut lines there
+        {
+            const uint8_t *p = gf.p, *e = gf.p + gf.n;
+            while (p < e) {
+                const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+                const uint8_t *le = nl ? nl : e;
+                if (*p == 'S') {
+                    const uint8_t *t1 = (const uint8_t *)memchr(p, '\t', (size_t)(le - p));
+                    if (!t1) return SVJG_E_UNSUPPORTED;
+                    const uint8_t *t2 = (const uint8_t *)memchr(t1 + 1, '\t', (size_t)(le - t1 - 1));
+                    if (!t2) return SVJG_E_UNSUPPORTED;
+                    Str name{t1 + 1, (uint32_t)(t2 - t1 - 1)};
+                    int colon = -1;
+                    for (int i = (int)name.n - 1; i >= 0; --i) if (name.p[i] == ':') { colon = i; break; }
+                    bool dot = false;
+                    for (uint32_t i = (uint32_t)(colon + 1); i < name.n; ++i) dot |= name.p[i] == '.';
+                    if (dot) {
+                        const uint8_t *re = le;                                   // line.rstrip()
+                        while (re > p && py_ws(re[-1])) --re;
+                        if (re <= t2) return SVJG_E_UNSUPPORTED;                  // third column gone: IndexError in the reference
+                        const uint8_t *t3 = (const uint8_t *)memchr(t2 + 1, '\t', (size_t)(re - t2 - 1));
+                        const uint8_t *se = t3 ? t3 : re;
+                        for (const uint8_t *q = p; q < se; ++q) if (*q >= 0x80) return SVJG_E_UNSUPPORTED;
+                        if ((uint64_t)(se - t2 - 1) >= 0xFFFFFFFFull) return SVJG_E_UNSUPPORTED;
+                        alt_len.put(name, 0) = (uint32_t)(se - t2 - 1);
+                    }
                 }
+                if (!nl) break;
+                p = nl + 1;
             }
-            if (!nl) break;
-            p = nl + 1;
         }
-    }
 
+        return 0;
+    };
+    int gfa_rc = 0;
+    std::thread gfa_thread([&] { gfa_rc = scan_gfa(); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{gfa_thread};
     // ---- the edge table -------------------------------------------------------------------------------------------------
     std::vector<JsonKey> keys;
     std::vector<Ent> ents;
+    keys.reserve(js.n / 128 + 16); ents.reserve(js.n / 128 + 16);     // (indent=4 output: ~145 bytes per key)
     {
         Parser ps{js.p, js.p + js.n};
         if (!ps.eat('{')) return SVJG_E_UNSUPPORTED;
-        std::unordered_map<Str, int, StrHash, StrEq> seen;
+        // a duplicate key makes json.load keep the last one.  Two keys WITH entries that are equal give two equal forward
+        // queries in the link table below and are refused there; a key with an empty list is remembered here and must not
+        // repeat any other key.
+        std::vector<Str> empties;
         if (!ps.eat('}')) {
             for (;;) {
                 Str k;
                 if (!ps.str(k) || !ps.eat(':') || !ps.eat('[')) return SVJG_E_UNSUPPORTED;
-                if (!seen.emplace(k, 1).second) return SVJG_E_UNSUPPORTED;            // duplicate key: json.load keeps the last one
-                JsonKey jk{}; jk.ent_lo = (uint32_t)ents.size();
+                JsonKey jk{}; jk.k = k; jk.ent_lo = (uint32_t)ents.size();
                 if (!ps.eat(']')) {
                     for (;;) {
                         Ent en{};
@@ -197,7 +272,7 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
                     jk.l = Str{k.p, (uint32_t)(a1 - k.p)}; jk.sl = a1[1] == '-';
                     jk.r = Str{rb, (uint32_t)(a3 - rb)}; jk.sr = a3[1] == '-';
                     keys.push_back(jk);
-                }
+                } else empties.push_back(k);
                 if (ps.eat(',')) continue;
                 if (ps.eat('}')) break;
                 return SVJG_E_UNSUPPORTED;
@@ -205,21 +280,31 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
         }
         ps.ws();
         if (ps.p != ps.e) return SVJG_E_UNSUPPORTED;
+        if (!empties.empty()) {
+            StrMap em;
+            for (auto &k : empties) em.put(k, 1);
+            for (auto &jk : keys) if (em.find(jk.k)) return SVJG_E_UNSUPPORTED;
+        }
     }
 
+    lap("edge table JSON");
+    gfa_thread.join();
+    if (gfa_rc) return gfa_rc;
+    lap("waiting for the alt node lengths from the GFA");
     // ---- nodes ------------------------------------------------------------------------------------------------------------
-    std::unordered_map<Str, uint32_t, StrHash, StrEq> name_ix;       // name -> index into info
+    StrMap name_ix;                                                   // name -> index into info
     std::vector<NodeInfo> info;
-    auto add_name = [&](Str nm) -> bool {
-        if (name_ix.find(nm) != name_ix.end()) return true;
+    auto add_name = [&](Str nm, uint32_t &ix) -> bool {
+        if (const uint32_t *q = name_ix.find(nm)) { ix = *q; return true; }
         NodeInfo ni{};
         if (!parse_name(nm, ni)) return false;
-        name_ix.emplace(nm, (uint32_t)info.size());
+        ix = (uint32_t)info.size();
+        name_ix.put(nm, ix);
         info.push_back(ni);
         return true;
     };
-    for (auto &kv : alt_len) if (!add_name(kv.first)) return SVJG_E_UNSUPPORTED;
-    for (auto &k : keys) if (!add_name(k.l) || !add_name(k.r)) return SVJG_E_UNSUPPORTED;
+    { uint32_t ix; for (size_t i = 0; i < alt_len.keys.size(); ++i) if (!add_name(alt_len.keys[i], ix)) return SVJG_E_UNSUPPORTED; }
+    for (auto &k : keys) if (!add_name(k.l, k.li) || !add_name(k.r, k.ri)) return SVJG_E_UNSUPPORTED;
     // chromosomes sorted by their bytes
     std::vector<Str> chroms;
     {
@@ -233,10 +318,11 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
         for (auto &ni : info) {
             ni.cidx = cidx[ni.chrom];
             ni.key = ((uint64_t)ni.cidx << 48) | ((uint64_t)ni.pos << 16) | ((uint64_t)ni.kind << 15) | (ni.kind ? ni.v2 : 0u);
-            if (ni.kind) { auto it = alt_len.find(ni.name); ni.aux = it == alt_len.end() ? SVJG_LEN_UNKNOWN : it->second; }
+            if (ni.kind) { const uint32_t *it = alt_len.find(ni.name); ni.aux = it ? *it : SVJG_LEN_UNKNOWN; }
             else ni.aux = ni.v2;
         }
     }
+    lap("node names");
     const uint32_t n_nodes = (uint32_t)info.size();
     std::vector<uint32_t> order(n_nodes);
     for (uint32_t i = 0; i < n_nodes; ++i) order[i] = i;
@@ -245,6 +331,7 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
     std::vector<uint32_t> id_of(n_nodes);                            // info index -> node id
     for (uint32_t i = 0; i < n_nodes; ++i) id_of[order[i]] = i;
 
+    lap("node order");
     svjg_hostgraph *G = new svjg_hostgraph();
     G->nodes.resize((size_t)n_nodes + 1);
     for (uint32_t i = 0; i < n_nodes; ++i) { G->nodes[i].key = info[order[i]].key; G->nodes[i].aux = info[order[i]].aux; G->nodes[i].row = 0; }
@@ -262,29 +349,27 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
     std::vector<Q> qs;
     qs.reserve(keys.size() * 2);
     for (uint32_t i = 0; i < keys.size(); ++i) {
-        const uint32_t a = id_of[name_ix[keys[i].l]], b = id_of[name_ix[keys[i].r]];
+        const uint32_t a = id_of[keys[i].li], b = id_of[keys[i].ri];
         const uint32_t sl = keys[i].sl, sr = keys[i].sr;
         qs.push_back(Q{((uint64_t)a << 33) | ((uint64_t)sl << 32) | ((uint64_t)b << 1) | sr, i, 0});
         qs.push_back(Q{((uint64_t)b << 33) | ((uint64_t)(sr ^ 1u) << 32) | ((uint64_t)a << 1) | (sl ^ 1u), i, 1});
     }
     std::sort(qs.begin(), qs.end(), [](const Q &x, const Q &y) { return x.key != y.key ? x.key < y.key : x.rev < y.rev; });
-    std::unordered_map<Str, uint32_t, StrHash, StrEq> slot_of;
+    StrMap slot_of;
     std::vector<uint32_t> left_count((size_t)n_nodes + 1, 0);
+    std::vector<uint32_t> hv;
+    G->edges.reserve(qs.size());
     for (size_t i = 0; i < qs.size();) {
         size_t j = i;
         while (j < qs.size() && qs[j].key == qs[i].key) ++j;
         // at most one forward and one reversed entry per query (keys are unique and name <-> id is one to one)
         if (j - i > 2 || (j - i == 2 && qs[i].rev == qs[i + 1].rev)) { delete G; return SVJG_E_UNSUPPORTED; }
-        std::vector<uint32_t> hv;
+        hv.clear();
         for (size_t t = i; t < j; ++t)
             for (uint32_t en = keys[qs[t].jk].ent_lo; en < keys[qs[t].jk].ent_hi; ++en) {
-                auto it = slot_of.find(ents[en].sv);
-                uint32_t s;
-                if (it == slot_of.end()) {
-                    s = (uint32_t)slot_of.size();
-                    slot_of.emplace(ents[en].sv, s);
-                    G->sv_blob.append((const char *)ents[en].sv.p, ents[en].sv.n); G->sv_blob.push_back('\0');
-                } else s = it->second;
+                bool fresh;
+                const uint32_t s = slot_of.put(ents[en].sv, (uint32_t)slot_of.size(), &fresh);
+                if (fresh) { G->sv_blob.append((const char *)ents[en].sv.p, ents[en].sv.n); G->sv_blob.push_back('\0'); }
                 hv.push_back((s << 1) | ents[en].allele);
             }
         svjg_edge ed{};
@@ -302,6 +387,7 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
     for (uint32_t i = 0; i < n_nodes; ++i) left_count[i + 1] += left_count[i];
     for (uint32_t i = 0; i <= n_nodes; ++i) G->nodes[i].row = left_count[i];
 
+    lap("link table");
     // ---- names that are proper substrings of other names (strand quirk, filter-alignments.py:206; svjg/graph.py: _hazards) -----
     {
         bool colon_in_chrom = false;
@@ -347,6 +433,7 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
         for (uint32_t i = 0; i < n_nodes; ++i) if (hz[i]) { G->nodes[id_of[i]].row |= 0x80000000u; ++G->n_hazard; }
     }
 
+    lap("substring hazards");
     const uint64_t n_edges = G->edges.size(), n_hits = G->hits.size();
     if (G->edges.empty()) G->edges.push_back(svjg_edge{});           // (the arrays are never empty, like numpy's in svjg/graph.py)
     if (G->hits.empty()) G->hits.push_back(0);

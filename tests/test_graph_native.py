@@ -63,6 +63,8 @@ def test_irregular_inputs_are_left_to_python(tmp_path):
         "escape": '{"1:1-4@+@1:5-9@+": [["1:DEL\\u002d4-9", 0]]}',
         "unicode": '{"1:1-4@+@1:5-9@+": [["é:DEL-4-9", 0]]}',
         "duplicate": '{"1:1-4@+@1:5-9@+": [["a", 0]], "1:1-4@+@1:5-9@+": [["b", 0]]}',
+        "duplicate_then_empty": '{"1:1-4@+@1:5-9@+": [["a", 0]], "1:1-4@+@1:5-9@+": []}',
+        "empty_then_duplicate": '{"1:1-4@+@1:5-9@+": [], "1:1-4@+@1:5-9@+": [["a", 0]]}',
         "allele2": '{"1:1-4@+@1:5-9@+": [["a", 2]]}',
         "allele_true": '{"1:1-4@+@1:5-9@+": [["a", true]]}',
         "allele_float": '{"1:1-4@+@1:5-9@+": [["a", 0.0]]}',
