@@ -154,6 +154,12 @@ def main():
             if tr and tr["text_bytes"] == int(gaf.size) and world == 1:
                 res["roofline"]["traffic"] = tr["traffic_bytes"]
                 res["roofline"]["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
+                if tr.get("valu_wave_instructions"):
+                    # what actually bounds the kernel: VALU issue (from the committed SQ_INSTS_VALU pass, 4 cycles per wave
+                    # instruction on 1024 SIMDs at 2.4 GHz), reported beside the HBM roofline the contract asks for
+                    issue_ms = tr["valu_wave_instructions"] * 4 / 1024 / 2.4e9 * 1e3
+                    res["roofline"]["valu_issue"] = {"wave_instructions_per_launch": tr["valu_wave_instructions"], "issue_ms": round(issue_ms, 3),
+                                                     "frac_of_launch": round(issue_ms / k_main, 3)}
         except (OSError, ValueError, KeyError):
             pass
         if not args.no_cpu_baseline and world == 1:            # reported on rank 0 at N = 1 only
