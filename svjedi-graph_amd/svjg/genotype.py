@@ -70,14 +70,17 @@ class VcfRows:
                 if line.startswith("#C"):
                     self.items.append(("h", FORMAT_HEADER))
                     continue
-                chrom, pos, _id, _ref, alt, _q, _f, info, *_rest = line.rstrip("\n").split("\t")
+                text = line.rstrip("\n")
+                cols = text.split("\t")
+                chrom, pos, _id, _ref, alt, _q, _f, info, *_rest = cols
                 svtype, key, length = row_key(chrom, pos, alt, info, ins_seen)
                 code = TYPE_CODE.get(svtype)
                 types.append(code if code is not None else 0)
                 oks.append((3 if slot_is_presence else 1) if (code is not None and abs(length) >= 50) else 0)
                 slots.append(slot_of.get(key, NONE))
-                raw = line.split("\t")
-                self.prefix.append(line.rstrip("\n") if len(raw) <= 8 else "\t".join(raw[:8]))
+                # the first eight columns as they stand (columns 1..8 cannot hold the terminator, so the split of the
+                # stripped line has the same first eight as the reference's split of the raw one)
+                self.prefix.append(text if len(cols) <= 8 else "\t".join(cols[:8]))
                 self.items.append(("r", len(types) - 1))
         self.sv_type = np.array(types, dtype=np.uint8)
         self.slot = np.array(slots, dtype=np.uint32)
