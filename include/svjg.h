@@ -127,8 +127,7 @@ int svjg_load_graph(svjg_ctx *ctx, const svjg_graph *g);
  * Lines end at \n, \r\n or a lone \r and the last line may be unterminated, as in Python's text mode.
  * The _file forms take the bytes [offset, offset + n_bytes) of the file itself (the `for line in aln_file` of
  * filter-alignments.py:123-126 without a host copy of the text): feeder threads pread() pieces into pinned buffers
- * that go to HBM while the next pieces are read; svjg_classify_file uses `offset` as base_offset.  Buffers of 64 MB
- * and more given to svjg_gaf_upload take the same staged route (memcpy instead of pread). */
+ * that go to HBM while the next pieces are read; svjg_classify_file uses `offset` as base_offset. */
 int svjg_gaf_upload(svjg_ctx *ctx, const char *gaf, uint64_t n_bytes);
 int svjg_gaf_upload_file(svjg_ctx *ctx, const char *path, uint64_t offset, uint64_t n_bytes);
 int svjg_classify_resident(svjg_ctx *ctx, uint64_t base_offset, int want_hits);

@@ -44,7 +44,15 @@ def main():
     print(f"graph tables -> device: {(time.perf_counter() - t) * 1e3:.0f} ms")
     data = flt.read_gaf(path)
     lib = ctx.lib
-    clock("svjg_gaf_upload, mapped file (staged memcpy)", lambda: ctx.upload(data))
+    # cold, as the scripts meet it (first touch of the mapping / first read of the file; includes the device allocation)
+    mode = sys.argv[2] if len(sys.argv) > 2 else "map"
+    t = time.perf_counter()
+    if mode == "map":
+        ctx.upload(data)
+    else:
+        ctx._chk(lib.svjg_gaf_upload_file(ctx.h, os.fsencode(path), 0, n))
+    print(f"cold first upload, {mode}: {(time.perf_counter() - t) * 1e3:.0f} ms")
+    clock("svjg_gaf_upload, mapped file (one hipMemcpyAsync)", lambda: ctx.upload(data))
     clock("svjg_gaf_upload_file (staged pread)", lambda: ctx._chk(lib.svjg_gaf_upload_file(ctx.h, os.fsencode(path), 0, n)))
     small = np.array(data[: 60 << 20])
     t = time.perf_counter(); ctx.upload(small); dt = time.perf_counter() - t
