@@ -186,6 +186,21 @@ const svjg_graph *svjg_graph_view(const svjg_hostgraph *g);           /* d_over 
 int  svjg_graph_info(const svjg_hostgraph *g, const char **sv_ids_blob, uint64_t *sv_ids_len, uint32_t *n_hazard);   /* sv_ids: NUL-terminated, slot order */
 void svjg_graph_free(svjg_hostgraph *g);
 
+/* ---- native VCF rows (libsvjg_host.so, no GPU) ----------------------------------------------------
+ * Fast path of svjedi-graph_amd/svjg/genotype.py for ordinary files: every data row's sv_id key (predict-genotype.py:118-211)
+ * looked up among `n_keys` NUL-terminated keys (slots[i] = count slot of key i, NULL: slot = i; a repeated key: the last
+ * wins, like json.load) -> the three input arrays of svjg_genotype; svjg_vcf_write then produces the output file
+ * (predict-genotype.py:102-115, :248-271) from svjg_genotype's results.  slot_is_presence: ok = 3 instead of 1 (the
+ * count table IS the JSON: svjg_genotype's gate bit 1).  SVJG_E_UNSUPPORTED for anything but plain ASCII rows with plain
+ * decimal POS / END (and for every row the reference would crash on): the caller then runs the Python path. */
+typedef struct svjg_vcf svjg_vcf;
+int  svjg_vcf_load(const char *vcf_path, const char *keys_blob, uint64_t blob_len, const uint32_t *slots, uint32_t n_keys,
+                   int slot_is_presence, svjg_vcf **out);
+int  svjg_vcf_arrays(const svjg_vcf *v, const uint8_t **sv_type, const uint32_t **slot, const uint8_t **ok, uint64_t *n_rows);
+int  svjg_vcf_write(const svjg_vcf *v, const char *out_path, const uint8_t *gt, const int64_t *pl, const uint32_t *raw,
+                    const uint8_t *genotyped, uint64_t *n_genotyped);
+void svjg_vcf_free(svjg_vcf *v);
+
 /* ---- measurement hooks (bench.py): HIP-event time of the kernels of the last classify / genotype ---- */
 int svjg_last_kernel_ms(svjg_ctx *ctx, float *classify_main_ms, float *classify_slow_ms, float *genotype_ms);
 int svjg_sync(svjg_ctx *ctx);

@@ -75,7 +75,8 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS) + ("svjg_write_informative_json", "svjg_count_informative_json", "svjg_host_free",
-                          "svjg_graph_load", "svjg_graph_view", "svjg_graph_info", "svjg_graph_free")
+                          "svjg_graph_load", "svjg_graph_view", "svjg_graph_info", "svjg_graph_free",
+                          "svjg_vcf_load", "svjg_vcf_arrays", "svjg_vcf_write", "svjg_vcf_free")
 _lib = None
 _host_lib = None
 
@@ -103,8 +104,76 @@ def load_host_library():
         lib.svjg_graph_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
         lib.svjg_graph_free.restype = None
         lib.svjg_graph_free.argtypes = [ctypes.c_void_p]
+        lib.svjg_vcf_load.restype = ctypes.c_int
+        lib.svjg_vcf_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int,
+                                      ctypes.POINTER(ctypes.c_void_p)]
+        lib.svjg_vcf_arrays.restype = ctypes.c_int
+        lib.svjg_vcf_arrays.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_void_p)] * 3 + [ctypes.POINTER(ctypes.c_uint64)]
+        lib.svjg_vcf_write.restype = ctypes.c_int
+        lib.svjg_vcf_write.argtypes = [ctypes.c_void_p, ctypes.c_char_p] + [ctypes.c_void_p] * 4 + [ctypes.POINTER(ctypes.c_uint64)]
+        lib.svjg_vcf_free.restype = None
+        lib.svjg_vcf_free.argtypes = [ctypes.c_void_p]
         _host_lib = lib
     return _host_lib
+
+
+class NativeVcfRows:
+    """Rows of a VCF held by libsvjg_host (svjg_vcf_*): the same three arrays as svjg.genotype.VcfRows, and the writer."""
+
+    def __init__(self, lib, h):
+        self.lib, self.h = lib, h
+        p = [ctypes.c_void_p() for _ in range(3)]
+        n = ctypes.c_uint64(0)
+        lib.svjg_vcf_arrays(h, ctypes.byref(p[0]), ctypes.byref(p[1]), ctypes.byref(p[2]), ctypes.byref(n))
+        n = n.value
+
+        def arr(ptr, dt):
+            return np.frombuffer(ctypes.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy() if n else np.zeros(0, dtype=dt)
+        self.sv_type, self.slot, self.ok = arr(p[0], np.uint8), arr(p[1], np.uint32), arr(p[2], np.uint8)
+
+    def write(self, out_path, gt, pl, raw, done):
+        gt = np.ascontiguousarray(gt, dtype=np.uint8); pl = np.ascontiguousarray(pl, dtype=np.int64)
+        raw = np.ascontiguousarray(raw, dtype=np.uint32); done = np.ascontiguousarray(done, dtype=np.uint8)
+        n = len(self.sv_type)
+        if len(gt) != n or pl.shape != (n, 3) or raw.shape != (n, 2) or len(done) != n:
+            raise ValueError("result arrays do not match the rows")
+        nd = ctypes.c_uint64(0)
+        rc = self.lib.svjg_vcf_write(self.h, os.fsencode(out_path), gt.ctypes.data, pl.ctypes.data, raw.ctypes.data, done.ctypes.data, ctypes.byref(nd))
+        if rc:
+            raise OSError(f"cannot write {out_path} ({rc})")
+        return nd.value
+
+    def close(self):
+        if self.h:
+            self.lib.svjg_vcf_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def vcf_load_native(vcf_path, keys, slots=None, slot_is_presence=False):
+    """NativeVcfRows, or None when the native reader leaves the file to svjg.genotype.VcfRows.  keys: iterable of sv_id strings
+    (slots: their count slots, default 0..n-1)."""
+    lib = load_host_library()
+    keys = list(keys)
+    try:
+        blob = ("\0".join(keys) + "\0").encode("ascii") if keys else b""
+    except UnicodeEncodeError:
+        return None
+    if blob.count(b"\0") != len(keys):                          # a NUL inside a key
+        return None
+    sl = None if slots is None else np.ascontiguousarray(slots, dtype=np.uint32)
+    h = ctypes.c_void_p()
+    rc = lib.svjg_vcf_load(os.fsencode(vcf_path), blob, len(blob), None if sl is None else sl.ctypes.data, len(keys), int(slot_is_presence), ctypes.byref(h))
+    if rc == -11:
+        return None
+    if rc:
+        raise SvjgError(f"svjg_vcf_load failed ({rc})")
+    return NativeVcfRows(lib, h)
 
 
 def graph_load_native(edges_json, gfa):

@@ -114,11 +114,35 @@ def write_vcf(out_path, rows, gt, pl, raw, done):
     return n_done
 
 
+def open_rows(vcf_path, slot_of, slot_is_presence=False):
+    """The rows of the VCF with their count slots: the native reader (libsvjg_host, svjg_vcf_load) for ordinary files, the
+    Python rows above (the semantics, and what raises the reference's exceptions) for everything it declines.
+    slot_of: dict key -> slot, or a list of keys (slot = index; a repeated key: the last one wins, like json.load).
+    SVJG_PY_VCF=1 forces the Python rows."""
+    import os
+    from . import capi
+    if not os.environ.get("SVJG_PY_VCF"):
+        if isinstance(slot_of, dict):
+            rows = capi.vcf_load_native(vcf_path, slot_of.keys(), np.fromiter(slot_of.values(), dtype=np.uint32, count=len(slot_of)), slot_is_presence)
+        else:
+            rows = capi.vcf_load_native(vcf_path, slot_of, None, slot_is_presence)
+        if rows is not None:
+            return rows
+    if not isinstance(slot_of, dict):
+        slot_of = {k: i for i, k in enumerate(slot_of)}
+    return VcfRows(vcf_path, slot_of, slot_is_presence)
+
+
 def genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support=3, err=0.00005, slot_is_presence=False):
     """Counts already live in the context (fused path, or set_counts): parse, run the kernel, write."""
-    rows = VcfRows(vcf_path, slot_of, slot_is_presence)
+    rows = open_rows(vcf_path, slot_of, slot_is_presence)
     gt, pl, raw, done = ctx.genotype(rows.sv_type, rows.slot, rows.ok, min_support, err)
-    return write_vcf(out_path, rows, gt, pl, raw, done)
+    if isinstance(rows, VcfRows):
+        return write_vcf(out_path, rows, gt, pl, raw, done)
+    try:
+        return rows.write(out_path, gt, pl, raw, done)
+    finally:
+        rows.close()
 
 
 def run(json_path, vcf_path, out_path, min_support=3, err=0.00005, device=0):
@@ -127,15 +151,12 @@ def run(json_path, vcf_path, out_path, min_support=3, err=0.00005, device=0):
     got = flt.read_handoff(json_path)                            # left by our filter-alignments.py for exactly this file, else None
     if got is None:
         got = capi.count_informative_json(json_path)             # len() of the two lists of every key (:219-226)
-    keys, counts = got
-    slot_of = {}
-    for i, k in enumerate(keys):
-        slot_of[k] = i                                           # a repeated key: the last one wins, like json.load
+    keys, counts = got                                           # (a repeated key: the last one wins, like json.load — open_rows)
     ctx = capi.Context(device)
     try:
         ctx.alloc_counts(len(keys))
         ctx.set_counts(counts)
-        n = genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support, err, slot_is_presence=True)
+        n = genotype_with_counts(ctx, vcf_path, list(keys), out_path, min_support, err, slot_is_presence=True)
     finally:
         ctx.close()
     print("Genotyped svs: " + str(n))

@@ -9,10 +9,10 @@ cp svjedi-graph_amd/csrc/libsvjg_host.so /tmp/svjg_host_keep.so
 restore() { cp /tmp/svjg_host_keep.so svjedi-graph_amd/csrc/libsvjg_host.so; [ -f /tmp/svjg_hostsim_keep.so ] && cp /tmp/svjg_hostsim_keep.so tests/hostsim/_hostsim.so; touch tests/hostsim/_hostsim.so; }
 trap restore EXIT
 SAN="-O1 -g -std=c++17 -Wall -shared -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer"
-g++ $SAN -pthread -o svjedi-graph_amd/csrc/libsvjg_host.so svjedi-graph_amd/csrc/svjg_json.cpp svjedi-graph_amd/csrc/svjg_graphload.cpp
+g++ $SAN -pthread -o svjedi-graph_amd/csrc/libsvjg_host.so svjedi-graph_amd/csrc/svjg_json.cpp svjedi-graph_amd/csrc/svjg_graphload.cpp svjedi-graph_amd/csrc/svjg_vcf.cpp
 g++ $SAN -o tests/hostsim/_hostsim.so tests/hostsim/hostsim.cpp
 touch tests/hostsim/_hostsim.so
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$ASAN python -m pytest -q -p no:cacheprovider \
-    tests/test_json_writer.py tests/test_graph_native.py tests/test_handoff.py tests/test_fuzz_golden.py tests/test_hostsim_parity.py 2>&1 | tee /tmp/svjg_asan.log | tail -3
+    tests/test_json_writer.py tests/test_vcf_native.py tests/test_graph_native.py tests/test_handoff.py tests/test_fuzz_golden.py tests/test_hostsim_parity.py 2>&1 | tee /tmp/svjg_asan.log | tail -3
 if grep -q "ERROR: AddressSanitizer\|runtime error" /tmp/svjg_asan.log; then echo "sanitizer findings: see /tmp/svjg_asan.log"; exit 1; fi
 echo "sanitizers: clean"
