@@ -4,6 +4,10 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <chrono>
 #include <vector>
 #include "../../include/svjg.h"
 
@@ -156,6 +160,14 @@ inline bool chd_place(const std::vector<uint64_t> &h, uint32_t n_slots, uint32_t
 
 inline KernelTables build_kernel_tables(const svjg_graph &g) {
     KernelTables kt;
+    const bool verbose = getenv("SVJG_VERBOSE") != nullptr;          // stage timers on stderr (measurement only)
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[svjg] kernel tables, %s: %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<uint64_t> node_pre((size_t)g.n_nodes, 0);    // name pre-hash of every node the name table holds
     std::vector<uint8_t> node_has((size_t)g.n_nodes, 0);
     std::vector<uint32_t> node_slot((size_t)g.n_nodes, 0);
@@ -195,6 +207,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             }
             hs.resize(w); key_node.resize(w); ent.resize(w * 10);
         }
+        lap("name words and pre-hashes");
         const uint64_t n = hs.size();
         std::vector<uint32_t> slot_of;
         uint64_t slots = n + n / 4 + 16;                      // load <= 0.8
@@ -205,6 +218,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             if (grow == 6) { kt.names_left_out += n; hs.clear(); key_node.clear(); slot_of.clear(); break; }   // never seen: everything takes the exact path
             slots += slots / 4;
         }
+        lap("hash and displace");
         kt.names.assign((size_t)kt.name_slots * NAME_ENT_WORDS, 0);
         for (uint64_t j = 0; j < kt.name_slots; ++j) {
             uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
@@ -251,6 +265,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
     }
     // A link that cannot be placed (never seen with 64-bit pre-hashes at load <= 0.4) would be a silent miss in the
     // kernel: its left node is flagged hazard-prone instead, which sends the lines that touch it to the exact path.  links_left_out counts links lost for good (never seen: the library then uses the exact path only).
+    lap("node records with inline links");
     uint64_t lsz = 16;
     while (lsz < 5 * g.n_edges / 2 + 2) lsz *= 2;
     {
@@ -273,6 +288,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
                 left_node.push_back((uint32_t)n);
             }
         }
+        lap("link candidates");
         std::vector<uint32_t> unplaced;
         uint64_t n_unplaced = 0;
         std::vector<int64_t> owner = cuckoo_place(pre, kt.link_mask, kt.link_seed, n_unplaced, &unplaced);
@@ -283,6 +299,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
         kt.links_unplaced = n_unplaced;
         for (uint32_t k : unplaced) kt.names[(size_t)node_slot[left_node[k]] * NAME_ENT_WORDS + 6] |= 1u << 5;
     }
+    lap("link table placement");
     kt.node_pre.swap(node_pre); kt.node_has.swap(node_has); kt.node_slot.swap(node_slot);
     return kt;
 }

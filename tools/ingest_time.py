@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measurement only: the stages between the GAF file and the hit records on the host.
 
-    python tools/ingest_time.py [c2|c3]
+    python tools/ingest_time.py [c2|c3|c4] [map|file] [n_alignments]
 """
 import os
 import sys
@@ -20,6 +20,8 @@ def main():
     from svjg.graph import Graph
     name = sys.argv[1] if len(sys.argv) > 1 else "c3"
     n_aln, n_sv, n_chrom, mix, seed = synth.CONFIGS[name]
+    if len(sys.argv) > 3:
+        n_aln = int(sys.argv[3])
     tmp = tempfile.mkdtemp(prefix="svjg_ing_", dir="/dev/shm")
     pre = os.path.join(tmp, "p")
     synth.generate(pre, n_aln, n_sv, n_chrom, mix, seed)
