@@ -165,6 +165,8 @@ constexpr unsigned long long DEFER_CUT = 1ull << 63;                    // defer
 
 // Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the 64-bit pre-hash of the node-name table
 // (svjg_line.h: name_prehash).
+// NW = words looked at: 8, or 6 when the caller knows L <= 24 (the words beyond are zero and add nothing to the hash)
+template <uint32_t NW>
 __device__ inline uint64_t name_words(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
     const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
     const uint32_t sh = a0 & 3u;
@@ -172,7 +174,9 @@ __device__ inline uint64_t name_words(const uint8_t *text, uint32_t a0, uint32_t
     uint64_t h = (uint64_t)L * 0x7FEB352Du;
     const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
 #pragma unroll
-    for (uint32_t i = 0; i < 8; ++i) {
+    for (uint32_t i = NW; i < 8; ++i) d[i] = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < NW; ++i) {
         const uint32_t nx = w[i + 1];
         const uint32_t nb = L > 4 * i ? L - 4 * i : 0u;                 // bytes of the name in this word
         d[i] = __builtin_amdgcn_alignbyte(nx, prev, sh) & (nb >= 4 ? 0xFFFFFFFFu : ((1u << ((8 * nb) & 31u)) - 1u));
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // -- the node of this lane: line, index in the line, name --
                 const bool act = lane < n_pass;
                 const uint32_t o = obase + p0 + lane;
-                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, oribit = 0, meta = 0, need_l = 0, need_r = 0, d[8];
+                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, oribit = 0, meta = 0, need_l = 0, need_r = 0, na0 = 0, d[8];
                 uint64_t h = 0;
                 bool live = false, probe = false;
                 if (act) {
@@ -577,9 +581,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         oribit = text[a0 - 1] == '<' ? 1u : 0u;
                         len = b0 - a0;
                         probe = len - 1u <= 31u;                         // names of 1..32 bytes; longer ones: exact path
-                        if (probe) h = name_words(text, a0, len, d);
+                        na0 = a0;
                     }
                 }
+                // (wave-uniform choice: node names of the usual length fit six words)
+                if (__ballot(probe && len > 24u)) { if (probe) h = name_words<8>(text, na0, len, d); }
+                else if (probe) h = name_words<6>(text, na0, len, d);
                 if (!live) { j = 0; lk = 0; lnb = 0; }
                 const unsigned long long lmask = (lk >= 64u ? ~0ull : ((1ull << lk) - 1ull)) << (lnb & 63u);   // the lanes of this node's line
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
