@@ -308,6 +308,34 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
         orc.filter(inf["gaf"].tobytes() + dense, want_hits=False)
 
 
+def test_node_names_of_25_to_32_bytes(ctx, tmp_path):
+    """Chromosome names that make node names longer than 24 bytes (the record's second name part, the eight-word hash)
+    next to short ones in the same passes; a name beyond 32 bytes sends its lines to the exact path.  Counts are the oracle's."""
+    import synth
+    from svjg.graph import Graph
+    pre = str(tmp_path / "n")
+    synth.generate(pre, 30000, 900, 3, "mixed", 57)
+    for ext in (".gfa", "_svs_edges.json", ".gaf", ".vcf"):
+        t = open(pre + ext).read()
+        t = t.replace("chr2:", "chromosome_2:").replace("chr2\t", "chromosome_2\t")             # 28-byte node names
+        t = t.replace("chr3:", "chromosome_number_three:").replace("chr3\t", "chromosome_number_three\t")   # > 32 bytes
+        open(pre + ext, "w").write(t)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    lens = [len(n) for n in g.node_names]
+    assert any(25 <= x <= 32 for x in lens) and any(x > 32 for x in lens) and any(x <= 24 for x in lens)
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    gaf = np.fromfile(pre + ".gaf", dtype=np.uint8)
+    want, _, n_lines = orc.filter(gaf, want_hits=False)
+    ctx.load_graph(g)
+    ctx.classify(gaf)
+    assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 0
+    st = ctx.stats()
+    n_three = sum(1 for l in open(pre + ".gaf") if "chromosome_number_three:" in l.split("\t")[5])
+    n_two = sum(1 for l in open(pre + ".gaf") if "chromosome_2:" in l.split("\t")[5])
+    assert st["n_lines"] == n_lines and n_two > 1000
+    assert st["n_deferred"] <= n_three + 50                     # the 28-byte names stay in the main kernel
+
+
 def test_lines_longer_than_the_look_ahead(ctx, tmp_path):
     """Every line carries a 3 KB tag: many lines run past the staged text of their stripe.  They get a stripe of their own in
     a second launch of the main kernel instead of the exact path (and the library widens the look-ahead for the next
