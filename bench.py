@@ -120,7 +120,7 @@ def main():
 
     st = ctx.stats()
     counts = ctx.counts()
-    gt, pl, raw, done = out
+    gt, pl, raw, done = (np.array(x) for x in out)            # (views of the library's pinned result block: copied before anything else runs)
 
     if rank == 0:
         total_aln = n_aln * world

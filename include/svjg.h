@@ -161,6 +161,11 @@ int svjg_allreduce_counts(svjg_ctx *ctx);
 int svjg_genotype(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok,
                   uint64_t n_rows, uint32_t min_support, double err,
                   uint8_t *gt, int64_t *pl, uint32_t *raw, uint8_t *genotyped);
+/* The same without the copy into caller buffers: the four pointers look into the context's pinned host block (where the
+ * device wrote the results) and stay valid until the next svjg_genotype / svjg_genotype_view / svjg_destroy on `ctx`. */
+int svjg_genotype_view(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok,
+                       uint64_t n_rows, uint32_t min_support, double err,
+                       const uint8_t **gt, const int64_t **pl, const uint32_t **raw, const uint8_t **genotyped);
 
 /* ---- host-side writer of <prefix>_informative_aln.json (libsvjg_host.so, no GPU involved) -----------------
  * Byte-identical to json.dumps(dict_of_informative_aln, sort_keys=True, indent=4) (filter-alignments.py:174-175)

@@ -498,11 +498,9 @@ extern "C" int svjg_allreduce_counts(svjg_ctx *c) {
 
 // ---- genotypes -----------------------------------------------------------------------------------------
 
-extern "C" int svjg_genotype(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
-                             uint32_t min_support, double err, uint8_t *gt, int64_t *pl, uint32_t *raw, uint8_t *genotyped) {
-    if (!c || !c->have_counts) return SVJG_E_ARG;
-    if (n_rows == 0) return 0;
-    if (!sv_type || !slot || !ok || !gt || !pl || !raw || !genotyped) return SVJG_E_ARG;
+// results of all rows -> the pinned host block of the context: [ pl 24 | raw 8 | gt 1 | done 1 ] x n_rows
+static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
+                         uint32_t min_support, double err) {
     HIPCHK(c, hipSetDevice(c->device));
     for (uint64_t r = 0; r < n_rows; ++r)
         if (slot[r] != NONE32 && slot[r] >= c->n_slots) { c->err = "slot out of range"; return SVJG_E_ARG; }
@@ -561,9 +559,37 @@ extern "C" int svjg_genotype(svjg_ctx *c, const uint8_t *sv_type, const uint32_t
         grow_to = max_n + 1 + 1024;
         c->logfact_n = 0;                                    // rebuild, sized by max_n
     }
+    HIPCHK(c, hipEventElapsedTime(&c->ms_geno, c->ev[4], c->ev[5]));
+    return 0;
+}
+
+extern "C" int svjg_genotype(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
+                             uint32_t min_support, double err, uint8_t *gt, int64_t *pl, uint32_t *raw, uint8_t *genotyped) {
+    if (!c || !c->have_counts) return SVJG_E_ARG;
+    if (n_rows == 0) return 0;
+    if (!sv_type || !slot || !ok || !gt || !pl || !raw || !genotyped) return SVJG_E_ARG;
+    const int rc = genotype_rows(c, sv_type, slot, ok, n_rows, min_support, err);
+    if (rc) return rc;
+    const uint8_t *hb = (const uint8_t *)c->h_rows;
     memcpy(pl, hb, n_rows * 24); memcpy(raw, hb + n_rows * 24, n_rows * 8);
     memcpy(gt, hb + n_rows * 32, n_rows); memcpy(genotyped, hb + n_rows * 33, n_rows);
-    HIPCHK(c, hipEventElapsedTime(&c->ms_geno, c->ev[4], c->ev[5]));
+    return 0;
+}
+
+// The same, results left where the device wrote them: the four pointers look into the context's pinned host block and stay
+// valid until the next svjg_genotype / svjg_genotype_view / svjg_destroy on this context.
+extern "C" int svjg_genotype_view(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
+                                  uint32_t min_support, double err, const uint8_t **gt, const int64_t **pl, const uint32_t **raw,
+                                  const uint8_t **genotyped) {
+    if (!c || !c->have_counts || !gt || !pl || !raw || !genotyped) return SVJG_E_ARG;
+    *gt = nullptr; *pl = nullptr; *raw = nullptr; *genotyped = nullptr;
+    if (n_rows == 0) return 0;
+    if (!sv_type || !slot || !ok) return SVJG_E_ARG;
+    const int rc = genotype_rows(c, sv_type, slot, ok, n_rows, min_support, err);
+    if (rc) return rc;
+    const uint8_t *hb = (const uint8_t *)c->h_rows;
+    *pl = (const int64_t *)hb; *raw = (const uint32_t *)(hb + n_rows * 24);
+    *gt = hb + n_rows * 32; *genotyped = hb + n_rows * 33;
     return 0;
 }
 

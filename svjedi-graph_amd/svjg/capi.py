@@ -69,6 +69,8 @@ _SIGS = {
     "svjg_genotype": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                      ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
+    "svjg_genotype_view": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                          ctypes.c_uint32, ctypes.c_double] + [ctypes.POINTER(ctypes.c_void_p)] * 4),
     "svjg_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                            ctypes.POINTER(ctypes.c_float)]),
     "svjg_sync": (ctypes.c_int, [ctypes.c_void_p]),
@@ -362,22 +364,27 @@ class Context:
         self._chk(self.lib.svjg_allreduce_counts(self.h))
 
     def genotype(self, sv_type, slot, ok, min_support, err, reuse_outputs=False):
-        """reuse_outputs: hand back the same four arrays on every call (they are overwritten by the next call): a loop that
-        genotypes again and again then does not pay for fresh pages each time."""
+        """-> (gt, pl[n, 3], raw[n, 2], genotyped).  reuse_outputs: the arrays are read-only views of the library's pinned
+        result block (svjg_genotype_view: no copy); they are overwritten by the next call and die with the context, so copy
+        what has to outlive either."""
         n = len(sv_type)
         sv_type = np.ascontiguousarray(sv_type, dtype=np.uint8)
         slot = np.ascontiguousarray(slot, dtype=np.uint32)
         ok = np.ascontiguousarray(ok, dtype=np.uint8)
-        cached = getattr(self, "_geno_out", None)
-        if reuse_outputs and cached is not None and len(cached[0]) == n:
-            gt, pl, raw, done = cached
-        else:
-            gt = np.empty(n, dtype=np.uint8)
-            pl = np.empty((n, 3), dtype=np.int64)
-            raw = np.empty((n, 2), dtype=np.uint32)
-            done = np.empty(n, dtype=np.uint8)
-            if reuse_outputs:
-                self._geno_out = (gt, pl, raw, done)
+        if reuse_outputs and n:
+            p = [ctypes.c_void_p() for _ in range(4)]
+            self._chk(self.lib.svjg_genotype_view(self.h, sv_type.ctypes.data, slot.ctypes.data, ok.ctypes.data, n, min_support,
+                                                  float(err), *[ctypes.byref(x) for x in p]))
+
+            def view(ptr, count, dt):
+                a = np.frombuffer((ctypes.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr.value), dtype=dt)
+                a.flags.writeable = False
+                return a
+            return view(p[0], n, np.uint8), view(p[1], n * 3, np.int64).reshape(n, 3), view(p[2], n * 2, np.uint32).reshape(n, 2), view(p[3], n, np.uint8)
+        gt = np.empty(n, dtype=np.uint8)
+        pl = np.empty((n, 3), dtype=np.int64)
+        raw = np.empty((n, 2), dtype=np.uint32)
+        done = np.empty(n, dtype=np.uint8)
         self._chk(self.lib.svjg_genotype(self.h, sv_type.ctypes.data, slot.ctypes.data, ok.ctypes.data, n, min_support,
                                          float(err), gt.ctypes.data, pl.ctypes.data, raw.ctypes.data, done.ctypes.data))
         return gt, pl, raw, done

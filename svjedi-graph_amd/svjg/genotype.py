@@ -136,7 +136,7 @@ def open_rows(vcf_path, slot_of, slot_is_presence=False):
 def genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support=3, err=0.00005, slot_is_presence=False):
     """Counts already live in the context (fused path, or set_counts): parse, run the kernel, write."""
     rows = open_rows(vcf_path, slot_of, slot_is_presence)
-    gt, pl, raw, done = ctx.genotype(rows.sv_type, rows.slot, rows.ok, min_support, err)
+    gt, pl, raw, done = ctx.genotype(rows.sv_type, rows.slot, rows.ok, min_support, err, reuse_outputs=True)   # views: written out right away
     if isinstance(rows, VcfRows):
         return write_vcf(out_path, rows, gt, pl, raw, done)
     try:

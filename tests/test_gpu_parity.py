@@ -128,6 +128,10 @@ def test_likelihood_known_answers(ctx, golden):
             assert np.array_equal(raw, c[:, 1:3].astype(np.uint32))
             bad = np.where((gt != c[:, 4]) | (pl != c[:, 5:8]).any(axis=1))[0]
             assert len(bad) == 0, (c[bad[:5]], gt[bad[:5]], pl[bad[:5]])
+            # the zero-copy form (svjg_genotype_view): read-only views of the library's pinned block, same contents
+            v = ctx.genotype(c[:, 0].astype(np.uint8), np.arange(len(sel), dtype=np.uint32),
+                             np.full(len(sel), 3, dtype=np.uint8), int(ms), float(e), reuse_outputs=True)
+            assert all(np.array_equal(a, b) and not b.flags.writeable for a, b in zip((gt, pl, raw, done), v))
 
 
 @pytest.mark.parametrize("tag,ms,err", [("ms3", 3, None), ("ms1", 1, None), ("ms0", 0, None), ("ms3_e1e-3", 3, 0.001)])
