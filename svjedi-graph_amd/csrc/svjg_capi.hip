@@ -27,6 +27,7 @@ constexpr uint64_t STAGE_PIECE = 8ull << 20;
 struct svjg_ctx {
     int device = 0;
     int n_cu = 256;
+    int occ_main = 0;                    // workgroups of k_classify_main one CU holds
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
     std::string err;
@@ -338,9 +339,12 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
         a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
         size_t lds = LDS_MAIN;
-        int occ = 0;                                          // persistent grid: every CU filled to what LDS / registers admit
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_classify_main, (int)WG, lds) != hipSuccess || occ < 1) occ = 1;
-        const uint32_t full = (uint32_t)c->n_cu * (uint32_t)occ;
+        if (c->occ_main < 1) {                                // persistent grid: every CU filled to what LDS / registers admit (asked once)
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_classify_main, (int)WG, lds) != hipSuccess || occ < 1) occ = 1;
+            c->occ_main = occ;
+        }
+        const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ_main;
         uint32_t grid = a.n_chunks < full ? a.n_chunks : full;
         if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -502,8 +506,6 @@ extern "C" int svjg_allreduce_counts(svjg_ctx *c) {
 static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
                          uint32_t min_support, double err) {
     HIPCHK(c, hipSetDevice(c->device));
-    for (uint64_t r = 0; r < n_rows; ++r)
-        if (slot[r] != NONE32 && slot[r] >= c->n_slots) { c->err = "slot out of range"; return SVJG_E_ARG; }
     // one device block and its pinned host twin: [ pl 24 | raw 8 | gt 1 | done 1 ] n rows of output, max_n, then
     // [ slot 4 | type 1 | ok 1 ] n rows of input -> ONE copy in and ONE copy out per call whatever the number of arrays
     const uint64_t out_bytes = n_rows * 34, maxn_off = (out_bytes + 7) & ~7ull, in_off = maxn_off + 8, in_bytes = n_rows * 6;
@@ -528,7 +530,7 @@ static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *sl
     GenoArgs a{};
     a.counts = c->d_counts; a.sv_type = d_type; a.slot = d_slot; a.ok = d_ok; a.n_rows = n_rows; a.min_support = min_support;
     a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
-    a.gt = d_gt; a.pl = d_pl; a.raw = d_raw; a.genotyped = d_done; a.max_n = d_maxn;
+    a.gt = d_gt; a.pl = d_pl; a.raw = d_raw; a.genotyped = d_done; a.max_n = d_maxn; a.n_slots = c->n_slots;
     const uint32_t grid = (uint32_t)((n_rows + TPB - 1) / TPB);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     // One pass with the log10(i!) table at hand; the kernel reports the largest n = ref + alt it met beyond the table, and
@@ -553,6 +555,7 @@ static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *sl
         if (attempt == 0) HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
         HIPCHK(c, hipMemcpyAsync(hb, base, maxn_off + 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*(const unsigned int *)(hb + maxn_off + 4)) { c->err = "slot out of range"; return SVJG_E_ARG; }   // (checked by the kernel, row by row)
         const unsigned int max_n = *(const unsigned int *)(hb + maxn_off);
         if (max_n == 0) break;                               // every row found its binomial term
         if (attempt == 1) { c->err = "log10(i!) table could not be sized"; return SVJG_E_HIP; }

@@ -937,7 +937,8 @@ struct GenoArgs {
     double l_ok, l_err, l_half;        // log10(1-e), log10(e), log10(1/2) computed by the host libm like CPython does
     const dd *logfact; uint32_t logfact_n;
     uint8_t *gt; int64_t *pl; uint32_t *raw; uint8_t *genotyped;
-    unsigned int *max_n;               // k_geno_maxn output
+    unsigned int *max_n;               // [0] largest n = ref + alt beyond the log10(i!) table, [1] set if a row names a slot >= n_slots
+    uint32_t n_slots;
 };
 
 // normalised counts (predict-genotype.py:327-338) and the rounded ones fed to comb()
@@ -950,9 +951,10 @@ __device__ inline void geno_counts(uint32_t type, uint32_t ref, uint32_t alt, do
 
 __device__ inline bool geno_gate(const GenoArgs &a, uint64_t r, uint32_t &ref, uint32_t &alt) {
     ref = alt = 0;
-    const uint32_t ok = a.ok[r];
-    if (!(ok & 1u) || a.slot[r] == NONE32) return false;
-    unsigned long long c = a.counts[a.slot[r]];
+    const uint32_t ok = a.ok[r], sl = a.slot[r];
+    if (sl != NONE32 && sl >= a.n_slots) { atomicOr(a.max_n + 1, 1u); return false; }   // a caller error, reported after the pass
+    if (!(ok & 1u) || sl == NONE32) return false;
+    unsigned long long c = a.counts[sl];
     ref = (uint32_t)c; alt = (uint32_t)(c >> 32);
     // sv_id is a key of the informative dict (:216): a key exists iff it has >= 1 informative alignment,
     // unless the caller says the slot itself proves presence (stand-alone run from a JSON, ok bit 1)

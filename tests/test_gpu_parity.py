@@ -132,6 +132,13 @@ def test_likelihood_known_answers(ctx, golden):
             v = ctx.genotype(c[:, 0].astype(np.uint8), np.arange(len(sel), dtype=np.uint32),
                              np.full(len(sel), 3, dtype=np.uint8), int(ms), float(e), reuse_outputs=True)
             assert all(np.array_equal(a, b) and not b.flags.writeable for a, b in zip((gt, pl, raw, done), v))
+    # a row that names a count slot beyond the table is a caller error, with or without the gate bit
+    from svjg import capi
+    for okv in (3, 0):
+        with pytest.raises(capi.SvjgError):
+            ctx.genotype(np.zeros(3, dtype=np.uint8), np.array([0, ctx.n_slots, 1], dtype=np.uint32), np.full(3, okv, dtype=np.uint8), 3, 0.00005)
+    gt, pl, raw, done = ctx.genotype(np.zeros(2, dtype=np.uint8), np.array([0, 0xFFFFFFFF], dtype=np.uint32), np.full(2, 3, dtype=np.uint8), 3, 0.00005)
+    assert done.tolist() == [1, 0]
 
 
 @pytest.mark.parametrize("tag,ms,err", [("ms3", 3, None), ("ms1", 1, None), ("ms0", 0, None), ("ms3_e1e-3", 3, 0.001)])
