@@ -50,7 +50,8 @@ struct svjg_ctx {
     svjg_hitrec *d_recs = nullptr;   uint64_t rec_cap = 0;
     DevStatus *d_st = nullptr;
     unsigned long long *d_dbg = nullptr;
-    DevStatus h_st{};
+    DevStatus *h_stp = nullptr;          // host twin of d_st in pinned memory: the status copies are asynchronous in both directions
+    DevStatus &hs() { return *h_stp; }
     uint32_t look = LOOK_MIN;             // look-ahead bytes of the classify stripes; grows when lines get cut off (svjg_kernels.h)
     uint64_t total_deferred = 0;
     // genotype scratch
@@ -103,11 +104,13 @@ extern "C" int svjg_init(int device, svjg_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     for (auto &ev : c->ev) hipEventCreate(&ev);
-    if (hipMalloc(&c->d_dbg, 16 * 8) != hipSuccess || hipMalloc(&c->d_st, sizeof(DevStatus)) != hipSuccess || hipMalloc(&c->d_maxn, sizeof(unsigned int)) != hipSuccess) {
+    if (hipMalloc(&c->d_dbg, 16 * 8) != hipSuccess || hipMalloc(&c->d_st, sizeof(DevStatus)) != hipSuccess || hipMalloc(&c->d_maxn, sizeof(unsigned int)) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_stp, sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) {
         g_init_error = "hipMalloc failed";
         delete c;
         return SVJG_E_NOMEM;
     }
+    memset(c->h_stp, 0, sizeof(DevStatus));
     hipFuncSetAttribute((const void *)k_classify_main, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = c;
     return 0;
@@ -131,6 +134,7 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_cut); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
     hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows);
     if (c->h_rows) hipHostFree(c->h_rows);
+    if (c->h_stp) hipHostFree(c->h_stp);
     for (auto &b : c->h_stage) if (b) hipHostFree(b);
     for (auto &ev : c->stage_ev) if (ev) hipEventDestroy(ev);
     for (auto &st : c->stage_stream) if (st) hipStreamDestroy(st);
@@ -147,12 +151,12 @@ static int upload(svjg_ctx *c, T **dst, const T *src, uint64_t n, uint64_t extra
 }
 
 static int reset_status(svjg_ctx *c, bool all) {
-    DevStatus s = c->h_st;
+    DevStatus s = c->hs();
     if (all) { memset(&s, 0, sizeof s); c->total_deferred = 0; }
     s.n_deferred = 0; s.overflow = 0; s.n_cut = 0;
     if (all) s.err = ~0ull;
-    c->h_st = s;
-    HIPCHK(c, hipMemcpyAsync(c->d_st, &c->h_st, sizeof s, hipMemcpyHostToDevice, c->stream));
+    c->hs() = s;
+    HIPCHK(c, hipMemcpyAsync(c->d_st, &c->hs(), sizeof s, hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 
@@ -320,14 +324,14 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
     if (n == 0) return 0;
     const bool all_slow = (c->gflags & SVJG_GRAPH_ALL_SLOW) != 0;
     uint64_t def_want = all_slow ? n / 24 + 64 : (n / 4096 + 65536);
-    uint64_t rec_want = want_hits ? c->h_st.n_recs + n / 64 + 65536 : 0;
+    uint64_t rec_want = want_hits ? c->hs().n_recs + n / 64 + 65536 : 0;
     int rc;
     for (int attempt = 0; attempt < 3; ++attempt) {
         if ((rc = ensure(c, (void **)&c->d_deferred, &c->deferred_cap, def_want, sizeof(uint64_t), false))) return rc;
         if (want_hits && (rc = ensure(c, (void **)&c->d_recs, &c->rec_cap, rec_want, sizeof(svjg_hitrec), true))) return rc;
         // snapshot so that an overflowed attempt can be rolled back
         HIPCHK(c, hipMemcpyAsync(c->d_snap, c->d_counts, ((uint64_t)c->n_slots + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
-        DevStatus before = c->h_st;
+        DevStatus before = c->hs();
         if ((rc = reset_status(c, false))) return rc;
         ClassifyArgs a{};
         a.gaf = c->d_gaf; a.n_bytes = n; a.base_offset = base_offset; a.g = c->gv;
@@ -351,13 +355,13 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&c->hs(), c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        uint64_t n_def = c->h_st.n_deferred;
+        uint64_t n_def = c->hs().n_deferred;
         // lines cut off by the staged text of their stripe: a second launch of the same kernel, one stripe per such line
         // (the line then has the whole staged text to itself); what still does not fit goes to the exact path
-        const uint64_t n_cut = c->h_st.n_incomplete - before.n_incomplete;
-        if (n_cut && !all_slow && !c->h_st.overflow) {
+        const uint64_t n_cut = c->hs().n_incomplete - before.n_incomplete;
+        if (n_cut && !all_slow && !c->hs().overflow) {
             if ((rc = ensure(c, (void **)&c->d_cut, &c->cut_cap, n_cut + 64, sizeof(uint64_t), false))) return rc;
             hipLaunchKernelGGL(k_pick_cut, dim3((uint32_t)((n_def + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->d_deferred, n_def, c->d_cut, &c->d_st->n_cut);
             ClassifyArgs a2 = a;
@@ -365,9 +369,9 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
             hipLaunchKernelGGL(k_classify_main, dim3(a2.n_chunks < full ? a2.n_chunks : full), dim3(WG), lds, c->stream, a2);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-            HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&c->hs(), c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            n_def = c->h_st.n_deferred;
+            n_def = c->hs().n_deferred;
         }
         if (a.diag & 16u) {
             unsigned long long d[8];
@@ -375,7 +379,7 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
             fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A %llu  B1 %llu  B2 %llu  R1 %llu  R3 %llu  R4 %llu  R5 %llu  R6+end %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
         }
         c->ms_slow = 0;
-        if (n_def && !(c->h_st.overflow & 1u)) {
+        if (n_def && !(c->hs().overflow & 1u)) {
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
             const uint64_t max_blocks = (uint64_t)c->n_cu * 4;              // 32 KB of LDS each: four per CU
             if (n_def - n_cut <= 16 * max_blocks) {
@@ -387,28 +391,28 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
             }
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-            HIPCHK(c, hipMemcpyAsync(&c->h_st, c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(&c->hs(), c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipEventElapsedTime(&c->ms_slow, c->ev[2], c->ev[3]));
         }
         HIPCHK(c, hipEventElapsedTime(&c->ms_main, c->ev[0], c->ev[1]));
-        if (!c->h_st.overflow) {
+        if (!c->hs().overflow) {
             c->total_deferred += n_def - n_cut;                       // lines that took the exact path (cut lines went through the second launch)
             // many lines ran past the staged text (long lines): widen the look-ahead for the following batches
-            const uint64_t cut = c->h_st.n_incomplete - before.n_incomplete, lines = c->h_st.n_lines - before.n_lines;
+            const uint64_t cut = c->hs().n_incomplete - before.n_incomplete, lines = c->hs().n_lines - before.n_lines;
             // (a cut line costs a stripe of its own in the second launch: worth a wider look-ahead from one line in 256 on)
             if (c->look < LOOK_MAX && cut * 256 > lines) c->look *= 2;
             break;
         }
         // roll back and retry with worst-case buffers
         if (attempt == 2) { c->err = "output buffers overflowed repeatedly"; return SVJG_E_NOMEM; }
-        if (c->h_st.overflow & 1u) def_want = n / 24 + 64;
-        if (c->h_st.overflow & 2u) rec_want = before.n_recs + (c->h_st.n_recs - before.n_recs) * 2 + n / 24 + 64;
+        if (c->hs().overflow & 1u) def_want = n / 24 + 64;
+        if (c->hs().overflow & 2u) rec_want = before.n_recs + (c->hs().n_recs - before.n_recs) * 2 + n / 24 + 64;
         HIPCHK(c, hipMemcpyAsync(c->d_counts, c->d_snap, ((uint64_t)c->n_slots + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
         uint64_t keep_err = before.err;
-        c->h_st = before; c->h_st.err = keep_err;
+        c->hs() = before; c->hs().err = keep_err;
     }
-    if (c->h_st.err != ~0ull) return SVJG_E_INPUT;
+    if (c->hs().err != ~0ull) return SVJG_E_INPUT;
     return 0;
 }
 
@@ -426,14 +430,14 @@ extern "C" int svjg_classify_file(svjg_ctx *c, const char *path, uint64_t offset
 
 extern "C" int svjg_get_stats(svjg_ctx *c, svjg_stats *out) {
     if (!c || !out) return SVJG_E_ARG;
-    out->n_lines = c->h_st.n_lines; out->n_deferred = c->total_deferred; out->n_hitrecs = c->h_st.n_recs; out->non_ascii = c->h_st.non_ascii;
+    out->n_lines = c->hs().n_lines; out->n_deferred = c->total_deferred; out->n_hitrecs = c->hs().n_recs; out->non_ascii = c->hs().non_ascii;
     return 0;
 }
 
 extern "C" int svjg_input_error(svjg_ctx *c, int *cls, uint64_t *off) {
     if (!c || !cls || !off) return SVJG_E_ARG;
-    if (c->h_st.err == ~0ull) { *cls = SVJG_EXC_NONE; *off = 0; }
-    else { *cls = (int)(c->h_st.err & 7); *off = c->h_st.err >> 3; }
+    if (c->hs().err == ~0ull) { *cls = SVJG_EXC_NONE; *off = 0; }
+    else { *cls = (int)(c->hs().err & 7); *off = c->hs().err >> 3; }
     return 0;
 }
 
@@ -460,7 +464,7 @@ extern "C" int svjg_set_counts(svjg_ctx *c, const uint32_t *in, uint32_t n_slots
 extern "C" int svjg_get_hits(svjg_ctx *c, svjg_hitrec *out, uint64_t cap, uint64_t *n) {
     if (!c || !n) return SVJG_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    uint64_t have = c->h_st.n_recs < cap ? c->h_st.n_recs : cap;
+    uint64_t have = c->hs().n_recs < cap ? c->hs().n_recs : cap;
     if (have && !out) return SVJG_E_ARG;
     if (have) HIPCHK(c, hipMemcpyAsync(out, c->d_recs, have * sizeof(svjg_hitrec), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
