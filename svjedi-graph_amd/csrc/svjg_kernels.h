@@ -175,11 +175,13 @@ __device__ inline uint64_t name_words(const uint8_t *text, uint32_t a0, uint32_t
     const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
 #pragma unroll
     for (uint32_t i = NW; i < 8; ++i) d[i] = 0u;
+    // words in front of word L / 4 are name bytes only, that word keeps its first L % 4 bytes, the ones behind it are zero
+    const uint32_t fw = L >> 2, pm = ~(0xFFFFFFFFu << ((8u * (L & 3u)) & 31u));
 #pragma unroll
     for (uint32_t i = 0; i < NW; ++i) {
         const uint32_t nx = w[i + 1];
-        const uint32_t nb = L > 4 * i ? L - 4 * i : 0u;                 // bytes of the name in this word
-        d[i] = __builtin_amdgcn_alignbyte(nx, prev, sh) & (nb >= 4 ? 0xFFFFFFFFu : ((1u << ((8 * nb) & 31u)) - 1u));
+        const uint32_t x = __builtin_amdgcn_alignbyte(nx, prev, sh);
+        d[i] = i < fw ? x : (i == fw ? (x & pm) : 0u);
         prev = nx;
         h += (uint64_t)d[i] * C[i];
     }
