@@ -191,8 +191,11 @@ __device__ inline uint64_t name_words(const uint8_t *text, uint32_t a0, uint32_t
 // record of the node-name table (svjg_host_tables.h): r0 = name bytes 0..15, r1 = bytes 16..23 | meta | length in bp,
 // r2.xy = bytes 24..31 (only names longer than 24 bytes look at them)
 __device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[8], uint32_t L) {
-    return (r1.z & 31u) == L - 1u && r0.x == d[0] && r0.y == d[1] && r0.z == d[2] && r0.w == d[3] &&
-           r1.x == d[4] && r1.y == d[5] && (L <= 24u || (r2.x == d[6] && r2.y == d[7]));
+    // one OR of differences instead of a chain of compares (three-input bit operations: (a ^ b) | c is one instruction)
+    uint32_t diff = ((r1.z & 31u) ^ (L - 1u)) | (r0.x ^ d[0]) | (r0.y ^ d[1]) | (r0.z ^ d[2]) | (r0.w ^ d[3]) | (r1.x ^ d[4]) | (r1.y ^ d[5]);
+    const uint32_t tail = (r2.x ^ d[6]) | (r2.y ^ d[7]);
+    diff |= L > 24u ? tail : 0u;
+    return diff == 0u;
 }
 
 // Workgroup barrier for data handed over through LDS only.  __syncthreads() also drains the wave's global-memory queue
