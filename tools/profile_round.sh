@@ -3,8 +3,8 @@
 # kernel trace + stats, FETCH_SIZE / WRITE_SIZE and three SQ counter groups in separate --pmc passes).
 #   gpurun -- bash tools/profile_round.sh r02 ; then copy the summaries from gpurun_out/r02/ into profiles/r02/
 set -e
-cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${1:-profile}; mkdir -p $O
+export TMPDIR=/tmp
 cd $R
 python3 bench.py --workload c3 > $O/bench_c3.json 2> $O/bench_c3.err
 python3 bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2>> $O/bench_c3.err
