@@ -87,7 +87,9 @@ def main():
     t1 = time.time()
     ctx.upload(gaf)
     t_h2d = time.time() - t1
-    group = shard.RcclGroup(ctx, world, rank, shard.torch_exchange) if world > 1 else None
+    if world > 1:
+        import dist_boot
+    group = shard.RcclGroup(ctx, world, rank, dist_boot.torch_exchange) if world > 1 else None
 
     def barrier():
         ctx.sync()

@@ -33,6 +33,7 @@ extern "C" {
 /* The input made the reference raise (it would exit 1, svjedi-graph.py:117-118).  svjg_input_error()
  * tells which Python exception and at which byte offset of the GAF. */
 #define SVJG_E_INPUT       (-10)
+#define SVJG_E_OVERFLOW    (-12)  /* 2^32 or more informative alignments for one SV (the count fields are 32 bits wide) */
 
 /* exception class the reference would have died with (svjg_input_error) */
 #define SVJG_EXC_NONE            0
@@ -150,6 +151,11 @@ int svjg_get_hits(svjg_ctx *ctx, svjg_hitrec *out, uint64_t cap, uint64_t *n);
 int svjg_comm_unique_id(char *out128);                                      /* rank 0, then broadcast by the launcher */
 int svjg_comm_init(svjg_ctx *ctx, const char *id128, int n_ranks, int rank);
 int svjg_allreduce_counts(svjg_ctx *ctx);
+/* ---- multi-GPU, one process (what the drop-in filter-alignments.py does with the GPUs it sees): one context per device,
+ * communicators from ncclCommInitAll, the same all-reduce issued for every context; n == 1 is allowed (no collective).
+ * Both all-reduce forms fail with SVJG_E_OVERFLOW when a per-SV count cannot be represented (>= 2^32). */
+int svjg_comm_init_all(svjg_ctx *const *ctxs, int n);
+int svjg_allreduce_counts_all(svjg_ctx *const *ctxs, int n);
 
 /* ---- genotypes (predict-genotype.py:216-227 gate, :281-325 likelihood) -----------------------------
  * Per VCF row r: sv_type[r] in {0 DEL, 1 INS, 2 INV, 3 BND}; slot[r] = count slot or 0xFFFFFFFF when the

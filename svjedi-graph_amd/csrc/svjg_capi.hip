@@ -46,13 +46,11 @@ struct svjg_ctx {
     hipEvent_t stage_ev[STAGE_THREADS * 2] = {};
     // outputs
     uint64_t *d_deferred = nullptr;  uint64_t deferred_cap = 0;
-    uint64_t *d_cut = nullptr;       uint64_t cut_cap = 0;
     svjg_hitrec *d_recs = nullptr;   uint64_t rec_cap = 0;
     DevStatus *d_st = nullptr;
     unsigned long long *d_dbg = nullptr;
     DevStatus *h_stp = nullptr;          // host twin of d_st in pinned memory: the status copies are asynchronous in both directions
     DevStatus &hs() { return *h_stp; }
-    uint32_t look = LOOK_MIN;             // look-ahead bytes of the classify stripes; grows when lines get cut off (svjg_kernels.h)
     uint64_t total_deferred = 0;
     // genotype scratch
     dd *d_logfact = nullptr;  uint32_t logfact_n = 0;  dd *d_bsum = nullptr;
@@ -131,7 +129,7 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     free_graph(c);
-    hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_cut); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
+    hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
     hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows);
     if (c->h_rows) hipHostFree(c->h_rows);
     if (c->h_stp) hipHostFree(c->h_stp);
@@ -153,7 +151,7 @@ static int upload(svjg_ctx *c, T **dst, const T *src, uint64_t n, uint64_t extra
 static int reset_status(svjg_ctx *c, bool all) {
     DevStatus s = c->hs();
     if (all) { memset(&s, 0, sizeof s); c->total_deferred = 0; }
-    s.n_deferred = 0; s.overflow = 0; s.n_cut = 0;
+    s.n_deferred = 0; s.overflow = 0;
     if (all) s.err = ~0ull;
     c->hs() = s;
     HIPCHK(c, hipMemcpyAsync(c->d_st, &c->hs(), sizeof s, hipMemcpyHostToDevice, c->stream));
@@ -166,6 +164,7 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     HIPCHK(c, hipSetDevice(c->device));
     free_graph(c);
     int rc;
+    struct Undo { svjg_ctx *c; bool armed = true; ~Undo() { if (armed) { hipStreamSynchronize(c->stream); free_graph(c); } } } undo{c};   // a failure midway leaves nothing behind
     if ((rc = upload(c, &c->d_nodes, g->nodes, g->n_nodes + 1))) return rc;
     if ((rc = upload(c, &c->d_edges, g->edges, g->n_edges))) return rc;
     if ((rc = upload(c, &c->d_hits, g->hits, g->n_hits))) return rc;
@@ -190,9 +189,10 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     c->gflags = g->flags;
     if (kt.links_left_out) c->gflags |= SVJG_GRAPH_ALL_SLOW;   // a link the main kernel could not find would be a silent miss
     c->n_slots = g->n_slots;
-    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)g->n_slots + 1) * 8));
-    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)g->n_slots + 1) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)g->n_slots + 2) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)g->n_slots + 2) * 8));
     c->have_graph = true; c->have_counts = true;
+    undo.armed = false;
     return svjg_reset_counts(c);
 }
 
@@ -201,8 +201,8 @@ extern "C" int svjg_alloc_counts(svjg_ctx *c, uint32_t n_slots) {
     HIPCHK(c, hipSetDevice(c->device));
     free_graph(c);
     c->n_slots = n_slots;
-    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)n_slots + 1) * 8));
-    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)n_slots + 1) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)n_slots + 2) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)n_slots + 2) * 8));
     c->have_counts = true;
     return svjg_reset_counts(c);
 }
@@ -210,7 +210,7 @@ extern "C" int svjg_alloc_counts(svjg_ctx *c, uint32_t n_slots) {
 extern "C" int svjg_reset_counts(svjg_ctx *c) {
     if (!c || !c->have_counts) return SVJG_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, ((uint64_t)c->n_slots + 1) * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, ((uint64_t)c->n_slots + 2) * 8, c->stream));
     int rc = reset_status(c, true);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -330,16 +330,15 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         if ((rc = ensure(c, (void **)&c->d_deferred, &c->deferred_cap, def_want, sizeof(uint64_t), false))) return rc;
         if (want_hits && (rc = ensure(c, (void **)&c->d_recs, &c->rec_cap, rec_want, sizeof(svjg_hitrec), true))) return rc;
         // snapshot so that an overflowed attempt can be rolled back
-        HIPCHK(c, hipMemcpyAsync(c->d_snap, c->d_counts, ((uint64_t)c->n_slots + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_snap, c->d_counts, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
         DevStatus before = c->hs();
         if ((rc = reset_status(c, false))) return rc;
         ClassifyArgs a{};
         a.gaf = c->d_gaf; a.n_bytes = n; a.base_offset = base_offset; a.g = c->gv;
         a.all_slow = all_slow; a.want_hits = want_hits != 0;
-        { const char *lk = getenv("SVJG_LOOK"); if (lk) { uint32_t v = (uint32_t)atoi(lk) & ~15u; if (v >= 256 && v <= LOOK_MAX) c->look = v; } }   // measurement knob
-        a.chunk = TEXT - c->look; a.starts = nullptr;
-        a.n_chunks = (uint32_t)((n + a.chunk - 1) / a.chunk);
-        { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob for profiling only
+#ifdef SVJG_ABLATE
+        { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob (measurement builds only)
+#endif
         a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
         a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
         size_t lds = LDS_MAIN;
@@ -347,42 +346,39 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
             int occ = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_classify_main, (int)WG, lds) != hipSuccess || occ < 1) occ = 1;
             c->occ_main = occ;
+#ifdef SVJG_ABLATE
+            { const char *oc = getenv("SVJG_OCC"); fprintf(stderr, "[svjg diag] occupancy API: %d workgroups of %u threads per CU (LDS %zu)\n", occ, WG, lds); if (oc && atoi(oc) > 0) c->occ_main = atoi(oc); }
+#endif
         }
-        const uint32_t full = (uint32_t)c->n_cu * (uint32_t)c->occ_main;
-        uint32_t grid = a.n_chunks < full ? a.n_chunks : full;
+        // one worker (wave) per resident slot; every worker owns the lines starting in its region of the text.  Small inputs:
+        // regions of at least one stripe, fewer workers.
+        const uint64_t full = (uint64_t)c->n_cu * (uint64_t)c->occ_main;
+        uint64_t region = ((n + full - 1) / full + 15) & ~15ull;
+        if (region < TEXT) region = TEXT;
+        a.region = region;
+        const uint32_t grid = (uint32_t)((n + region - 1) / region);
+#ifdef SVJG_TIMING
         if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
+#endif
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         HIPCHK(c, hipMemcpyAsync(&c->hs(), c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        uint64_t n_def = c->hs().n_deferred;
-        // lines cut off by the staged text of their stripe: a second launch of the same kernel, one stripe per such line
-        // (the line then has the whole staged text to itself); what still does not fit goes to the exact path
-        const uint64_t n_cut = c->hs().n_incomplete - before.n_incomplete;
-        if (n_cut && !all_slow && !c->hs().overflow) {
-            if ((rc = ensure(c, (void **)&c->d_cut, &c->cut_cap, n_cut + 64, sizeof(uint64_t), false))) return rc;
-            hipLaunchKernelGGL(k_pick_cut, dim3((uint32_t)((n_def + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, c->d_deferred, n_def, c->d_cut, &c->d_st->n_cut);
-            ClassifyArgs a2 = a;
-            a2.starts = c->d_cut; a2.n_chunks = (uint32_t)n_cut;
-            hipLaunchKernelGGL(k_classify_main, dim3(a2.n_chunks < full ? a2.n_chunks : full), dim3(WG), lds, c->stream, a2);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-            HIPCHK(c, hipMemcpyAsync(&c->hs(), c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            n_def = c->hs().n_deferred;
-        }
+        const uint64_t n_def = c->hs().n_deferred;
+#ifdef SVJG_TIMING
         if (a.diag & 16u) {
             unsigned long long d[8];
             HIPCHK(c, hipMemcpy(d, c->d_dbg, sizeof d, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A %llu  B1 %llu  B2 %llu  R1 %llu  R3 %llu  R4 %llu  R5 %llu  R6+end %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+            fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A %llu  B1 %llu  B2 %llu  R1 %llu  NP-load %llu  NP-scan %llu  NP-link %llu  R6+end %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
         }
+#endif
         c->ms_slow = 0;
         if (n_def && !(c->hs().overflow & 1u)) {
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
             const uint64_t max_blocks = (uint64_t)c->n_cu * 4;              // 32 KB of LDS each: four per CU
-            if (n_def - n_cut <= 16 * max_blocks) {
+            if (n_def <= 16 * max_blocks) {
                 // few lines: one wave per line (latency of a line O(k) instead of O(k^2) name resolutions)
                 hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)(n_def < max_blocks ? n_def : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def);
             } else {
@@ -397,18 +393,14 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         }
         HIPCHK(c, hipEventElapsedTime(&c->ms_main, c->ev[0], c->ev[1]));
         if (!c->hs().overflow) {
-            c->total_deferred += n_def - n_cut;                       // lines that took the exact path (cut lines went through the second launch)
-            // many lines ran past the staged text (long lines): widen the look-ahead for the following batches
-            const uint64_t cut = c->hs().n_incomplete - before.n_incomplete, lines = c->hs().n_lines - before.n_lines;
-            // (a cut line costs a stripe of its own in the second launch: worth a wider look-ahead from one line in 256 on)
-            if (c->look < LOOK_MAX && cut * 256 > lines) c->look *= 2;
+            c->total_deferred += n_def;                               // lines that took the exact path
             break;
         }
         // roll back and retry with worst-case buffers
         if (attempt == 2) { c->err = "output buffers overflowed repeatedly"; return SVJG_E_NOMEM; }
         if (c->hs().overflow & 1u) def_want = n / 24 + 64;
         if (c->hs().overflow & 2u) rec_want = before.n_recs + (c->hs().n_recs - before.n_recs) * 2 + n / 24 + 64;
-        HIPCHK(c, hipMemcpyAsync(c->d_counts, c->d_snap, ((uint64_t)c->n_slots + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_counts, c->d_snap, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
         uint64_t keep_err = before.err;
         c->hs() = before; c->hs().err = keep_err;
     }
@@ -493,14 +485,79 @@ extern "C" int svjg_comm_init(svjg_ctx *c, const char *id128, int n_ranks, int r
     return 0;
 }
 
-// the path's only collective: sum of the per-SV count vector (packed ref | alt << 32 as one u64 each)
+// the two guard elements behind the count vector <- largest ref / alt field (k_counts_guard)
+static int launch_guard(svjg_ctx *c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->d_counts + c->n_slots, 0, 16, c->stream));
+    if (c->n_slots) {
+        uint32_t grid = (c->n_slots + TPB - 1) / TPB;
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(k_counts_guard, dim3(grid), dim3(TPB), 0, c->stream, c->d_counts, c->n_slots);
+        HIPCHK(c, hipGetLastError());
+    }
+    return 0;
+}
+static int check_guard(svjg_ctx *c) {
+    unsigned long long g[2] = {0, 0};
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(g, c->d_counts + c->n_slots, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (g[0] >= (1ull << 32) || g[1] >= (1ull << 32)) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
+    return 0;
+}
+
+// the path's only collective: sum of the per-SV count vector (packed ref | alt << 32 as one u64 each, plus the two guard elements)
 extern "C" int svjg_allreduce_counts(svjg_ctx *c) {
     if (!c || !c->have_counts) return SVJG_E_ARG;
     if (!c->comm) { c->err = "svjg_comm_init has not been called"; return SVJG_E_ARG; }
-    HIPCHK(c, hipSetDevice(c->device));
-    ncclResult_t r = ncclAllReduce(c->d_counts, c->d_counts, c->n_slots, ncclUint64, ncclSum, c->comm, c->stream);
+    int rc = launch_guard(c);
+    if (rc) return rc;
+    ncclResult_t r = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
     if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return SVJG_E_RCCL; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_guard(c);
+}
+
+// One process, several GPUs (the drop-in filter-alignments.py): one communicator per context from ncclCommInitAll, then the same
+// all-reduce issued for every context between ncclGroupStart / ncclGroupEnd.  n == 1: only the overflow guard runs.
+extern "C" int svjg_comm_init_all(svjg_ctx *const *ctxs, int n) {
+    if (!ctxs || n < 1 || n > 64) return SVJG_E_ARG;
+    for (int i = 0; i < n; ++i) if (!ctxs[i]) return SVJG_E_ARG;
+    if (n == 1) return 0;
+    int devs[64];
+    ncclComm_t comms[64];
+    for (int i = 0; i < n; ++i) {
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) { ctxs[0]->err = "svjg_comm_init_all: one context per device"; return SVJG_E_ARG; }
+    }
+    ncclResult_t r = ncclCommInitAll(comms, n, devs);
+    if (r != ncclSuccess) { ctxs[0]->err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return SVJG_E_RCCL; }
+    for (int i = 0; i < n; ++i) {
+        if (ctxs[i]->comm) ncclCommDestroy(ctxs[i]->comm);
+        ctxs[i]->comm = comms[i];
+    }
+    return 0;
+}
+
+extern "C" int svjg_allreduce_counts_all(svjg_ctx *const *ctxs, int n) {
+    if (!ctxs || n < 1 || n > 64) return SVJG_E_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !ctxs[i]->have_counts || ctxs[i]->n_slots != ctxs[0]->n_slots) return SVJG_E_ARG;
+        if (n > 1 && !ctxs[i]->comm) { ctxs[0]->err = "svjg_comm_init_all has not been called"; return SVJG_E_ARG; }
+    }
+    int rc;
+    for (int i = 0; i < n; ++i) if ((rc = launch_guard(ctxs[i]))) { if (i) ctxs[0]->err = ctxs[i]->err; return rc; }
+    if (n > 1) {
+        ncclResult_t r = ncclGroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; ++i) {
+            svjg_ctx *c = ctxs[i];
+            if (hipSetDevice(c->device) != hipSuccess) { ctxs[0]->err = "hipSetDevice"; ncclGroupEnd(); return SVJG_E_HIP; }
+            r = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
+        }
+        const ncclResult_t r2 = ncclGroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) { ctxs[0]->err = std::string("ncclAllReduce (group): ") + ncclGetErrorString(r); return SVJG_E_RCCL; }
+    }
+    for (int i = 0; i < n; ++i) if ((rc = check_guard(ctxs[i]))) { if (i) ctxs[0]->err = ctxs[i]->err; return rc; }
     return 0;
 }
 

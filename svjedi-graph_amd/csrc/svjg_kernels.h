@@ -1,10 +1,10 @@
 // HIP kernels of libsvjg_hip.so (gfx950 / MI355X, wave64).  No MFMA anywhere: this is byte / integer
 // work bounded by HBM reads.
 //
-//   k_classify_main  persistent workgroups over 16 KB stripes of GAF text (see the comment in front of the kernel):
+//   k_classify_main  persistent single-wave workers over 8 KB stripes of GAF text (see the comment in front of the kernel):
 //                      coalesced HBM -> register -> LDS staging, SWAR byte classes, rank-indexed lists of line
 //                      starts / tabs / orientation marks, then loop-free per-line, per-node and per-link phases with
-//                      node-name and link hash tables, packed 64-bit (ref | alt << 32) atomics into the per-SV count vector
+//                      a perfect-hash node-record table, packed 64-bit (ref | alt << 32) atomics into the per-SV count vector
 //   k_classify_slow  one lane per deferred line, exact string path (svjg::slow_line) on an LDS copy of the line
 //   k_logfact_*      log10(i!) table in double-double for the binomial term
 //   k_genotype       one VCF row per lane, fp64 / double-double likelihoods (predict-genotype.py:281-325)
@@ -14,58 +14,34 @@
 
 namespace svjg {
 
-#ifndef SVJG_WG
-#define SVJG_WG 256
-#endif
-constexpr uint32_t WG = SVJG_WG;                 // classify kernel: 4 waves per workgroup, four workgroups per CU (123 VGPRs -> 16 waves / CU; 31 KB of LDS each)
-constexpr uint32_t NWAVE = WG / 64;
+constexpr uint32_t WG = 64;                      // classify kernel: ONE wave per workgroup = one autonomous worker (no workgroup barriers anywhere)
 constexpr uint32_t TPB = 256;                    // block size of the small per-row / per-line kernels
-constexpr uint32_t PIECES = 4;                   // 16-byte pieces of text per lane and stripe
-constexpr uint32_t SPAN = PIECES * 16;           // bytes of byte classification per lane: one 64-bit mask per byte class
-constexpr uint32_t TEXT = SPAN * WG;             // 16 KB staged in LDS
-// A stripe = the bytes of text whose lines one workgroup iteration owns = TEXT minus a look-ahead that lets lines
-// starting near its end be complete.  The look-ahead is a launch parameter (ClassifyArgs::chunk = TEXT - look-ahead): the
-// host starts at LOOK_MIN and doubles it, up to LOOK_MAX, when a batch had lines cut off by the staged text (they go
-// to the exact path, which is correct but slow), so short-line files do not pay for long-line ones.
-#ifndef SVJG_LOOK_MIN
-#define SVJG_LOOK_MIN 512
-#endif
-constexpr uint32_t LOOK_MIN = SVJG_LOOK_MIN, LOOK_MAX = TEXT / 2;
-// Phase B turns the staged text into rank-indexed lists (all positions are offsets into the staged text):
+constexpr uint32_t PIECES = 4;                   // 16-byte pieces of text per lane and half
+constexpr uint32_t SPAN = PIECES * 16;           // bytes of byte classification per lane and half: one 64-bit mask per byte class
+constexpr uint32_t HALF = SPAN * WG;             // 4 KB: what the 64 lanes classify at once
+constexpr uint32_t NHALF = 2;
+constexpr uint32_t TEXT = NHALF * HALF;          // 8 KB staged in LDS per stripe
+// A worker owns the lines that START in its region of the text and walks them in stripes: a stripe stages TEXT bytes from the
+// 16-byte block that holds the first line not yet worked off, handles every line that ends inside the staged text, and the
+// next stripe begins at the first line that did not (so no byte is classified twice except the tail of one line per stripe,
+// and a line of up to ~8 KB never needs a second launch).  Phase B turns the staged text into rank-indexed lists (positions
+// are offsets into the staged text):
 constexpr uint32_t MAXL = TEXT / 64;                 // line starts per stripe (a stripe with more goes to the exact path as a whole)
 constexpr uint32_t CAP_T = TEXT / 8;                // tab positions per stripe
 constexpr uint32_t CAP_O = TEXT / 16;               // orientation marks ('<' '>') per stripe
 constexpr uint32_t KMAX = 64;                    // path nodes per alignment handled by the main kernel: one wave pass (longer paths: exact path)
-#ifndef SVJG_LRW
-#define SVJG_LRW 32
-#endif
-constexpr uint32_t LRW = SVJG_LRW;               // lines per wave and round
-#ifndef SVJG_NWAVE_R
-#define SVJG_NWAVE_R (SVJG_WG / 64)
-#endif
-constexpr uint32_t NWAVE_R = SVJG_NWAVE_R;       // waves of a workgroup that share out the stripe's lines (all of them take part in phases A and B)
-static_assert(LRW <= 64 && KMAX <= 64, "round geometry: a line's nodes fit one wave pass");
+constexpr uint32_t LRW = 64;                     // lines per round: one line per lane in the line phase
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
-// LDS carve-up of k_classify_main (bytes): text, the non-digit bitmap and the lists are shared by the workgroup,
-// the round arrays are private to one wave
-constexpr uint32_t L_TEXT = 0;
-constexpr uint32_t L_NDBM = L_TEXT + TEXT + 16;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab
+// LDS of one worker (bytes)
+constexpr uint32_t L_TEXT = 0;                                             // staged text + slack for the word reads behind a name / column
+constexpr uint32_t L_NDBM = L_TEXT + TEXT + 64;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab
 constexpr uint32_t L_TP = L_NDBM + TEXT / 8 + 16;                          // u16[CAP_T + 16]  position of tab #t of the stripe
-constexpr uint32_t L_OP = L_TP + (CAP_T + 16) * 2;                         // u16[CAP_O + 8]   position of orientation mark #o
-constexpr uint32_t L_OL = L_OP + (CAP_O + 8) * 2;                          // u16[CAP_O + 8]   line (ordinal in the stripe) that holds mark #o
-constexpr uint32_t L_LS = L_OL + (CAP_O + 8) * 2;                          // u16[MAXL + 8]    start of line #l ; [n] = 0xFFFF
-constexpr uint32_t L_LT = L_LS + (MAXL + 8) * 2;                           // u16[MAXL + 8]    tabs in front of line #l
-constexpr uint32_t L_LO = L_LT + (MAXL + 8) * 2;                           // u16[MAXL + 8]    orientation marks in front of line #l
-constexpr uint32_t L_MISC = L_LO + (MAXL + 8) * 2;                         // u32[32]: [1] stripe holds a byte >= 0x80, [2] line starts in front of the owned range, [8 + w] / [16 + w] scan totals of wave w
-constexpr uint32_t L_WAVE = L_MISC + 128;
-constexpr uint32_t W_NEEDL = 0;                                            // u32[LRW]  path length a link's left side must reach (Ts + d_over)
-constexpr uint32_t W_NEEDR = W_NEEDL + LRW * 4;                            // u32[LRW]  ... and its right side (d_over + Tlen - Te - 1)
-constexpr uint32_t W_META = W_NEEDR + LRW * 4;                             // u32[LRW]  first mark of the line (relative to the round) | k << 16 | status << 24
-constexpr uint32_t W_PEND = W_META + LRW * 4;                              // u16[LRW]  tab after the path column
-constexpr uint32_t WAVE_BYTES = (W_PEND + LRW * 2 + 15) / 16 * 16;
-constexpr uint32_t LDS_MAIN = L_WAVE + NWAVE * WAVE_BYTES;
-static_assert(L_NDBM % 16 == 0 && L_TP % 16 == 0 && L_OP % 16 == 0 && L_LS % 16 == 0 && L_MISC % 16 == 0, "LDS alignment");
+constexpr uint32_t L_OPL = L_TP + (CAP_T + 16) * 2;                        // u32[CAP_O + 8]   orientation mark #o: position | line (ordinal in the stripe) << 16
+constexpr uint32_t L_LINE = L_OPL + (CAP_O + 8) * 4;                       // u16[4][MAXL + 8] line #l: start, tabs in front of it, marks in front of it, -- ; [n].start = 0xFFFF
+constexpr uint32_t L_RL = L_LINE + (MAXL + 8) * 8;                         // uint4[LRW] per line of the round: need_l, need_r, first mark (rel.) | k << 16 | status << 24, tab behind the path
+constexpr uint32_t LDS_MAIN = L_RL + LRW * 16;
+static_assert(L_NDBM % 16 == 0 && L_TP % 16 == 0 && L_OPL % 16 == 0 && L_LINE % 16 == 0 && L_RL % 16 == 0, "LDS alignment");
 
 // status words (device)
 struct DevStatus {
@@ -73,8 +49,6 @@ struct DevStatus {
     unsigned long long n_deferred;       // entries appended to the deferred list
     unsigned long long n_recs;           // hit records appended
     unsigned long long err;              // min over (file offset << 3 | exception class); ~0 = none
-    unsigned long long n_incomplete;     // lines deferred because they run past the staged text
-    unsigned long long n_cut;            // k_pick_cut: entries of the second launch's list
     unsigned int non_ascii;
     unsigned int overflow;               // bit 0: deferred list, bit 1: hit-record buffer
 };
@@ -86,16 +60,13 @@ struct ClassifyArgs {
     GraphView g;                         // global-memory views
     uint32_t all_slow;
     uint32_t want_hits;
-    uint32_t n_chunks;
-    uint32_t chunk;                      // stripe stride in bytes (multiple of 16, TEXT - look-ahead)
-    const uint64_t *starts;              // second launch only: n_chunks line starts; every stripe begins at one of them and owns that ONE line
-                                         // (lines the first launch found cut off by its staged text: here they have the whole TEXT to themselves)
-    uint32_t diag;                       // measurement only (SVJG_DIAG): 1 stop after B, 2 stop after R2, 4 no node lookup, 8 no atomics
+    uint64_t region;                     // bytes of text per worker (multiple of 16): worker w owns the lines that start in [w * region, (w + 1) * region)
+    uint32_t diag;                       // measurement only (SVJG_DIAG): 1 stop after B, 2 stop after R1, 8 no atomics
     unsigned long long *counts;          // [n_slots] ref | alt << 32
     uint64_t *deferred;  uint64_t deferred_cap;
     svjg_hitrec *recs;   uint64_t rec_cap;
     DevStatus *st;
-    unsigned long long *dbg;             // measurement only (SVJG_DIAG & 16): per-phase cycle sums of lane 0 of every workgroup
+    unsigned long long *dbg;             // measurement only (SVJG_DIAG & 16): per-phase cycle sums of lane 0 of every worker
 };
 
 __device__ inline uint32_t zero_bytes(uint32_t t) {                    // 0x80 in every byte of t that is zero (exact)
@@ -147,21 +118,7 @@ __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
     return x - v;
 }
 
-// block-wide exclusive scan; `slot` = WG/64 words of LDS; two barriers inside
-__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t *slot, uint32_t &total) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t wtot, ex = wave_excl_scan(v, wtot);
-    __syncthreads();
-    if (lane == 63) slot[wave] = wtot;
-    __syncthreads();
-    uint32_t base = 0; total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < WG / 64; ++w) { uint32_t x = slot[w]; if (w < wave) base += x; total += x; }
-    return base + ex;
-}
-
 enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round
-constexpr unsigned long long DEFER_CUT = 1ull << 63;                    // deferred-list entry: the line was cut off by the staged text
 
 // Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the 64-bit pre-hash of the node-name table
 // (svjg_line.h: name_prehash).
@@ -198,10 +155,6 @@ __device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2
     return diff == 0u;
 }
 
-// Workgroup barrier for data handed over through LDS only.  __syncthreads() also drains the wave's global-memory queue
-// (s_waitcnt vmcnt(0)): that would stall on the next stripe's prefetch and on the count atomics still in flight.
-__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, the fences only pin the compiler
 __device__ inline void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -209,31 +162,33 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The classify kernel.  One workgroup walks stripes of the GAF text; the next stripe's HBM loads are issued into
-// registers before the current one is processed, so the only HBM read of the text overlaps the parse.  Per stripe:
-//   A   registers -> LDS (16 B per lane, coalesced on the HBM side)                                  [workgroup barrier]
-//   B1  one 64-byte SPAN per lane, branch-free SWAR classification of every byte: 64-bit masks of line terminators,
-//       tabs and orientation marks ('<' '>') in registers, the "neither digit nor tab" bitmap -> LDS; workgroup prefix
-//       sum of the three counts                                                                       [workgroup barrier]
+// The classify kernel.  ONE WAVE = one autonomous worker (64-lane workgroups, no workgroup barrier anywhere): it owns the lines
+// that start in its region of the text and walks them in stripes of TEXT = 8 KB staged in LDS.  A stripe begins at the 16-byte
+// block that holds the first line not yet worked off; lines that end inside the staged text are handled, the first one that
+// does not is where the next stripe begins (a line longer than a stripe goes to the exact path).  The next stripe's HBM loads
+// are issued into registers as soon as its start is known (right after the byte classes), so the only HBM read of the text
+// overlaps the line and node phases.  Waves of a CU drift apart, so the dense byte classification of one fills the issue
+// slots another leaves while it waits for LDS / table round trips.  Per stripe:
+//   A   registers -> LDS (16 B per lane and piece, coalesced on the HBM side); on the registers: "any byte >= 0x80" and the
+//       "id:f:" filter (four sliding 4-byte SADs per piece against "d:f:")
+//   B1  two 64-byte SPANs per lane, branch-free SWAR classification of every byte: 64-bit masks of line terminators,
+//       tabs and orientation marks ('<' '>') in registers, the "neither digit nor tab" bitmap -> LDS; wave prefix sums
 //   B2  every terminator / tab / mark knows its ordinal in the stripe: rank-indexed lists -> LDS
-//         LS[l] LT[l] LO[l]  start of line l, tabs and marks in front of it      TP[t]  position of tab t
-//         OP[o] OL[o]        position of mark o, line that holds it                                  [workgroup barrier]
-//   then every WAVE on its own, for an equal share of the stripe's lines, in rounds of up to LRW lines
+//         LINE[l] = start of line l, tabs and marks in front of it      TP[t]  position of tab t
+//         OPL[o]  = position of mark o | line that holds it << 16
+//   then in rounds of up to 64 lines
 //   (no loops over bytes or bits from here on: a line's j-th tab is TP[LT[l] + j], its j-th node starts at OP[LO[l] + j]):
 //   R1 one LINE per lane: twelve column boundaries, column lengths, digits-only test on the bitmap, the four decimal
 //      values that matter (Tlen, Ts, Te, Alen), path geometry
 //   NP node passes over up to 64 consecutive marks covering whole lines, one path NODE per lane, everything in registers:
-//      name -> both candidate slots of the node-name hash table, and in the SAME round trip both candidate slots of
-//      the link to the next node (link slots are hashed from the two name pre-hashes); then id / length, running path
-//      length by a segmented wave scan, first occurrence of every name (the reference's list.index / str.split
-//      quirks) by wave shuffles, overlap test, link key check, one 64-bit atomic (ref | alt << 32) per hit,
-//      optional hit records
+//      name -> the bucket's displacement -> the ONE record the name can be in (perfect hash); then id / length, running path
+//      length by a wave scan, first occurrence of every name (the reference's list.index / str.split
+//      quirks) by wave shuffles, overlap test, link among the record's inline links (link table on a miss), one 64-bit
+//      atomic (ref | alt << 32) per hit, optional hit records
 //   R6 deferred-line offsets, one aggregated atomic per wave
-//                                                                                                     [workgroup barrier]
 
-// 0x80 in every byte of w that is an ASCII digit
-template <bool ASCII> __device__ inline uint32_t digit_flags(uint32_t w) {
-    if (ASCII) return (w + 0x50505050u) & ~(w + 0x46464646u) & 0x80808080u;            // bytes < 0x80: no carries between byte lanes
+// 0x80 in every byte of w that is an ASCII digit (text that may hold bytes >= 0x80)
+__device__ inline uint32_t digit_flags_any(uint32_t w) {
     const uint32_t t = w ^ 0x30303030u;                                                 // digit <=> high nibble 0 and low nibble < 10
     return zero_bytes(t & 0xF0F0F0F0u) & ((~((t & 0x0F0F0F0Fu) + 0x06060606u) & 0x10101010u) << 3);
 }
@@ -244,27 +199,56 @@ __device__ inline uint32_t gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint3
     return (lo | (hi << 8)) >> 7;
 }
 
-// Phase B1 of k_classify_main for one lane: classes of the SPAN bytes at text + tid * SPAN.
+// (a ^ b) + c in one instruction (v_xad_u32; VOP3 takes no literals on gfx950: b travels in an SGPR, c in a VGPR)
+__device__ inline uint32_t xad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
+// Phase B1 for one lane: classes of the SPAN bytes at text + slot * SPAN (slot = half * 64 + lane).
 // terminator = '\n', or a '\r' not followed by '\n' (Python universal newlines).
+// ASCII text (every byte < 0x80): (byte ^ c) + 0x7F has bit 7 set exactly where the byte differs from c, with no carries
+// between the byte lanes; (byte ^ '0') + 0x76 has it set exactly where the byte is no digit.
 template <bool ASCII>
-__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t tid, uint64_t c0, uint32_t V,
+__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t slot, uint64_t c0, uint32_t V,
                                      unsigned long long &NL, unsigned long long &TAB, unsigned long long &ORI) {
-    const uint32_t sp = tid * SPAN;
+    const uint32_t sp = slot * SPAN;
     // rotated piece order: the 16-byte LDS reads of a wave hit different banks.  The 16-bit masks are collected in loop
     // order and the four of a class rotated into place at the end (one 64-bit rotate instead of four shifts).
-    const uint32_t rot = (tid >> 2) & 3u;
+    const uint32_t rot = (slot >> 2) & 3u;
     uint32_t nlm[PIECES], tabm[PIECES], orim[PIECES], ndm[PIECES];
 #pragma unroll
     for (uint32_t c = 0; c < PIECES; ++c) {
         const uint32_t pc = (c + rot) & 3u;
         const uint32_t pb = sp + pc * 16;
         const uint4 v = *(const uint4 *)(text + pb);
-        uint32_t nl = eq_mask16_t<ASCII>(v, 0x0A0A0A0Au);
-        const uint32_t tab = eq_mask16_t<ASCII>(v, 0x09090909u);
-        const uint32_t ori = eq_mask16_t<ASCII>(make_uint4(v.x | 0x02020202u, v.y | 0x02020202u, v.z | 0x02020202u, v.w | 0x02020202u), 0x3E3E3E3Eu);
-        const uint32_t dig = gather16(digit_flags<ASCII>(v.x), digit_flags<ASCII>(v.y), digit_flags<ASCII>(v.z), digit_flags<ASCII>(v.w));
+        uint32_t nl, tab, ori, nd;
+        bool has_cr;
+        if (ASCII) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t fn[4], ft[4], fo[4], fd[4], crall = 0xFFFFFFFFu;
+            const uint32_t k7f = 0x7F7F7F7Fu, k76 = 0x76767676u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t tn = xad(w[k], 0x0A0A0A0Au, k7f), tt = xad(w[k], 0x09090909u, k7f);
+                const uint32_t to = xad(w[k] | 0x02020202u, 0x3E3E3E3Eu, k7f), td = xad(w[k], 0x30303030u, k76);
+                crall &= xad(w[k], 0x0D0D0D0Du, k7f);
+                fn[k] = ~tn & 0x80808080u; ft[k] = ~tt & 0x80808080u; fo[k] = ~to & 0x80808080u;
+                fd[k] = td & tt & 0x80808080u;                             // neither a digit nor a tab
+            }
+            nl = gather16(fn[0], fn[1], fn[2], fn[3]); tab = gather16(ft[0], ft[1], ft[2], ft[3]);
+            ori = gather16(fo[0], fo[1], fo[2], fo[3]); nd = gather16(fd[0], fd[1], fd[2], fd[3]);
+            has_cr = (~crall & 0x80808080u) != 0;
+        } else {
+            nl = eq_mask16(v, 0x0A0A0A0Au); tab = eq_mask16(v, 0x09090909u);
+            ori = eq_mask16(make_uint4(v.x | 0x02020202u, v.y | 0x02020202u, v.z | 0x02020202u, v.w | 0x02020202u), 0x3E3E3E3Eu);
+            const uint32_t dig = gather16(digit_flags_any(v.x), digit_flags_any(v.y), digit_flags_any(v.z), digit_flags_any(v.w));
+            nd = ~(dig | tab) & 0xFFFFu;
+            has_cr = (zero_bytes(v.x ^ 0x0D0D0D0Du) | zero_bytes(v.y ^ 0x0D0D0D0Du) | zero_bytes(v.z ^ 0x0D0D0D0Du) | zero_bytes(v.w ^ 0x0D0D0D0Du)) != 0;
+        }
         // carriage returns: cheap any-test first (no text file has them in practice)
-        if (any_byte_t<ASCII>(v, 0x0D0D0D0Du)) {
+        if (has_cr) {
             uint32_t cr = eq_mask16(v, 0x0D0D0D0Du);
             while (cr) {
                 uint32_t b = __builtin_ctz(cr); cr &= cr - 1;
@@ -273,7 +257,7 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
                 if (nx != '\n') nl |= 1u << b;
             }
         }
-        nlm[c] = nl; tabm[c] = tab; orim[c] = ori; ndm[c] = ~(dig | tab) & 0xFFFFu;
+        nlm[c] = nl; tabm[c] = tab; orim[c] = ori; ndm[c] = nd;
     }
     auto place = [&](const uint32_t (&m)[PIECES]) -> unsigned long long {      // piece c of the loop sits at 16-bit position (c + rot) & 3
         const unsigned long long x = (unsigned long long)(m[0] | (m[1] << 16)) | ((unsigned long long)(m[2] | (m[3] << 16)) << 32);
@@ -282,7 +266,7 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
     unsigned long long nl64 = place(nlm);
     const unsigned long long tab64 = place(tabm), ori64 = place(orim), nd64 = place(ndm);
     if (sp + SPAN > V) nl64 &= sp >= V ? 0ull : ((1ull << (V - sp)) - 1ull);   // ignore anything at or beyond the valid length
-    *(uint2 *)(ndbm + tid * 2) = make_uint2((uint32_t)nd64, (uint32_t)(nd64 >> 32));
+    *(uint2 *)(ndbm + slot * 2) = make_uint2((uint32_t)nd64, (uint32_t)(nd64 >> 32));
     NL = nl64; TAB = tab64; ORI = ori64;
 }
 
@@ -297,7 +281,7 @@ __device__ inline uint32_t field_val(const uint8_t *text, uint32_t a, uint32_t n
     // the first n8 bytes move to the top of the 64-bit (hi:lo): what follows the column drops out, leading bytes are zero digits
     const unsigned long long x = (((unsigned long long)hi0 << 32) | lo0) << ((8 * (8 - n8)) & 63u);
     const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    // digit pairs by shift-and-add (x * 10 = (x << 3) + (x << 1)), the rest with 24-bit multiplies (full rate; v_mul_lo_u32 is not)
+    // digit pairs by shift-and-add (x * 10 = (x << 3) + (x << 1)), the rest with 24-bit multiplies
     const uint32_t pl = (((lo << 3) + (lo << 1)) + (lo >> 8)) & 0x00FF00FFu, ph = (((hi << 3) + (hi << 1)) + (hi >> 8)) & 0x00FF00FFu;
     uint32_t r = __umul24(__umul24(pl & 0xFFu, 100u) + (pl >> 16), 10000u) + __umul24(ph & 0xFFu, 100u) + (ph >> 16);
     if (n == 9) r = r * 10u + ((uint32_t)text[a + 8] & 0xFu);
@@ -315,20 +299,34 @@ __device__ inline bool bits_clear(const uint32_t *bm, uint32_t a, uint32_t n) {
     return (x & m) == 0;
 }
 
-#ifndef SVJG_MINW
-#define SVJG_MINW 4
-#endif
+// "id:f:" anywhere in a line changes what the reference does with it (filter-alignments.py:193-196: float() of the tag value may
+// raise, Alen == 0 no longer does): such lines take the exact path.  The filter looks for the two bytes "d:" at every byte
+// offset of the staged text (no tag minigraph writes holds them; a hit only costs the stripe's lines the exact path):
+// (byte ^ 'd') | (next byte ^ ':') is a zero byte exactly at a match.  acc collects, in bit 7 of every byte lane, "some word had
+// a zero byte here" (v_qsad_pk_u16_u8 would test four offsets of a 4-byte pattern at once but runs at a quarter of the rate).
+template <bool ASCII>
+__device__ inline uint32_t idf_word(uint32_t w, uint32_t nx, uint32_t acc) {
+    const uint32_t c = (w ^ 0x64646464u) | (__builtin_amdgcn_alignbyte(nx, w, 1) ^ 0x3A3A3A3Au);
+    if (ASCII) return acc | ~(c + 0x7F7F7F7Fu);                          // bytes < 0x80: no carries between the byte lanes
+    return acc | zero_bytes(c);
+}
+template <bool ASCII>
+__device__ inline uint32_t idf_piece(const uint4 v, uint32_t nx, uint32_t acc) {
+    acc = idf_word<ASCII>(v.x, v.y, acc); acc = idf_word<ASCII>(v.y, v.z, acc);
+    acc = idf_word<ASCII>(v.z, v.w, acc); return idf_word<ASCII>(v.w, nx, acc);
+}
+
 // Static wave priorities (s_setprio): the byte classification of phases A / B1 is dense VALU work, the line and node phases
 // are chains of LDS and memory round trips.  A wave in the latency-bound phases wins the issue arbitration against the
-// waves that classify bytes, so its loads go out early and the classifying waves fill the gaps: -9 % on C3.
+// waves that classify bytes, so its loads go out early and the classifying waves fill the gaps.
 #ifndef SVJG_P_B2
-#define SVJG_P_B2 1          /* list building (in front of the last barrier of phase B) */
+#define SVJG_P_B2 1          /* list building */
 #define SVJG_P_R1 2          /* line phase */
 #define SVJG_P_LOAD 3        /* node pass until its table loads are issued */
 #define SVJG_P_REST 2        /* rest of the node pass */
 #endif
 #ifndef SVJG_P_A
-#define SVJG_P_A 1          /* registers -> LDS, next stripe's loads issued (in front of the first barrier) */
+#define SVJG_P_A 1          /* registers -> LDS */
 #endif
 constexpr int P_A = SVJG_P_A;
 constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST = SVJG_P_REST;
@@ -338,181 +336,212 @@ constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST =
 #else
 #define DIAG(bit) false
 #endif
+#ifndef SVJG_MINW
+#define SVJG_MINW 2
+#endif
+__device__ inline unsigned long long low_bits64(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+__device__ inline uint32_t clamp64(uint32_t hi, uint32_t lo) { return hi > lo ? (hi - lo < 64u ? hi - lo : 64u) : 0u; }   // min(max(hi - lo, 0), 64)
+
 __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *text = lds + L_TEXT;
     uint32_t *ndbm = (uint32_t *)(lds + L_NDBM);
-    uint16_t *TP = (uint16_t *)(lds + L_TP), *OP = (uint16_t *)(lds + L_OP), *OL = (uint16_t *)(lds + L_OL);
-    uint16_t *LS = (uint16_t *)(lds + L_LS), *LT = (uint16_t *)(lds + L_LT), *LO = (uint16_t *)(lds + L_LO);
-    uint32_t *misc = (uint32_t *)(lds + L_MISC);
+    uint16_t *TP = (uint16_t *)(lds + L_TP);
+    uint32_t *OPL = (uint32_t *)(lds + L_OPL);
+    uint2 *LINE = (uint2 *)(lds + L_LINE);                              // .x = start | tabs in front << 16, .y = marks in front
+    uint4 *RL = (uint4 *)(lds + L_RL);
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint8_t *wb = lds + L_WAVE + wave * WAVE_BYTES;                    // this wave's private arrays
-    uint32_t *l_need_l = (uint32_t *)(wb + W_NEEDL), *l_need_r = (uint32_t *)(wb + W_NEEDR);
-    uint32_t *l_meta = (uint32_t *)(wb + W_META);
-    uint16_t *l_pend = (uint16_t *)(wb + W_PEND);
-
+    const uint32_t lane = threadIdx.x;
     const GraphView g = a.g;
+
+    unsigned long long pos = (unsigned long long)blockIdx.x * a.region;   // first byte not worked off yet (wave-uniform)
+    if (pos >= a.n_bytes) return;
+    const unsigned long long rend = pos + a.region < a.n_bytes ? pos + a.region : a.n_bytes;   // lines starting before it are this worker's
 
     unsigned long long wave_lines = 0;
     // measurement only (build with -DSVJG_TIMING, run with SVJG_DIAG & 16): time this wave spends per phase
 #ifdef SVJG_TIMING
     unsigned long long stamp = __builtin_readcyclecounter(), acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&](int ph) { const unsigned long long t = __builtin_readcyclecounter(); acc[ph] += t - stamp; stamp = t; };
+#elif defined(SVJG_MARK)
+    // static census (tools/isa): the phase boundaries show up as comments in the -S output
+#define tick(ph) asm volatile("; MARK " #ph)
 #else
     auto tick = [](int) {};
 #endif
 
-    // stripe prefetch registers
-    uint4 pf[PIECES];
+    // stripe prefetch registers: piece i of the lane = bytes [(i * 64 + lane) * 16, + 16) of the staged text
+    constexpr uint32_t NPF = TEXT / (WG * 16);
+    uint4 pf[NPF];
     uint32_t pf_head = '\n';                                           // byte right before the stripe (decides whether it starts a line)
-    const bool list_mode = a.starts != nullptr;
-    auto stripe_start = [&](uint32_t chunk) -> uint64_t {              // where the stripe's staged text begins (16-byte aligned)
-        const uint32_t c = chunk < a.n_chunks ? chunk : a.n_chunks - 1;
-        return list_mode ? (a.starts[c] & ~15ull) : (uint64_t)c * a.chunk;
-    };
-    auto prefetch = [&](uint32_t chunk) {                            // no bounds tests: the buffer is zero padded by TEXT + 64 bytes
-        const uint64_t c0 = stripe_start(chunk);
-        const uint4 *src = (const uint4 *)(a.gaf + c0) + tid;
+    auto prefetch = [&](unsigned long long c0) {                     // no bounds tests: the buffer is zero padded by TEXT + 64 bytes
+        const uint4 *src = (const uint4 *)(a.gaf + c0) + lane;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (uint32_t i = 0; i < PIECES; ++i) {                          // non-temporal: the text is streamed once and should not displace the node records in L2 (-1.5 %)
+        for (uint32_t i = 0; i < NPF; ++i) {                             // non-temporal: the text is streamed once and should not displace the node records in L2
             const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(src + i * WG));
             pf[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
         pf_head = c0 ? a.gaf[c0 - 1] : (uint32_t)'\n';
     };
-    prefetch(blockIdx.x);
-    if (tid == 0) misc[1] = 0;                                           // "stripe holds a byte >= 0x80"
-    lds_barrier();
+    prefetch(pos & ~15ull);
 
-    for (uint32_t chunk = blockIdx.x; chunk < a.n_chunks; chunk += gridDim.x) {
-        const uint64_t c0 = stripe_start(chunk);
-        const uint32_t V = (uint32_t)((a.n_bytes - c0 < (uint64_t)TEXT) ? (a.n_bytes - c0) : (uint64_t)TEXT);   // valid bytes staged
-        // lines starting in [own_lo, own_lim) belong to the stripe: everything below the stride, or (second launch) the one listed line
-        const uint32_t own_lo = list_mode ? (uint32_t)(a.starts[chunk] & 15ull) : 0u;
-        const uint32_t own_lim = list_mode ? own_lo + 1u : (V < a.chunk ? V : a.chunk);
+    for (;;) {
+        const unsigned long long c0 = pos & ~15ull;
+        const uint32_t own_lo = (uint32_t)(pos - c0);                   // lines starting in [own_lo, lim2) belong to this stripe
+        const uint32_t V = (uint32_t)((a.n_bytes - c0 < (unsigned long long)TEXT) ? (a.n_bytes - c0) : (unsigned long long)TEXT);   // valid bytes staged
+        const uint32_t own_lim = rend - c0 < (unsigned long long)V ? (uint32_t)(rend - c0) : V;
         const bool at_eof = c0 + V == a.n_bytes;
 
-        // ---- A: registers -> LDS, then start the next stripe's HBM loads ---------------------------------
+        // ---- A: registers -> LDS; bytes >= 0x80 and the "id:f:" filter on the registers -------------------------
+        __builtin_amdgcn_s_setprio(P_A);
         uint32_t hi_bits = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < PIECES; ++i) {
+        for (uint32_t i = 0; i < NPF; ++i) {
             hi_bits |= pf[i].x | pf[i].y | pf[i].z | pf[i].w;
-            *(uint4 *)(text + (i * WG + tid) * 16) = pf[i];
+            *(uint4 *)(text + (i * WG + lane) * 16) = pf[i];
         }
-        if (hi_bits & 0x80808080u) { a.st->non_ascii = 1; misc[1] = 1; }
         const uint32_t head_byte = pf_head;
-        lds_barrier();
-        const bool ascii = misc[1] == 0;                                 // workgroup-uniform: the cheaper SWAR classes apply
-        prefetch(chunk + gridDim.x);
+        const bool ascii = __ballot((hi_bits & 0x80808080u) != 0) == 0;   // wave-uniform: the cheaper SWAR classes apply
+        if (!ascii && lane == 0) a.st->non_ascii = 1;
+        uint32_t idf_acc = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < NPF; ++i) {
+            // first word of the following piece: the next lane's, for lane 63 lane 0's of the next register (behind the staged text: nothing)
+            const uint32_t wrap = i + 1 < NPF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pf[i + 1 < NPF ? i + 1 : i].x) : 0u;
+            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)wrap, (int)pf[i].x, 0x130, 0xF, 0xF, false);   // wave_shl:1
+            idf_acc = ascii ? idf_piece<true>(pf[i], nx, idf_acc) : idf_piece<false>(pf[i], nx, idf_acc);
+        }
+        const bool idf = __ballot((idf_acc & 0x80808080u) != 0) != 0;
+        wave_sync();
         __builtin_amdgcn_s_setprio(0);
         tick(0);
 
-        // ---- B1: byte classes, counts, workgroup prefix sum ------------------------------------------------
-        unsigned long long NL, TAB, ORI;
-        const uint32_t sp = tid * SPAN;
-        if (ascii) classify_span<true>(a, text, ndbm, tid, c0, V, NL, TAB, ORI);
-        else classify_span<false>(a, text, ndbm, tid, c0, V, NL, TAB, ORI);
-        uint32_t head = 0;                                               // does the stripe begin at a line start?
-        if (tid == 0) head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
-        // a terminator at sp + b starts a line at sp + b + 1; the stripe owns it if that lies in [own_lo, own_lim)
-        const uint32_t keep = own_lim > sp + 1 ? (own_lim - sp - 1 < 64u ? own_lim - sp - 1 : 64u) : 0u;
-        const uint32_t skip = own_lo > sp + 1 ? (own_lo - sp - 1 < 64u ? own_lo - sp - 1 : 64u) : 0u;
-        const unsigned long long below_lo = skip >= 64u ? ~0ull : ((1ull << skip) - 1ull);
-        const unsigned long long OWN = NL & (keep >= 64u ? ~0ull : ((1ull << keep) - 1ull)) & ~below_lo;
-        const uint32_t head_own = head & (uint32_t)(own_lo == 0 && 0 < own_lim);
-        if (tid == 0) misc[2] = (head & (uint32_t)(0 < own_lo)) + (uint32_t)__popcll(NL & below_lo);   // (own_lo < 16: only this lane can see such starts)
-        const uint32_t cA = ((uint32_t)__popcll(NL) + head) | (((uint32_t)__popcll(OWN) + head_own) << 16);
-        const uint32_t cB = (uint32_t)__popcll(TAB) | ((uint32_t)__popcll(ORI) << 16);
-        uint32_t wA, wB;
-        const uint32_t exA = wave_excl_scan(cA, wA), exB = wave_excl_scan(cB, wB);
-        if (lane == 0) { misc[8 + wave] = wA; misc[16 + wave] = wB; }
-        lds_barrier();
-        uint32_t baseA = 0, baseB = 0, totA = 0, totB = 0;
+        // ---- B1: byte classes ---------------------------------------------------------------------------------
+        unsigned long long NL[NHALF], TAB[NHALF], ORI[NHALF];
 #pragma unroll
-        for (uint32_t w = 0; w < NWAVE; ++w) {
-            const uint32_t xa = misc[8 + w], xb = misc[16 + w];
-            if (w < wave) { baseA += xa; baseB += xb; }
-            totA += xa; totB += xb;
+        for (uint32_t h = 0; h < NHALF; ++h) {
+            if (ascii) classify_span<true>(a, text, ndbm, h * WG + lane, c0, V, NL[h], TAB[h], ORI[h]);
+            else classify_span<false>(a, text, ndbm, h * WG + lane, c0, V, NL[h], TAB[h], ORI[h]);
         }
-        if (tid == 0) misc[1] = 0;                                       // (every wave has read it; set again only after the stripe's last barrier)
-        const uint32_t n_s = totA & 0xFFFFu, n_own = totA >> 16;         // line starts in the staged text, and how many of them this stripe owns
-        const uint32_t tot_tab = totB & 0xFFFFu, tot_ori = totB >> 16;
-        const uint32_t sb = ((baseA + exA) & 0xFFFFu) + (tid == 0 ? head : 0u);    // ordinal of the first line start this lane creates
+        // does the stripe begin at a line start?  (wave-uniform)
+        const uint32_t head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
+        // the last line start in the staged text (a terminator at b starts a line at b + 1)
+        uint32_t s_last = NONE32;
+        {
+            const unsigned long long b1 = __ballot(NL[1] != 0), b0 = __ballot(NL[0] != 0);
+            if (b1 | b0) {
+                const uint32_t hh = b1 ? 1u : 0u;
+                const uint32_t L = 63u - (uint32_t)__builtin_clzll(b1 ? b1 : b0);
+                const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hh ? NL[1] : NL[0]), (int)L);
+                const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((hh ? NL[1] : NL[0]) >> 32), (int)L);
+                const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+                s_last = (hh * WG + L) * SPAN + (63u - (uint32_t)__builtin_clzll(m)) + 1u;
+            } else if (head) s_last = 0;
+        }
+        // which lines this stripe handles, and where the next one begins
+        uint32_t lim2 = own_lim;
+        bool last_stripe = false, long_line = false;
+        unsigned long long next_pos = c0 + V;
+        if (at_eof) last_stripe = true;                                  // every line ends inside the staged text (the last one maybe without a terminator)
+        else if (s_last == NONE32 || s_last < own_lo) { }                // no line starts here: the stripe lies inside one long line
+        else if (c0 + s_last >= rend) last_stripe = true;                // the last line start is the next worker's: all of this worker's lines end in here
+        else if (s_last > own_lo) { lim2 = s_last; next_pos = c0 + s_last; }   // the line at s_last has no end in here: the next stripe begins with it
+        else long_line = true;                                           // a single line longer than the staged text: exact path
+        if (next_pos >= rend) last_stripe = true;
+        if (!last_stripe) prefetch(next_pos & ~15ull);
+
+        // counts and wave prefix sums; a terminator at sp + b starts a line at sp + b + 1, owned if that lies in [own_lo, lim2)
+        unsigned long long OWN[NHALF];
+        uint32_t exA[NHALF], exB[NHALF], totA[NHALF], totB[NHALF];
+        const uint32_t head_own = head & (uint32_t)(own_lo == 0 && 0 < lim2);
+        uint32_t l_first = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < NHALF; ++h) {
+            const uint32_t sp = (h * WG + lane) * SPAN;
+            const unsigned long long below_lo = low_bits64(clamp64(own_lo, sp + 1));
+            OWN[h] = NL[h] & low_bits64(clamp64(lim2, sp + 1)) & ~below_lo;
+            const uint32_t hd = (h == 0 && lane == 0) ? head : 0u, hdo = (h == 0 && lane == 0) ? head_own : 0u;
+            if (h == 0) l_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((head & (uint32_t)(0 < own_lo)) + (uint32_t)__popcll(NL[0] & below_lo)));   // (own_lo < 16: only lane 0 can see such starts)
+            const uint32_t cA = ((uint32_t)__popcll(NL[h]) + hd) | (((uint32_t)__popcll(OWN[h]) + hdo) << 16);
+            const uint32_t cB = (uint32_t)__popcll(TAB[h]) | ((uint32_t)__popcll(ORI[h]) << 16);
+            exA[h] = wave_excl_scan(cA, totA[h]); exB[h] = wave_excl_scan(cB, totB[h]);
+        }
+        const uint32_t totAs = totA[0] + totA[1], totBs = totB[0] + totB[1];
+        const uint32_t n_s = totAs & 0xFFFFu, n_own = totAs >> 16;       // line starts in the staged text, and how many of them this stripe handles
+        const uint32_t tot_tab = totBs & 0xFFFFu, tot_ori = totBs >> 16;
         tick(1);
 
-        if (a.all_slow || n_s > MAXL || tot_tab > CAP_T || tot_ori > CAP_O) {
-            // the lists cannot hold this stripe (or the caller wants the exact path): every owned line is deferred as it is
-            const uint32_t mine = (uint32_t)__popcll(OWN) + head_own;
-            uint32_t wt;
-            const uint32_t ex = wave_excl_scan(mine, wt);
-            unsigned long long dbase = 0;
-            if (wt) {
-                if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)wt);
-                dbase = __shfl(dbase, 0) + ex;
-                if (head_own) { if (dbase < a.deferred_cap) a.deferred[dbase] = c0; else atomicOr(&a.st->overflow, 1u); ++dbase; }
-                for (unsigned long long m = OWN; m; m &= m - 1, ++dbase) {
-                    if (dbase < a.deferred_cap) a.deferred[dbase] = c0 + sp + (uint32_t)__builtin_ctzll(m) + 1u; else atomicOr(&a.st->overflow, 1u);
+        if (a.all_slow || idf || long_line || n_s > MAXL || tot_tab > CAP_T || tot_ori > CAP_O) {
+            // the lists cannot hold this stripe / "id:f:" somewhere in it / the caller wants the exact path: every owned line is deferred as it is
+            if (n_own) {
+                unsigned long long dbase = 0;
+                if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)n_own);
+                dbase = __shfl(dbase, 0);
+#pragma unroll
+                for (uint32_t h = 0; h < NHALF; ++h) {
+                    const uint32_t sp = (h * WG + lane) * SPAN;
+                    unsigned long long d = dbase + (((h ? totA[0] : 0u) + exA[h]) >> 16);
+                    if (h == 0 && lane == 0 && head_own) { if (d < a.deferred_cap) a.deferred[d] = c0; else atomicOr(&a.st->overflow, 1u); ++d; }
+                    for (unsigned long long m = OWN[h]; m; m &= m - 1, ++d) {
+                        if (d < a.deferred_cap) a.deferred[d] = c0 + sp + (uint32_t)__builtin_ctzll(m) + 1u; else atomicOr(&a.st->overflow, 1u);
+                    }
                 }
             }
-            if (tid == 0 && !list_mode) wave_lines += n_own;
-            lds_barrier();
+            wave_lines += n_own;
+            wave_sync();
+            if (last_stripe) break;
+            pos = next_pos;
             continue;
         }
 
         __builtin_amdgcn_s_setprio(P_B2);
         // ---- B2: rank-indexed lists ----------------------------------------------------------------------
-        {
-            const uint32_t tb = (baseB + exB) & 0xFFFFu, ob = (baseB + exB) >> 16;
-            if (tid == 0) {
-                if (head) { LS[0] = 0; LT[0] = 0; LO[0] = 0; }
-                LS[n_s] = 0xFFFFu; LT[n_s] = (uint16_t)tot_tab; LO[n_s] = (uint16_t)tot_ori;
-            }
+        if (lane == 0) {
+            if (head) LINE[0] = make_uint2(0u, 0u);
+            LINE[n_s] = make_uint2(0xFFFFu | (tot_tab << 16), tot_ori);
+        }
+#pragma unroll
+        for (uint32_t h = 0; h < NHALF; ++h) {
+            const uint32_t sp = (h * WG + lane) * SPAN;
+            const uint32_t bA = (h ? totA[0] : 0u) + exA[h], bB = (h ? totB[0] : 0u) + exB[h];
+            const uint32_t sb = (bA & 0xFFFFu) + ((h == 0 && lane == 0) ? head : 0u);   // ordinal of the first line start this lane creates
+            const uint32_t tb = bB & 0xFFFFu, ob = bB >> 16;
             uint32_t j = sb;
-            for (unsigned long long m = NL; m; m &= m - 1, ++j) {
+            for (unsigned long long m = NL[h]; m; m &= m - 1, ++j) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(m);
                 const unsigned long long below = (1ull << b) - 1ull;
-                LS[j] = (uint16_t)(sp + b + 1);
-                LT[j] = (uint16_t)(tb + (uint32_t)__popcll(TAB & below));
-                LO[j] = (uint16_t)(ob + (uint32_t)__popcll(ORI & below));
+                LINE[j] = make_uint2((sp + b + 1) | ((tb + (uint32_t)__popcll(TAB[h] & below)) << 16), ob + (uint32_t)__popcll(ORI[h] & below));
             }
             j = tb;
-            for (unsigned long long m = TAB; m; m &= m - 1, ++j) TP[j] = (uint16_t)(sp + (uint32_t)__builtin_ctzll(m));
+            for (unsigned long long m = TAB[h]; m; m &= m - 1, ++j) TP[j] = (uint16_t)(sp + (uint32_t)__builtin_ctzll(m));
             j = ob;
-            for (unsigned long long m = ORI; m; m &= m - 1, ++j) {
+            for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                OP[j] = (uint16_t)(sp + b);
-                OL[j] = (uint16_t)(sb + (uint32_t)__popcll(NL & ((1ull << b) - 1ull)) - 1u);   // 0xFFFF: tail of a line of the previous stripe
+                // line that holds the mark; 0xFFFF: tail of a line of the previous stripe
+                OPL[j] = (sp + b) | ((sb + (uint32_t)__popcll(NL[h] & ((1ull << b) - 1ull)) - 1u) << 16);
             }
         }
-        lds_barrier();
+        wave_sync();
         tick(2);
 
         __builtin_amdgcn_s_setprio(P_R1);
-        // ---- rounds: this wave's share of the stripe's lines -----------------------------------------------
-        const uint32_t per = (n_own + NWAVE_R - 1) / NWAVE_R, l_first = misc[2];
-        const uint32_t l_lo = l_first + (wave * per < n_own ? wave * per : n_own), l_hi = l_lo + per < l_first + n_own ? l_lo + per : l_first + n_own;
-        for (uint32_t lbase = DIAG(1u) ? l_hi : l_lo, taken = 0; lbase < l_hi; lbase += taken) {   // wave-uniform trip count
+        // ---- rounds of up to LRW lines -----------------------------------------------------------------------------
+        const uint32_t l_hi = l_first + n_own;
+        for (uint32_t lbase = DIAG(1u) ? l_hi : l_first; lbase < l_hi; lbase += LRW) {   // wave-uniform trip count
             const uint32_t cnt = l_hi - lbase < LRW ? l_hi - lbase : LRW;
-            const uint32_t obase = LO[lbase];
+            const uint32_t obase = LINE[lbase].y;
             // ---- R1: one line per lane --------------------------------------------------------------
-            uint32_t status = ST_NONE, k = 0, s = 0, rel = 0, kall = 0;
-            bool cut = false;                                            // the line runs past the staged text
-            uint32_t li = lane;                                          // index into the round arrays; opaque to the compiler so that the
-            asm volatile("" : "+v"(li));                                 // addresses are recomputed here instead of being kept (and spilled) across the stripe loop
+            uint32_t status = ST_NONE, k = 0, s = 0, rel = 0, kall = 0, r_need_l = 0, r_need_r = 0, r_pend = 0;
             if (lane < cnt) {
                 const uint32_t L = lbase + lane;
-                s = LS[L];
-                const uint32_t nx = LS[L + 1], tr = LT[L], tn = LT[L + 1], o0 = LO[L], o1 = LO[L + 1];
+                const uint2 l0 = LINE[L], l1 = LINE[L + 1];
+                s = l0.x & 0xFFFFu;
+                const uint32_t nx = l1.x & 0xFFFFu, tr = l0.x >> 16, tn = l1.x >> 16, o0 = l0.y, o1 = l1.y;
                 kall = o1 - o0; rel = o0 - obase;
-                uint32_t e = V;
-                bool complete = true;
-                if (nx != 0xFFFFu) e = nx - 1;
-                else if (!at_eof) { complete = false; cut = true; }
                 status = ST_DEFER;
-                if (complete) {
+                if (nx != 0xFFFFu || at_eof) {                           // (always: the stripe handles only lines that end in it)
+                    uint32_t e = nx != 0xFFFFu ? nx - 1 : V;
                     uint32_t nt = tn - tr;
                     if (e > s && py_space(text[e - 1])) {                // line.rstrip(): blanks, a CR, trailing tabs
                         do --e; while (e > s && py_space(text[e - 1]));
@@ -529,11 +558,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     if (ok) {
                         ok = bits_clear(ndbm, t0 + 1, t3 - t0 - 1) & bits_clear(ndbm, t5 + 1, t11 - t5 - 1);
                         const uint32_t alen = field_val(text, t9 + 1, t10 - t9 - 1);
-                        ok &= alen != 0;                                 // ZeroDivisionError unless an id:f: tag exists: exact path decides
+                        ok &= alen != 0;                                 // ZeroDivisionError (no id:f: tag in this stripe): exact path decides
                         // path column (t4, t5): every orientation mark of the line sits in it, the first one right after t4
                         k = kall;
                         ok &= k >= 1 && k <= KMAX && t5 > t4 + 1;
-                        if (ok) ok = (uint32_t)OP[o0] == t4 + 1 && (uint32_t)OP[o0 + k - 1] < t5;
+                        if (ok) ok = (OPL[o0] & 0xFFFFu) == t4 + 1 && (OPL[o0 + k - 1] & 0xFFFFu) < t5;
                         if (ok) {
                             status = k >= 2 ? ST_OK : ST_NOHIT;
                             // check_bkpt_overlap (filter-alignments.py:258-273) for a link of this line reads
@@ -541,17 +570,15 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                             // the two right-hand sides are fixed per line (clamped to 32 bits: the sums stay below 2^31)
                             const long long tlen = field_val(text, t5 + 1, t6 - t5 - 1), ts = field_val(text, t6 + 1, t7 - t6 - 1), te = field_val(text, t7 + 1, t8 - t7 - 1);
                             const long long need_l = ts + (long long)g.d_over, need_r = (long long)g.d_over + tlen - te - 1;
-                            l_need_l[li] = need_l > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)need_l;
-                            l_need_r[li] = need_r < 0 ? 0u : need_r > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)need_r;
-                            l_pend[li] = (uint16_t)t5;
+                            r_need_l = need_l > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)need_l;
+                            r_need_r = need_r < 0 ? 0u : need_r > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)need_r;
+                            r_pend = t5;
                         }
                     }
                 }
             }
             if (status != ST_OK) k = 0;
-            const uint32_t taken_r = cnt;                                // the round takes all its lines; their marks are worked off in passes
-            taken = taken_r;
-            if (lane < LRW) l_meta[li] = rel | (k << 16) | (status << 24);
+            RL[lane] = make_uint4(r_need_l, r_need_r, rel | (k << 16) | (status << 24), r_pend);
             wave_sync();
             tick(3);
             if (DIAG(2u)) continue;                                      // measurement only: stop after R1
@@ -573,11 +600,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 uint64_t h = 0;
                 bool live = false, probe = false;
                 if (act) {
-                    const uint32_t opv = OP[o], opn = OP[o + 1];        // (independent of the line: one LDS round trip with OL)
-                    ln = (uint32_t)OL[o] - lbase;
-                    meta = l_meta[ln];
-                    const uint32_t pend = l_pend[ln];
-                    need_l = l_need_l[ln]; need_r = l_need_r[ln];
+                    const uint32_t opl = OPL[o], opn = OPL[o + 1] & 0xFFFFu;
+                    const uint32_t opv = opl & 0xFFFFu;
+                    ln = (opl >> 16) - lbase;
+                    const uint4 rl = RL[ln];
+                    meta = rl.z;
+                    const uint32_t pend = rl.w;
+                    need_l = rl.x; need_r = rl.y;
                     live = (meta >> 24) == ST_OK;
                     lnb = (meta & 0xFFFFu) - p0; lk = (meta >> 16) & 0xFFu; j = lane - lnb;
                     if (live) {
@@ -595,7 +624,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 if (!live) { j = 0; lk = 0; lnb = 0; }
                 const unsigned long long lmask = (lk >= 64u ? ~0ull : ((1ull << lk) - 1ull)) << (lnb & 63u);   // the lanes of this node's line
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
-                //    the name can be in: 64 bytes with the spelling, id, length and the node's two commonest links --
+                //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
                 if (probe) dsp = g.name_disp[name_bucket(h, g.name_buckets)];
                 uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0xFFFFFFFFu, 0), r2 = make_uint4(0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0), r3 = make_uint4(0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0);
@@ -613,7 +642,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 {
                     const unsigned long long badm = __ballot(live && (id == NONE32 || lbp >= (1u << 25)));
                     if (live && (badm & lmask)) {
-                        if (j == 0) l_meta[ln] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
+                        if (j == 0) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
                         live = false;
                     }
                 }
@@ -712,7 +741,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     if (!DIAG(8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
                     if (a.want_hits) {
                         if (rbase + jj < a.rec_cap) {
-                            svjg_hitrec r; r.line_start = a.base_offset + c0 + LS[lbase + ln]; r.slot = hv >> 1;
+                            svjg_hitrec r; r.line_start = a.base_offset + c0 + (LINE[lbase + ln].x & 0xFFFFu); r.slot = hv >> 1;
                             r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
                             a.recs[rbase + jj] = r;
                         } else atomicOr(&a.st->overflow, 2u);
@@ -723,11 +752,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             wave_sync();
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
-                uint32_t lr = lane;
-                asm volatile("" : "+v"(lr));
-                const bool defer = lane < taken && (l_meta[lr] >> 24) == ST_DEFER;
-                const unsigned long long cb = __ballot(cut && lane < taken && !list_mode);
-                if (cb && lane == 0) atomicAdd(&a.st->n_incomplete, (unsigned long long)__popcll(cb));
+                const bool defer = lane < cnt && (RL[lane].z >> 24) == ST_DEFER;
                 unsigned long long db = __ballot(defer);
                 if (db) {
                     unsigned long long dbase = 0;
@@ -735,29 +760,24 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     dbase = __shfl(dbase, 0);
                     if (defer) {
                         unsigned long long idx = dbase + __popcll(db & ((1ull << lane) - 1ull));
-                        // a line cut off by the staged text gets a second chance with a stripe of its own (DEFER_CUT) before the exact path
-                        if (idx < a.deferred_cap) a.deferred[idx] = (c0 + s) | ((cut && !list_mode) ? DEFER_CUT : 0ull); else atomicOr(&a.st->overflow, 1u);
+                        if (idx < a.deferred_cap) a.deferred[idx] = c0 + s; else atomicOr(&a.st->overflow, 1u);
                     }
                 }
             }
             wave_sync();                                                 // round state is reused
+            __builtin_amdgcn_s_setprio(P_R1);
         }
-        __builtin_amdgcn_s_setprio(P_A);
-        if (!list_mode) wave_lines += l_hi - l_lo;
-        lds_barrier();                                                 // text, bitmap and lists are overwritten by the next stripe
+        wave_lines += n_own;
+        wave_sync();                                                     // text, bitmap and lists are overwritten by the next stripe
         tick(7);
+        if (last_stripe) break;
+        pos = next_pos;
     }
     if (lane == 0 && wave_lines) atomicAdd(&a.st->n_lines, wave_lines);
 #ifdef SVJG_TIMING
     if ((a.diag & 16u) && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc[i]);
 #endif
-}
-
-// starts of the lines the first launch found cut off by its staged text -> a list of their own for the second launch
-__global__ __launch_bounds__(TPB) void k_pick_cut(const uint64_t *deferred, uint64_t n_def, uint64_t *out, unsigned long long *n_out) {
-    const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-    if (i < n_def && (deferred[i] & DEFER_CUT)) out[atomicAdd(n_out, 1ull)] = deferred[i] & ~DEFER_CUT;
 }
 
 struct SlowEmit {
@@ -784,7 +804,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
     __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
     const uint32_t lane = threadIdx.x;
     for (uint64_t b0 = (uint64_t)blockIdx.x * SLOW_TPB; b0 < n_def; b0 += (uint64_t)gridDim.x * SLOW_TPB) {
-        const bool have = b0 + lane < n_def && !(a.deferred[b0 + lane] & DEFER_CUT);   // (cut lines went through the second launch)
+        const bool have = b0 + lane < n_def;
         uint64_t s = 0, e = 0;
         if (have) {
             s = a.deferred[b0 + lane];
@@ -835,7 +855,6 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
     const uint32_t lane = threadIdx.x;
     for (uint64_t b = blockIdx.x; b < n_def; b += gridDim.x) {
         const uint64_t s = a.deferred[b];
-        if (s & DEFER_CUT) continue;                                     // (cut lines went through the second launch)
         // the terminator: 64 aligned 16-byte blocks per step
         const uint64_t a0 = s & ~15ull;
         uint64_t e = ~0ull;
@@ -880,6 +899,24 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
         } else rc = wave_min(slow_line(a.g, a.gaf, s, e, em, lane, 64u, &order), order);
         if (lane == 0 && rc) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (unsigned long long)rc);
         __syncthreads();
+    }
+}
+
+// Overflow guard of the packed count vector (ref | alt << 32, summed as one 64-bit integer by the kernels' atomics and by the
+// all-reduce): the largest ref field and the largest alt field go to the two extra elements behind the vector, which travel
+// through the same all-reduce; if the SUM over the ranks of these maxima stays below 2^32 no slot can have carried from one
+// half into the other (the host then mirrors the OverflowError of a Python-side sum).
+__global__ __launch_bounds__(TPB) void k_counts_guard(unsigned long long *counts, uint32_t n_slots) {
+    uint32_t mr = 0, ma = 0;
+    for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_slots; i += gridDim.x * TPB) {
+        const unsigned long long c = counts[i];
+        const uint32_t r = (uint32_t)c, al = (uint32_t)(c >> 32);
+        mr = r > mr ? r : mr; ma = al > ma ? al : ma;
+    }
+    for (int d = 32; d; d >>= 1) { const uint32_t y = __shfl_down(mr, d), z = __shfl_down(ma, d); mr = mr > y ? mr : y; ma = ma > z ? ma : z; }
+    if ((threadIdx.x & 63) == 0) {
+        if (mr) atomicMax(&counts[n_slots], (unsigned long long)mr);
+        if (ma) atomicMax(&counts[n_slots + 1], (unsigned long long)ma);
     }
 }
 

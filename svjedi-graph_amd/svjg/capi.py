@@ -66,6 +66,8 @@ _SIGS = {
     "svjg_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "svjg_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "svjg_allreduce_counts": (ctypes.c_int, [ctypes.c_void_p]),
+    "svjg_comm_init_all": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    "svjg_allreduce_counts_all": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "svjg_genotype": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                      ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
@@ -298,7 +300,11 @@ class Context:
         if rc == -10:
             cls, off = ctypes.c_int(0), ctypes.c_uint64(0)
             self.lib.svjg_input_error(self.h, ctypes.byref(cls), ctypes.byref(off))
-            raise EXC_CLASS.get(cls.value, ValueError)(f"malformed GAF line at byte offset {off.value}")
+            e = EXC_CLASS.get(cls.value, ValueError)(f"malformed GAF line at byte offset {off.value}")
+            e.svjg_offset = off.value                           # (svjg/filter.py: reference_error)
+            raise e
+        if rc == -12:
+            raise OverflowError(self.lib.svjg_last_error(self.h).decode())
         if rc:
             raise SvjgError(f"libsvjg_hip error {rc}: {self.lib.svjg_last_error(self.h).decode()}")
 
@@ -396,6 +402,21 @@ class Context:
 
     def sync(self):
         self._chk(self.lib.svjg_sync(self.h))
+
+
+def _handles(ctxs):
+    return (ctypes.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+
+
+def comm_init_all(ctxs):
+    """One process, one Context per GPU: RCCL communicators for all of them (ncclCommInitAll inside the library)."""
+    ctxs[0]._chk(ctxs[0].lib.svjg_comm_init_all(_handles(ctxs), len(ctxs)))
+
+
+def allreduce_counts_all(ctxs):
+    """The path's one collective for a single-process run: afterwards every context holds the summed count vector.
+    With one context only the overflow guard runs.  OverflowError if a per-SV count does not fit 32 bits."""
+    ctxs[0]._chk(ctxs[0].lib.svjg_allreduce_counts_all(_handles(ctxs), len(ctxs)))
 
 
 def unique_id():

@@ -51,6 +51,47 @@ def check_utf8(data):
         dec.decode(bytes(data[a:a + (1 << 26)]), final=a + (1 << 26) >= n)
 
 
+def first_utf8_error(data, limit=None):
+    """Byte offset of the first invalid UTF-8 sequence in data[:limit], or None."""
+    import codecs
+    dec = codecs.getincrementaldecoder("utf-8")()
+    n = int(data.size) if limit is None else min(int(data.size), int(limit))
+    step = 1 << 26
+    for a in range(0, n, step):
+        try:
+            dec.decode(bytes(data[a:min(a + step, n)]), final=a + step >= n and n == int(data.size))
+        except UnicodeDecodeError as e:
+            # e.start is relative to what the decoder was given now plus what it had kept back (< 4 bytes)
+            return max(0, a + e.start - 3) if e.start < 3 and a else a + e.start
+    return None
+
+
+def reference_error(data, exc):
+    """Which exception the reference dies with when a line is malformed (`exc`, raised by the library with the line's offset)
+    AND the file holds bytes that are not UTF-8: the reference reads the GAF in text mode, in blocks of 8192 bytes that are
+    decoded as they are read, so the UnicodeDecodeError of a block comes before the ValueError / IndexError / ... of any line
+    that ends in or behind that block (filter-alignments.py:123-126)."""
+    off = getattr(exc, "svjg_offset", None)
+    if off is None:
+        return exc
+    n = int(data.size)
+    e = int(off)
+    while e < n and data[e] not in (10, 13):                # the offending line's terminator
+        blk = np.asarray(data[e:e + 65536])
+        hit = np.flatnonzero((blk == 10) | (blk == 13))
+        if hit.size:
+            e += int(hit[0])
+            break
+        e += blk.size
+    bad = first_utf8_error(data, min(n, (e // 8192 + 1) * 8192 + 4))
+    if bad is not None and e >= (bad // 8192) * 8192:
+        try:
+            bytes(data[bad:bad + 4]).decode("utf-8")
+        except UnicodeDecodeError as u:
+            return u
+    return exc
+
+
 def _stamp(t, what):
     """stage timers on stderr when SVJG_VERBOSE is set (measurement only)"""
     if os.environ.get("SVJG_VERBOSE"):
@@ -73,14 +114,13 @@ def pick_devices(n_bytes, device=None):
     return list(range(max(1, min(n_vis, n_bytes // MIN_BYTES_PER_DEVICE))))
 
 
-def _classify_shard(dev, graph, data, lo, hi, want_hits, out, r, path=None):
-    """One GPU, its contiguous byte range [lo, hi) of the file, chunk by chunk (cuts at line terminators).  With `path`
-    the library reads the chunk from the file itself (pinned, double-buffered ingest); `data` (the mapped file) is then
-    only looked at around the cut points."""
+def _classify_on_device(ctx, graph, data, ranges, want_hits, out, r, path=None):
+    """One GPU (one Context that keeps adding to its count vector), its contiguous byte ranges [lo, hi) of the file in file
+    order, each streamed chunk by chunk (cuts at line terminators).  With `path` the library reads the chunk from the file
+    itself (pinned, double-buffered ingest); `data` (the mapped file) is then only looked at around the cut points."""
     try:
-        ctx = capi.Context(dev)
-        try:
-            ctx.load_graph(graph)
+        ctx.load_graph(graph)
+        for lo, hi in ranges:
             n_chunks = max(1, -(-(hi - lo) // CHUNK_BYTES))
             cuts = [lo + c for c in shard.cut_points(data[lo:hi], n_chunks)]
             for a, b in zip(cuts[:-1], cuts[1:]):
@@ -88,12 +128,9 @@ def _classify_shard(dev, graph, data, lo, hi, want_hits, out, r, path=None):
                     ctx.classify_file(path, a, b - a, want_hits=want_hits)
                 elif b > a:
                     ctx.classify(data[a:b], base_offset=a, want_hits=want_hits)
-            st = ctx.stats()
-            out[r] = (ctx.counts().astype(np.uint64), ctx.hits() if want_hits else None, st, None)
-        finally:
-            ctx.close()
+        out[r] = None
     except BaseException as e:                    # re-raised by the caller: the reference dies at the FIRST bad line of the file
-        out[r] = (None, None, None, e)
+        out[r] = e
 
 
 def classify_file(ctx, graph, gaf_path, want_hits=True):
@@ -102,87 +139,141 @@ def classify_file(ctx, graph, gaf_path, want_hits=True):
     ctx.load_graph(graph)
     n = int(data.size)
     cuts = shard.cut_points(data, max(1, -(-n // CHUNK_BYTES)))
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        if b > a:
-            ctx.classify(data[a:b], base_offset=a, want_hits=want_hits)
+    try:
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b > a:
+                ctx.classify(data[a:b], base_offset=a, want_hits=want_hits)
+    except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+        raise reference_error(data, e)
     if ctx.stats()["non_ascii"]:
         check_utf8(data)
     return ctx.counts(), (ctx.hits() if want_hits else None), data
 
 
 def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
-    """-> (counts[n_slots, 2], hit records, the file's bytes).  The file is cut into one contiguous byte range per GPU
-    (line boundaries; rank order = file order), every range is streamed through its GPU in chunks, the per-SV counts are
-    summed and the hit records concatenated."""
+    """-> (counts[n_slots, 2], hit records, the file's bytes).  The file is cut into one contiguous byte range per entry of
+    `devices` (line boundaries; shard order = file order); every GPU streams its ranges through ONE context, so its count
+    vector holds the sum of its shards, and the per-GPU vectors are summed by the path's one collective, an RCCL all-reduce
+    inside the library (svjg_allreduce_counts_all: ncclCommInitAll over the contexts of this process).  Hit records stay per
+    GPU and are concatenated (the JSON writer orders them by line offset)."""
     t = _t or [time.perf_counter()]
     data = read_gaf(gaf_path)
     devs = devices if devices is not None else pick_devices(int(data.size))
     cuts = shard.cut_points(data, len(devs))
-    out = [None] * len(devs)
-    if len(devs) == 1:
-        _classify_shard(devs[0], graph, data, cuts[0], cuts[1], want_hits, out, 0, gaf_path)
-    else:
-        th = [threading.Thread(target=_classify_shard, args=(d, graph, data, cuts[r], cuts[r + 1], want_hits, out, r, gaf_path))
-              for r, d in enumerate(devs)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-    for counts, recs, st, err in out:             # shards are in file order: the first failing shard holds the first bad line
-        if err is not None:
-            raise err
-    _stamp(t, f"tables -> device, upload + classify on {len(devs)} GPU(s)")
-    if any(o[2]["non_ascii"] for o in out):
-        check_utf8(data)
-    total = np.zeros((graph.n_slots, 2), dtype=np.uint64)
-    for o in out:
-        total += o[0]
-    if (total >= 2 ** 32).any():
-        raise OverflowError("more than 2^32 informative alignments for one SV")
-    recs = None
-    if want_hits:
-        recs = out[0][1] if len(out) == 1 else np.concatenate([o[1] for o in out])
-    _stamp(t, "counts + hit records -> host")
-    return total.astype(np.uint32), recs, data
+    distinct = list(dict.fromkeys(devs))
+    ranges = {d: [(cuts[r], cuts[r + 1]) for r, x in enumerate(devs) if x == d] for d in distinct}
+    ctxs = []
+    try:
+        for d in distinct:
+            ctxs.append(capi.Context(d))
+        errs = [None] * len(distinct)
+        if len(distinct) == 1:
+            _classify_on_device(ctxs[0], graph, data, ranges[distinct[0]], want_hits, errs, 0, gaf_path)
+        else:
+            th = [threading.Thread(target=_classify_on_device, args=(ctxs[i], graph, data, ranges[d], want_hits, errs, i, gaf_path))
+                  for i, d in enumerate(distinct)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+        # the first failing shard (file order) holds the first bad line
+        first_bad = [(ranges[d][0][0], errs[i]) for i, d in enumerate(distinct) if errs[i] is not None]
+        if first_bad:
+            raise reference_error(data, min(first_bad, key=lambda x: x[0])[1])
+        _stamp(t, f"tables -> device, upload + classify on {len(distinct)} GPU(s)")
+        if any(c.stats()["non_ascii"] for c in ctxs):
+            check_utf8(data)
+        if len(ctxs) > 1:
+            capi.comm_init_all(ctxs)
+        capi.allreduce_counts_all(ctxs)           # (one GPU: only the overflow guard)
+        total = ctxs[0].counts()
+        recs = None
+        if want_hits:
+            recs = ctxs[0].hits() if len(ctxs) == 1 else np.concatenate([c.hits() for c in ctxs])
+        _stamp(t, "count all-reduce, counts + hit records -> host")
+        return total, recs, data
+    finally:
+        for c in ctxs:
+            c.close()
 
 
 # ---- counts hand-off to predict-genotype.py ---------------------------------------------------------------------------
 # predict-genotype.py only needs len() of the two lists of every key (predict-genotype.py:219-226), but the JSON it is
-# given is ~5x the GAF.  filter-alignments.py therefore also leaves the key -> (n_ref, n_alt) table in the temp directory,
-# tagged with the JSON's path, size and mtime; predict-genotype.py uses it only if all three still match and parses
-# the JSON otherwise.  Nothing is written next to the user's files.  SVJG_NO_HANDOFF=1 disables both sides.
-def handoff_path(json_path):
+# given is ~5x the GAF.  filter-alignments.py therefore also leaves the key -> (n_ref, n_alt) table in a directory only
+# this user can write (mode 0700 under $XDG_CACHE_HOME / ~/.cache), tagged with the JSON's size, mtime and a digest of its
+# first and last megabyte; predict-genotype.py uses it only if the directory and the file belong to the caller, nobody else
+# may write them, and all three tags still match — and parses the JSON otherwise.  Nothing is written next to the user's
+# files.  SVJG_NO_HANDOFF=1 disables both sides.
+def _handoff_dir(create):
+    base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    d = os.path.join(base, "svjedi-graph_amd")
+    if create:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise OSError(f"{d} is not a private directory of this user")
+    return d
+
+
+def handoff_path(json_path, create=False):
     import hashlib
-    import tempfile
     h = hashlib.sha1(os.path.abspath(json_path).encode()).hexdigest()[:24]
-    return os.path.join(tempfile.gettempdir(), f"svjg_counts_{os.getuid()}_{h}.npz")
+    return os.path.join(_handoff_dir(create), f"counts_{h}.npz")
+
+
+def _json_digest(json_path, size):
+    """sha1 over the first and the last MB of the file and its size: binds the table to the JSON's content, not only to its
+    size and time stamp (a same-size rewrite on a file system with coarse mtimes would otherwise pass)."""
+    import hashlib
+    h = hashlib.sha1(str(size).encode())
+    with open(json_path, "rb") as f:
+        h.update(f.read(1 << 20))
+        if size > (1 << 20):
+            f.seek(max(1 << 20, size - (1 << 20)))
+            h.update(f.read(1 << 20))
+    return np.frombuffer(h.digest(), dtype=np.uint8)
 
 
 def write_handoff(json_path, sv_ids, counts):
     if os.environ.get("SVJG_NO_HANDOFF"):
         return
+    target = None
     try:
+        target = handoff_path(json_path, create=True)
         keep = np.flatnonzero(counts.sum(axis=1) > 0)                       # the JSON holds only SVs with an informative alignment
         keys = sorted((sv_ids[i], int(i)) for i in keep)                    # json.dumps(sort_keys=True) order
         st = os.stat(json_path)
-        tmp = handoff_path(json_path) + f".{os.getpid()}.tmp.npz"
+        tmp = target + f".{os.getpid()}.tmp.npz"
         np.savez(tmp, keys=np.frombuffer("\0".join(k for k, _ in keys).encode("utf-8"), dtype=np.uint8),
                  counts=counts[[i for _, i in keys]].astype(np.uint32).reshape(-1, 2),
-                 tag=np.array([st.st_size, st.st_mtime_ns], dtype=np.int64))
-        os.replace(tmp, handoff_path(json_path))
+                 tag=np.array([st.st_size, st.st_mtime_ns], dtype=np.int64), digest=_json_digest(json_path, st.st_size))
+        os.replace(tmp, target)
     except OSError:
-        pass                                                                 # an optimisation only
+        # an optimisation only — but a stale table must not outlive a failed update
+        try:
+            if target:
+                os.unlink(target)
+        except OSError:
+            pass
 
 
 def read_handoff(json_path):
-    """-> (keys, counts) if a hand-off table for exactly this JSON file exists, else None."""
+    """-> (keys, counts) if a hand-off table written by this user for exactly this JSON file exists, else None."""
     if os.environ.get("SVJG_NO_HANDOFF"):
         return None
     try:
         st = os.stat(json_path)
-        with np.load(handoff_path(json_path)) as z:
+        p = handoff_path(json_path)
+        fst = os.lstat(p)
+        import stat
+        if not stat.S_ISREG(fst.st_mode) or fst.st_uid != os.getuid() or (fst.st_mode & 0o022):
+            return None
+        with np.load(p) as z:
             tag = z["tag"]
             if int(tag[0]) != st.st_size or int(tag[1]) != st.st_mtime_ns:
+                return None
+            if not np.array_equal(z["digest"], _json_digest(json_path, st.st_size)):
                 return None
             blob = z["keys"].tobytes().decode("utf-8")
             counts = z["counts"].astype(np.uint32).reshape(-1, 2)

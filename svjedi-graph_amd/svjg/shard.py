@@ -54,8 +54,9 @@ def file_shard(path, n_ranks, rank):
 
 class RcclGroup:
     """RCCL communicator living inside libsvjg_hip; the 128-byte unique id travels over whatever
-    bootstrap the launcher offers (`exchange` = callable(bytes|None) -> bytes, e.g. a torch.distributed
-    broadcast on the gloo backend)."""
+    bootstrap the launcher offers (`exchange` = callable(bytes|None) -> bytes; bench.py passes a broadcast over its
+    launcher's process group, tools/dist_boot.py).  One process per GPU; the single-process form the drop-in scripts use
+    is capi.comm_init_all / capi.allreduce_counts_all."""
 
     def __init__(self, ctx, n_ranks, rank, exchange):
         from . import capi
@@ -66,24 +67,3 @@ class RcclGroup:
 
     def allreduce_counts(self):
         self.ctx.allreduce_counts()
-
-
-def torch_exchange(uid):
-    """Broadcast rank 0's unique id through torch.distributed (any backend that moves CPU bytes)."""
-    import torch
-    import torch.distributed as dist
-    t = torch.zeros(128, dtype=torch.uint8)
-    if uid is not None:
-        t = torch.frombuffer(bytearray(uid), dtype=torch.uint8).clone()
-    dist.broadcast(t, src=0)
-    return bytes(t.numpy().tobytes())
-
-
-def torch_allreduce_counts(counts):
-    """Host-side sum of a count vector over torch.distributed (gloo): used by the CPU tests of the sharding
-    logic and by tools that reduce on the host; the GPU path uses RcclGroup."""
-    import torch
-    import torch.distributed as dist
-    t = torch.from_numpy(counts.astype(np.int64))
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.numpy().astype(counts.dtype)

@@ -419,6 +419,7 @@ def test_fuzz_cases(ctx, golden):
     """The 500 mutated GAF fragments of golden/fuzz (outcomes recorded from the reference itself): every fragment alone,
     then all the accepted ones in one file (the counts add up), then each fatal one behind a run of good lines."""
     import base64
+    from svjg import filter as flt
     from svjg.graph import Graph
     from tests.test_fuzz_golden import documented_divergence
     t = f"{golden}/testdir"
@@ -427,8 +428,8 @@ def test_fuzz_cases(ctx, golden):
     ctx.load_graph(g)
     total, good, n_dev = {}, [], 0
     def skip(c, raw):
-        # Unicode digits in decimal columns; a malformed id:f: tag (the main kernel does not read tags)
-        return documented_divergence({"raw": raw}) or (c["rc"] and c["error"] == "ValueError" and b"id:f:" in raw)
+        # Unicode digits in decimal columns
+        return documented_divergence({"raw": raw})
 
     for i, c in enumerate(cases):
         raw = base64.b64decode(c["gaf"])
@@ -436,7 +437,10 @@ def test_fuzz_cases(ctx, golden):
             continue
         ctx.reset_counts()
         try:
-            ctx.classify(np.frombuffer(raw, dtype=np.uint8))
+            try:
+                ctx.classify(np.frombuffer(raw, dtype=np.uint8))
+            except Exception as e:
+                raise flt.reference_error(np.frombuffer(raw, dtype=np.uint8), e)   # the host's part (svjg/filter.py): which error comes first
             if ctx.stats()["non_ascii"]:
                 raw.decode("utf-8")                    # the host's check (svjg/filter.py), as the reference's text-mode read
             got = ("ok", _counts_dict(g, ctx.counts()))

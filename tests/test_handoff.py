@@ -1,41 +1,72 @@
 """The counts hand-off between the two drop-in scripts (svjg/filter.py: write_handoff / read_handoff): it must describe
-exactly what a parse of the JSON gives, and must be ignored as soon as the JSON file is not the one it was written for."""
+exactly what a parse of the JSON gives, must be ignored as soon as the JSON file is not the one it was written for, and must
+live where only the calling user can write."""
 import json
 import os
 import shutil
+import stat
 
 import numpy as np
 
 from svjg import capi, filter as flt
 
 
+def _case(golden, tmp_path):
+    src = f"{golden}/testdir/ref_informative_aln.json"
+    dst = str(tmp_path / "p_informative_aln.json")
+    shutil.copy(src, dst)
+    ref = json.load(open(dst))
+    sv_ids = sorted(ref) + ["chrZ:DEL-1-2"]               # one SV without informative alignments: not in the JSON
+    counts = np.array([[len(ref[k][0]), len(ref[k][1])] for k in sorted(ref)] + [[0, 0]], dtype=np.uint32)
+    return dst, sv_ids, counts
+
+
 def test_handoff_matches_the_json(golden, tmp_path, monkeypatch):
-    monkeypatch.setenv("TMPDIR", str(tmp_path))
-    import tempfile
-    tempfile.tempdir = None                                   # re-read TMPDIR
-    try:
-        src = f"{golden}/testdir/ref_informative_aln.json"
-        dst = str(tmp_path / "p_informative_aln.json")
-        shutil.copy(src, dst)
-        ref = json.load(open(dst))
-        sv_ids = sorted(ref) + ["chrZ:DEL-1-2"]               # one SV without informative alignments: not in the JSON
-        counts = np.array([[len(ref[k][0]), len(ref[k][1])] for k in sorted(ref)] + [[0, 0]], dtype=np.uint32)
-        perm = np.random.default_rng(1).permutation(len(sv_ids))    # slots are in graph order, not in key order
-        flt.write_handoff(dst, [sv_ids[i] for i in perm], counts[perm])
-        got = flt.read_handoff(dst)
-        assert got is not None
-        keys, cnt = got
-        k2, c2 = capi.count_informative_json(dst)
-        assert keys == k2 and np.array_equal(cnt, c2)
-        # the file changes: the table no longer applies
-        with open(dst, "a") as fh:
-            fh.write(" ")
-        assert flt.read_handoff(dst) is None
-        flt.write_handoff(dst, sv_ids, counts)
-        os.utime(dst, ns=(1, 1))
-        assert flt.read_handoff(dst) is None
-        monkeypatch.setenv("SVJG_NO_HANDOFF", "1")
-        flt.write_handoff(dst, sv_ids, counts)
-        assert flt.read_handoff(dst) is None
-    finally:
-        tempfile.tempdir = None
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "cache"))
+    dst, sv_ids, counts = _case(golden, tmp_path)
+    perm = np.random.default_rng(1).permutation(len(sv_ids))    # slots are in graph order, not in key order
+    flt.write_handoff(dst, [sv_ids[i] for i in perm], counts[perm])
+    d = tmp_path / "cache" / "svjedi-graph_amd"
+    assert stat.S_IMODE(os.stat(d).st_mode) == 0o700            # a directory of the user's own, nothing in the shared temp dir
+    got = flt.read_handoff(dst)
+    assert got is not None
+    keys, cnt = got
+    k2, c2 = capi.count_informative_json(dst)
+    assert keys == k2 and np.array_equal(cnt, c2)
+    # the file changes: the table no longer applies
+    with open(dst, "a") as fh:
+        fh.write(" ")
+    assert flt.read_handoff(dst) is None
+    flt.write_handoff(dst, sv_ids, counts)
+    os.utime(dst, ns=(1, 1))
+    assert flt.read_handoff(dst) is None
+    monkeypatch.setenv("SVJG_NO_HANDOFF", "1")
+    flt.write_handoff(dst, sv_ids, counts)
+    assert flt.read_handoff(dst) is None
+
+
+def test_handoff_is_bound_to_content_and_owner(golden, tmp_path, monkeypatch):
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "cache"))
+    dst, sv_ids, counts = _case(golden, tmp_path)
+    flt.write_handoff(dst, sv_ids, counts)
+    assert flt.read_handoff(dst) is not None
+    # same size, same time stamp, other content (what a coarse-mtime file system would let through): the digest catches it
+    st = os.stat(dst)
+    raw = bytearray(open(dst, "rb").read())
+    i = raw.index(b"read")
+    raw[i:i + 4] = b"READ"
+    open(dst, "wb").write(raw)
+    os.utime(dst, ns=(st.st_atime_ns, st.st_mtime_ns))
+    assert os.stat(dst).st_size == st.st_size and os.stat(dst).st_mtime_ns == st.st_mtime_ns
+    assert flt.read_handoff(dst) is None
+    # a table others could have written is not trusted
+    flt.write_handoff(dst, sv_ids, counts)
+    p = flt.handoff_path(dst)
+    assert flt.read_handoff(dst) is not None
+    os.chmod(p, 0o666)
+    assert flt.read_handoff(dst) is None
+    os.chmod(p, 0o600)
+    os.chmod(os.path.dirname(p), 0o777)
+    assert flt.read_handoff(dst) is None
+    flt.write_handoff(dst, sv_ids, counts)                     # ... and nothing is written into such a directory either
+    os.chmod(os.path.dirname(p), 0o700)

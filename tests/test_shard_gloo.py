@@ -1,5 +1,5 @@
 """Multi-rank path on CPU: byte-range sharding of a GAF at line boundaries + ONE sum all-reduce of the per-SV
-count vector (svjedi-graph_amd/svjg/shard.py), world_size 2 over gloo.  On the GPU the per-rank counts come from
+count vector (svjedi-graph_amd/svjg/shard.py, tools/dist_boot.py), world_size 2 over gloo.  On the GPU the per-rank counts come from
 libsvjg_hip and the all-reduce is RCCL inside the library (svjg_allreduce_counts); here the per-rank counts come
 from the CPU oracle so that the sharding / reduction logic is what is under test."""
 import json
@@ -13,6 +13,7 @@ import pytest
 from oracle import oracle_c as OC
 from oracle import oracle_py as O
 from svjg import shard
+import dist_boot
 
 
 def test_cut_points_keep_lines_whole():
@@ -44,8 +45,8 @@ def _worker(rank, world, port, pre, out):
         orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
         mine, off = shard.file_shard(pre + ".gaf", world, rank)
         counts, _, n_lines = orc.filter(mine, want_hits=False)
-        total = shard.torch_allreduce_counts(counts)
-        uid = shard.torch_exchange(bytes(range(128)) if rank == 0 else None)     # the RCCL-id bootstrap path
+        total = dist_boot.torch_allreduce_counts(counts)
+        uid = dist_boot.torch_exchange(bytes(range(128)) if rank == 0 else None)     # the RCCL-id bootstrap path
         np.save(f"{out}.{rank}.npy", total)
         json.dump({"lines": int(n_lines), "offset": int(off), "uid_ok": uid == bytes(range(128))}, open(f"{out}.{rank}.json", "w"))
     finally:

@@ -9,8 +9,8 @@
 #define REP 4096
 #define CH 8
 
-enum Op { ADD32, XOR32, AND_OR, MUL_LO, MUL_U24, MAD_U24, MAD_U64, MUL_HI, LSHL64, LSHR64, ADD64, BCNT, BCNT64, FF1, FF1_64, DOT4, ALIGNBYTE, PERM, BFE, DPP_ADD, BALLOT, READLANE, SHFL, CMP_CNDMASK, SAD_U8, LSHL_OR, NOPS };
-static const char *NAMES[] = {"v_add_u32", "v_xor_b32", "v_and_or_b32", "v_mul_lo_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_mad_u64_u32", "v_mul_hi_u32", "v_lshlrev_b64", "v_lshrrev_b64", "64-bit add (2 instr)", "v_bcnt_u32_b32", "popcll (2 bcnt)", "v_ffbl_b32 (ctz)", "ctzll", "v_dot4_u32_u8", "v_alignbyte_b32", "v_perm_b32", "v_bfe_u32", "v_add_u32 dpp row_shr", "ballot (v_cmp -> sgpr)", "v_readlane", "ds_bpermute (shfl)", "v_cmp + v_cndmask", "v_sad_u8", "v_lshl_or_b32"};
+enum Op { ADD32, XOR32, AND_OR, MUL_LO, MUL_U24, MAD_U24, MAD_U64, MUL_HI, LSHL64, LSHR64, ADD64, BCNT, BCNT64, FF1, FF1_64, DOT4, ALIGNBYTE, PERM, BFE, DPP_ADD, BALLOT, READLANE, SHFL, CMP_CNDMASK, SAD_U8, LSHL_OR, QSAD, PK_MIN, XAD, BITOP3, MUL_LO2, FMA32, NOPS };
+static const char *NAMES[] = {"v_add_u32", "v_xor_b32", "v_and_or_b32", "v_mul_lo_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_mad_u64_u32", "v_mul_hi_u32", "v_lshlrev_b64", "v_lshrrev_b64", "64-bit add (2 instr)", "v_bcnt_u32_b32", "popcll (2 bcnt)", "v_ffbl_b32 (ctz)", "ctzll", "v_dot4_u32_u8", "v_alignbyte_b32", "v_perm_b32", "v_bfe_u32", "v_add_u32 dpp row_shr", "ballot (v_cmp -> sgpr)", "v_readlane", "ds_bpermute (shfl)", "v_cmp + v_cndmask", "v_sad_u8", "v_lshl_or_b32", "v_qsad_pk_u16_u8", "v_pk_min_u16", "v_xad_u32", "v_bitop3_b32", "v_mul_lo_u32 (by a register)", "v_fma_f32"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t seed, uint32_t *out) {
@@ -48,6 +48,12 @@ __global__ __launch_bounds__(256) void k(uint32_t seed, uint32_t *out) {
             if (OP == CMP_CNDMASK) x[c] = x[c] > s ? x[c] - s : x[(c + 1) % CH];
             if (OP == SAD_U8) x[c] = __builtin_amdgcn_sad_u8(x[c], s, x[(c + 1) % CH]);
             if (OP == LSHL_OR) x[c] = (x[c] << 3) | x[(c + 1) % CH];
+            if (OP == QSAD) y[c] = __builtin_amdgcn_qsad_pk_u16_u8(y[c], s, y[(c + 1) % CH]);
+            if (OP == PK_MIN) { typedef uint16_t u16x2 __attribute__((ext_vector_type(2))); x[c] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x[c]), __builtin_bit_cast(u16x2, x[(c + 1) % CH] + s))); }
+            if (OP == XAD) { uint32_t r; asm volatile("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x[c]), "s"(s), "v"(x[(c + 1) % CH])); x[c] = r; }
+            if (OP == BITOP3) x[c] = (x[c] & ~x[(c + 1) % CH]) ^ (x[(c + 2) % CH] | s);
+            if (OP == MUL_LO2) x[c] = x[c] * x[(c + 1) % CH];
+            if (OP == FMA32) { float f = __builtin_bit_cast(float, x[c]); f = __builtin_fmaf(f, 1.0001f, 0.5f); x[c] = __builtin_bit_cast(uint32_t, f); }
         }
     }
     uint32_t acc = 0;
