@@ -345,6 +345,10 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         if (c->occ_main < 1) {                                // persistent grid: every CU filled to what LDS / registers admit (asked once)
             int occ = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_classify_main, (int)WG, lds) != hipSuccess || occ < 1) occ = 1;
+            // LDS is handed out in units of LDS_GRANULE bytes (measured: a 15 568-byte workgroup is admitted 9 times per CU where the
+            // API says 10); a worker too many would run in a second round behind the others
+            const int by_lds = (int)((160u * 1024u) / ((lds + LDS_GRANULE - 1) / LDS_GRANULE * LDS_GRANULE));
+            if (by_lds >= 1 && occ > by_lds) occ = by_lds;
             c->occ_main = occ;
 #ifdef SVJG_ABLATE
             { const char *oc = getenv("SVJG_OCC"); fprintf(stderr, "[svjg diag] occupancy API: %d workgroups of %u threads per CU (LDS %zu)\n", occ, WG, lds); if (oc && atoi(oc) > 0) c->occ_main = atoi(oc); }

@@ -26,21 +26,27 @@ constexpr uint32_t TEXT = NHALF * HALF;          // 8 KB staged in LDS per strip
 // next stripe begins at the first line that did not (so no byte is classified twice except the tail of one line per stripe,
 // and a line of up to ~8 KB never needs a second launch).  Phase B turns the staged text into rank-indexed lists (positions
 // are offsets into the staged text):
-constexpr uint32_t MAXL = TEXT / 64;                 // line starts per stripe (a stripe with more goes to the exact path as a whole)
-constexpr uint32_t CAP_T = TEXT / 8;                // tab positions per stripe
-constexpr uint32_t CAP_O = TEXT / 16;               // orientation marks ('<' '>') per stripe
+// The lists are sized for ordinary line shapes (a 12-column line with a handful of tags is >= ~100 bytes); a stripe whose text
+// is denser than that is first cut down to its first half and only then sent to the exact path as a whole.
+constexpr uint32_t MAXL = 64;                       // line starts per stripe = lines of one round (one line per lane in the line phase)
+constexpr uint32_t CAP_T = 832;                     // tab positions per stripe
+constexpr uint32_t CAP_O = 256;                     // orientation marks ('<' '>') per stripe
 constexpr uint32_t KMAX = 64;                    // path nodes per alignment handled by the main kernel: one wave pass (longer paths: exact path)
-constexpr uint32_t LRW = 64;                     // lines per round: one line per lane in the line phase
+constexpr uint32_t LRW = MAXL;                   // lines per round
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
-// LDS of one worker (bytes)
+// LDS of one worker (bytes); the hardware hands LDS out in units of 1280 bytes: 12 800 bytes = twelve workers per CU
 constexpr uint32_t L_TEXT = 0;                                             // staged text + slack for the word reads behind a name / column
-constexpr uint32_t L_NDBM = L_TEXT + TEXT + 64;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab
+constexpr uint32_t L_NDBM = L_TEXT + TEXT + 64;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab (line phase only)
+constexpr uint32_t L_RL = L_NDBM;                                          // uint4[LRW] per line, written at the END of the line phase (the bitmap is dead by then):
+                                                                           //   need_l, need_r, first mark (rel.) | k << 16 | status << 24, tab behind the path
 constexpr uint32_t L_TP = L_NDBM + TEXT / 8 + 16;                          // u16[CAP_T + 16]  position of tab #t of the stripe
 constexpr uint32_t L_OPL = L_TP + (CAP_T + 16) * 2;                        // u32[CAP_O + 8]   orientation mark #o: position | line (ordinal in the stripe) << 16
 constexpr uint32_t L_LINE = L_OPL + (CAP_O + 8) * 4;                       // u16[4][MAXL + 8] line #l: start, tabs in front of it, marks in front of it, -- ; [n].start = 0xFFFF
-constexpr uint32_t L_RL = L_LINE + (MAXL + 8) * 8;                         // uint4[LRW] per line of the round: need_l, need_r, first mark (rel.) | k << 16 | status << 24, tab behind the path
-constexpr uint32_t LDS_MAIN = L_RL + LRW * 16;
+constexpr uint32_t LDS_MAIN = L_LINE + (MAXL + 8) * 8;
+constexpr uint32_t LDS_GRANULE = 1280;
+static_assert(LRW * 16 <= TEXT / 8 + 16, "the per-line records fit the bitmap they replace");
+static_assert(LDS_MAIN <= 10 * LDS_GRANULE, "twelve workers per CU");
 static_assert(L_NDBM % 16 == 0 && L_TP % 16 == 0 && L_OPL % 16 == 0 && L_LINE % 16 == 0 && L_RL % 16 == 0, "LDS alignment");
 
 // status words (device)
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     uint16_t *TP = (uint16_t *)(lds + L_TP);
     uint32_t *OPL = (uint32_t *)(lds + L_OPL);
     uint2 *LINE = (uint2 *)(lds + L_LINE);                              // .x = start | tabs in front << 16, .y = marks in front
-    uint4 *RL = (uint4 *)(lds + L_RL);
+    uint4 *RL = (uint4 *)(lds + L_RL);                                  // (the bitmap's bytes: see L_RL)
 
     const uint32_t lane = threadIdx.x;
     const GraphView g = a.g;
@@ -390,7 +396,6 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         const unsigned long long c0 = pos & ~15ull;
         const uint32_t own_lo = (uint32_t)(pos - c0);                   // lines starting in [own_lo, lim2) belong to this stripe
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (unsigned long long)TEXT) ? (a.n_bytes - c0) : (unsigned long long)TEXT);   // valid bytes staged
-        const uint32_t own_lim = rend - c0 < (unsigned long long)V ? (uint32_t)(rend - c0) : V;
         const bool at_eof = c0 + V == a.n_bytes;
 
         // ---- A: registers -> LDS; bytes >= 0x80 and the "id:f:" filter on the registers -------------------------
@@ -426,50 +431,63 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         }
         // does the stripe begin at a line start?  (wave-uniform)
         const uint32_t head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
-        // the last line start in the staged text (a terminator at b starts a line at b + 1)
-        uint32_t s_last = NONE32;
-        {
-            const unsigned long long b1 = __ballot(NL[1] != 0), b0 = __ballot(NL[0] != 0);
-            if (b1 | b0) {
-                const uint32_t hh = b1 ? 1u : 0u;
-                const uint32_t L = 63u - (uint32_t)__builtin_clzll(b1 ? b1 : b0);
-                const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hh ? NL[1] : NL[0]), (int)L);
-                const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((hh ? NL[1] : NL[0]) >> 32), (int)L);
-                const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-                s_last = (hh * WG + L) * SPAN + (63u - (uint32_t)__builtin_clzll(m)) + 1u;
-            } else if (head) s_last = 0;
-        }
-        // which lines this stripe handles, and where the next one begins
-        uint32_t lim2 = own_lim;
-        bool last_stripe = false, long_line = false;
-        unsigned long long next_pos = c0 + V;
-        if (at_eof) last_stripe = true;                                  // every line ends inside the staged text (the last one maybe without a terminator)
-        else if (s_last == NONE32 || s_last < own_lo) { }                // no line starts here: the stripe lies inside one long line
-        else if (c0 + s_last >= rend) last_stripe = true;                // the last line start is the next worker's: all of this worker's lines end in here
-        else if (s_last > own_lo) { lim2 = s_last; next_pos = c0 + s_last; }   // the line at s_last has no end in here: the next stripe begins with it
-        else long_line = true;                                           // a single line longer than the staged text: exact path
-        if (next_pos >= rend) last_stripe = true;
-        if (!last_stripe) prefetch(next_pos & ~15ull);
-
-        // counts and wave prefix sums; a terminator at sp + b starts a line at sp + b + 1, owned if that lies in [own_lo, lim2)
+        uint32_t Vh = V;                                                 // bytes of the staged text this stripe looks at: all of them, or (dense text) the first half
+        bool eof_h = at_eof;
+        uint32_t lim2, n_s, n_own, tot_tab, tot_ori, l_first;
+        bool last_stripe, long_line;
+        unsigned long long next_pos;
         unsigned long long OWN[NHALF];
         uint32_t exA[NHALF], exB[NHALF], totA[NHALF], totB[NHALF];
-        const uint32_t head_own = head & (uint32_t)(own_lo == 0 && 0 < lim2);
-        uint32_t l_first = 0;
+        uint32_t head_own;
+        for (uint32_t attempt = 0;; ++attempt) {
+            // the last line start in the text looked at (a terminator at b starts a line at b + 1)
+            uint32_t s_last = NONE32;
+            {
+                const unsigned long long b1 = __ballot(NL[1] != 0), b0 = __ballot(NL[0] != 0);
+                if (b1 | b0) {
+                    const uint32_t hh = b1 ? 1u : 0u;
+                    const uint32_t L = 63u - (uint32_t)__builtin_clzll(b1 ? b1 : b0);
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hh ? NL[1] : NL[0]), (int)L);
+                    const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((hh ? NL[1] : NL[0]) >> 32), (int)L);
+                    const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+                    s_last = (hh * WG + L) * SPAN + (63u - (uint32_t)__builtin_clzll(m)) + 1u;
+                } else if (head) s_last = 0;
+            }
+            // which lines this stripe handles, and where the next one begins
+            const uint32_t own_lim = rend - c0 < (unsigned long long)Vh ? (uint32_t)(rend - c0) : Vh;
+            lim2 = own_lim;
+            last_stripe = false; long_line = false;
+            next_pos = c0 + Vh;
+            if (eof_h) last_stripe = true;                               // every line ends inside the staged text (the last one maybe without a terminator)
+            else if (s_last == NONE32 || s_last < own_lo) { }            // no line starts here: the stripe lies inside one long line
+            else if (c0 + s_last >= rend) last_stripe = true;            // the last line start is the next worker's: all of this worker's lines end in here
+            else if (s_last > own_lo) { lim2 = s_last; next_pos = c0 + s_last; }   // the line at s_last has no end in here: the next stripe begins with it
+            else long_line = true;                                       // a single line longer than the text looked at: exact path
+            if (next_pos >= rend) last_stripe = true;
+
+            // counts and wave prefix sums; a terminator at sp + b starts a line at sp + b + 1, owned if that lies in [own_lo, lim2)
+            head_own = head & (uint32_t)(own_lo == 0 && 0 < lim2);
+            l_first = 0;
 #pragma unroll
-        for (uint32_t h = 0; h < NHALF; ++h) {
-            const uint32_t sp = (h * WG + lane) * SPAN;
-            const unsigned long long below_lo = low_bits64(clamp64(own_lo, sp + 1));
-            OWN[h] = NL[h] & low_bits64(clamp64(lim2, sp + 1)) & ~below_lo;
-            const uint32_t hd = (h == 0 && lane == 0) ? head : 0u, hdo = (h == 0 && lane == 0) ? head_own : 0u;
-            if (h == 0) l_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((head & (uint32_t)(0 < own_lo)) + (uint32_t)__popcll(NL[0] & below_lo)));   // (own_lo < 16: only lane 0 can see such starts)
-            const uint32_t cA = ((uint32_t)__popcll(NL[h]) + hd) | (((uint32_t)__popcll(OWN[h]) + hdo) << 16);
-            const uint32_t cB = (uint32_t)__popcll(TAB[h]) | ((uint32_t)__popcll(ORI[h]) << 16);
-            exA[h] = wave_excl_scan(cA, totA[h]); exB[h] = wave_excl_scan(cB, totB[h]);
+            for (uint32_t h = 0; h < NHALF; ++h) {
+                const uint32_t sp = (h * WG + lane) * SPAN;
+                const unsigned long long below_lo = low_bits64(clamp64(own_lo, sp + 1));
+                OWN[h] = NL[h] & low_bits64(clamp64(lim2, sp + 1)) & ~below_lo;
+                const uint32_t hd = (h == 0 && lane == 0) ? head : 0u, hdo = (h == 0 && lane == 0) ? head_own : 0u;
+                if (h == 0) l_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((head & (uint32_t)(0 < own_lo)) + (uint32_t)__popcll(NL[0] & below_lo)));   // (own_lo < 16: only lane 0 can see such starts)
+                const uint32_t cA = ((uint32_t)__popcll(NL[h]) + hd) | (((uint32_t)__popcll(OWN[h]) + hdo) << 16);
+                const uint32_t cB = (uint32_t)__popcll(TAB[h]) | ((uint32_t)__popcll(ORI[h]) << 16);
+                exA[h] = wave_excl_scan(cA, totA[h]); exB[h] = wave_excl_scan(cB, totB[h]);
+            }
+            const uint32_t totAs = totA[0] + totA[1], totBs = totB[0] + totB[1];
+            n_s = totAs & 0xFFFFu; n_own = totAs >> 16;                  // line starts in the text looked at, and how many of them this stripe handles
+            tot_tab = totBs & 0xFFFFu; tot_ori = totBs >> 16;
+            if (attempt || Vh <= HALF || !(n_s > MAXL || tot_tab > CAP_T || tot_ori > CAP_O)) break;
+            // the lists cannot hold the whole stripe: look at its first half only (the next stripe begins inside this one)
+            NL[1] = 0; TAB[1] = 0; ORI[1] = 0;
+            Vh = HALF; eof_h = false;
         }
-        const uint32_t totAs = totA[0] + totA[1], totBs = totB[0] + totB[1];
-        const uint32_t n_s = totAs & 0xFFFFu, n_own = totAs >> 16;       // line starts in the staged text, and how many of them this stripe handles
-        const uint32_t tot_tab = totBs & 0xFFFFu, tot_ori = totBs >> 16;
+        if (!last_stripe) prefetch(next_pos & ~15ull);
         tick(1);
 
         if (a.all_slow || idf || long_line || n_s > MAXL || tot_tab > CAP_T || tot_ori > CAP_O) {
@@ -540,8 +558,8 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t nx = l1.x & 0xFFFFu, tr = l0.x >> 16, tn = l1.x >> 16, o0 = l0.y, o1 = l1.y;
                 kall = o1 - o0; rel = o0 - obase;
                 status = ST_DEFER;
-                if (nx != 0xFFFFu || at_eof) {                           // (always: the stripe handles only lines that end in it)
-                    uint32_t e = nx != 0xFFFFu ? nx - 1 : V;
+                if (nx != 0xFFFFu || eof_h) {                            // (always: the stripe handles only lines that end in it)
+                    uint32_t e = nx != 0xFFFFu ? nx - 1 : Vh;
                     uint32_t nt = tn - tr;
                     if (e > s && py_space(text[e - 1])) {                // line.rstrip(): blanks, a CR, trailing tabs
                         do --e; while (e > s && py_space(text[e - 1]));
