@@ -115,6 +115,11 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
     return x;
 }
+// ballot without the bool -> int detour of __ballot (one v_cmp into an SGPR pair), value of a lane whose number is wave-uniform
+__device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ inline uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+// value of the lane below, lane 0 gets `first`
+__device__ inline uint32_t lane_below_or(uint32_t v, uint32_t first) { return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
 // value of the lane below / above (lane 0 / lane 63 keep their own), one DPP move instead of a trip through the LDS crossbar
 __device__ inline uint32_t lane_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
 __device__ inline uint32_t lane_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); }   // wave_shl:1
@@ -127,21 +132,19 @@ __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
 enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round
 
 // Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the 64-bit pre-hash of the node-name table
-// (svjg_line.h: name_prehash).
-// NW = words looked at: 8, or 6 when the caller knows L <= 24 (the words beyond are zero and add nothing to the hash)
-template <uint32_t NW>
-__device__ inline uint64_t name_words(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
+// (svjg_line.h: name_prehash), in two parts: words 0..5 (enough for names of up to 24 bytes; d[6] = d[7] = 0) and, for
+// longer names, words 6 and 7 and what they add to the hash.
+// words in front of word L / 4 are name bytes only, that word keeps its first L % 4 bytes, the ones behind it are zero
+__device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
     const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
     const uint32_t sh = a0 & 3u;
     uint32_t prev = w[0];
     uint64_t h = (uint64_t)L * 0x7FEB352Du;
-    const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
-#pragma unroll
-    for (uint32_t i = NW; i < 8; ++i) d[i] = 0u;
-    // words in front of word L / 4 are name bytes only, that word keeps its first L % 4 bytes, the ones behind it are zero
+    const uint32_t C[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du};
+    d[6] = 0u; d[7] = 0u;
     const uint32_t fw = L >> 2, pm = ~(0xFFFFFFFFu << ((8u * (L & 3u)) & 31u));
 #pragma unroll
-    for (uint32_t i = 0; i < NW; ++i) {
+    for (uint32_t i = 0; i < 6; ++i) {
         const uint32_t nx = w[i + 1];
         const uint32_t x = __builtin_amdgcn_alignbyte(nx, prev, sh);
         d[i] = i < fw ? x : (i == fw ? (x & pm) : 0u);
@@ -149,6 +152,16 @@ __device__ inline uint64_t name_words(const uint8_t *text, uint32_t a0, uint32_t
         h += (uint64_t)d[i] * C[i];
     }
     return h;
+}
+__device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
+    const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
+    const uint32_t sh = a0 & 3u;
+    const uint32_t w6 = w[6], w7 = w[7], w8 = w[8];
+    const uint32_t fw = L >> 2, pm = ~(0xFFFFFFFFu << ((8u * (L & 3u)) & 31u));
+    const uint32_t x6 = __builtin_amdgcn_alignbyte(w7, w6, sh), x7 = __builtin_amdgcn_alignbyte(w8, w7, sh);
+    d[6] = 6u < fw ? x6 : (6u == fw ? (x6 & pm) : 0u);
+    d[7] = 7u < fw ? x7 : (7u == fw ? (x7 & pm) : 0u);
+    return (uint64_t)d[6] * 0xFD7046C5u + (uint64_t)d[7] * 0xB55A4F09u;
 }
 
 // record of the node-name table (svjg_host_tables.h): r0 = name bytes 0..15, r1 = bytes 16..23 | meta | length in bp,
@@ -306,20 +319,21 @@ __device__ inline bool bits_clear(const uint32_t *bm, uint32_t a, uint32_t n) {
 }
 
 // "id:f:" anywhere in a line changes what the reference does with it (filter-alignments.py:193-196: float() of the tag value may
-// raise, Alen == 0 no longer does): such lines take the exact path.  The filter looks for the two bytes "d:" at every byte
-// offset of the staged text (no tag minigraph writes holds them; a hit only costs the stripe's lines the exact path):
-// (byte ^ 'd') | (next byte ^ ':') is a zero byte exactly at a match.  acc collects, in bit 7 of every byte lane, "some word had
-// a zero byte here" (v_qsad_pk_u16_u8 would test four offsets of a 4-byte pattern at once but runs at a quarter of the rate).
-template <bool ASCII>
-__device__ inline uint32_t idf_word(uint32_t w, uint32_t nx, uint32_t acc) {
-    const uint32_t c = (w ^ 0x64646464u) | (__builtin_amdgcn_alignbyte(nx, w, 1) ^ 0x3A3A3A3Au);
-    if (ASCII) return acc | ~(c + 0x7F7F7F7Fu);                          // bytes < 0x80: no carries between the byte lanes
-    return acc | zero_bytes(c);
+// raise, Alen == 0 no longer does): such lines take the exact path.  Wherever the five bytes start, one of the two-byte
+// pieces "id" (even offset) or "d:" (odd offset) sits at an EVEN offset of the text, i.e. fills one aligned half of a word.  The
+// filter therefore looks at aligned halfwords only: running 16-bit minima of word ^ "idid" and word ^ "d:d:"; a zero half
+// is a hit.  No tag minigraph writes and hardly any read name holds either piece at an even offset, and a false alarm only
+// costs the stripe's lines the exact path.  (v_qsad_pk_u16_u8, four sliding 4-byte windows per instruction, runs at a
+// quarter of the rate; a search at every byte offset needs an extra v_alignbyte per word.)
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pk_min_u16(uint32_t x, uint32_t y) {
+    const u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y));
+    return __builtin_bit_cast(uint32_t, r);
 }
-template <bool ASCII>
-__device__ inline uint32_t idf_piece(const uint4 v, uint32_t nx, uint32_t acc) {
-    acc = idf_word<ASCII>(v.x, v.y, acc); acc = idf_word<ASCII>(v.y, v.z, acc);
-    acc = idf_word<ASCII>(v.z, v.w, acc); return idf_word<ASCII>(v.w, nx, acc);
+__device__ inline void idf_piece(const uint4 v, uint32_t &acc_id, uint32_t &acc_dc) {
+    constexpr uint32_t ID = 0x64696469u, DC = 0x3A643A64u;                // "idid", "d:d:" (little endian)
+    acc_id = pk_min_u16(pk_min_u16(acc_id, v.x ^ ID), pk_min_u16(v.y ^ ID, v.z ^ ID)); acc_id = pk_min_u16(acc_id, v.w ^ ID);
+    acc_dc = pk_min_u16(pk_min_u16(acc_dc, v.x ^ DC), pk_min_u16(v.y ^ DC, v.z ^ DC)); acc_dc = pk_min_u16(acc_dc, v.w ^ DC);
 }
 
 // Static wave priorities (s_setprio): the byte classification of phases A / B1 is dense VALU work, the line and node phases
@@ -407,17 +421,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             *(uint4 *)(text + (i * WG + lane) * 16) = pf[i];
         }
         const uint32_t head_byte = pf_head;
-        const bool ascii = __ballot((hi_bits & 0x80808080u) != 0) == 0;   // wave-uniform: the cheaper SWAR classes apply
+        const bool ascii = ballot64((hi_bits & 0x80808080u) != 0) == 0;   // wave-uniform: the cheaper SWAR classes apply
         if (!ascii && lane == 0) a.st->non_ascii = 1;
-        uint32_t idf_acc = 0;
+        uint32_t idf_id = 0xFFFFFFFFu, idf_dc = 0xFFFFFFFFu;
 #pragma unroll
-        for (uint32_t i = 0; i < NPF; ++i) {
-            // first word of the following piece: the next lane's, for lane 63 lane 0's of the next register (behind the staged text: nothing)
-            const uint32_t wrap = i + 1 < NPF ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pf[i + 1 < NPF ? i + 1 : i].x) : 0u;
-            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)wrap, (int)pf[i].x, 0x130, 0xF, 0xF, false);   // wave_shl:1
-            idf_acc = ascii ? idf_piece<true>(pf[i], nx, idf_acc) : idf_piece<false>(pf[i], nx, idf_acc);
-        }
-        const bool idf = __ballot((idf_acc & 0x80808080u) != 0) != 0;
+        for (uint32_t i = 0; i < NPF; ++i) idf_piece(pf[i], idf_id, idf_dc);
+        // a 16-bit half of a running minimum is zero <=> some aligned halfword matched
+        const bool idf = ballot64(((((idf_id - 0x00010001u) & ~idf_id) | ((idf_dc - 0x00010001u) & ~idf_dc)) & 0x80008000u) != 0) != 0;
         wave_sync();
         __builtin_amdgcn_s_setprio(0);
         tick(0);
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             // the last line start in the text looked at (a terminator at b starts a line at b + 1)
             uint32_t s_last = NONE32;
             {
-                const unsigned long long b1 = __ballot(NL[1] != 0), b0 = __ballot(NL[0] != 0);
+                const unsigned long long b1 = ballot64(NL[1] != 0), b0 = ballot64(NL[0] != 0);
                 if (b1 | b0) {
                     const uint32_t hh = b1 ? 1u : 0u;
                     const uint32_t L = 63u - (uint32_t)__builtin_clzll(b1 ? b1 : b0);
@@ -602,45 +612,33 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             if (DIAG(2u)) continue;                                      // measurement only: stop after R1
             // ---- node passes: up to 64 consecutive marks that cover whole lines; one mark (path node) per lane ----------------
             for (uint32_t i0 = 0; i0 < cnt;) {
-                const uint32_t p0 = (uint32_t)__shfl((int)rel, (int)i0);
-                const unsigned long long nofit = __ballot(lane >= i0 && lane < cnt && rel + kall - p0 > 64u);
+                const uint32_t p0 = rdlane(rel, i0);
+                const unsigned long long nofit = ballot64(lane >= i0 && lane < cnt && rel + kall - p0 > 64u);
                 uint32_t i1 = nofit ? (uint32_t)__builtin_ctzll(nofit) : cnt;
                 if (i1 == i0) { ++i0; continue; }                        // a line with more than 64 marks (> KMAX): already deferred
-                const uint32_t n_pass = (uint32_t)__shfl((int)(rel + kall), (int)i1 - 1) - p0;
-                const unsigned long long okl = __ballot(lane >= i0 && lane < i1 && status == ST_OK);
+                const uint32_t n_pass = rdlane(rel + kall, i1 - 1) - p0;
+                const unsigned long long okl = ballot64(lane >= i0 && lane < i1 && status == ST_OK);
                 i0 = i1;
                 if (!okl) continue;                                      // no line of the pass has a path to look at
                 __builtin_amdgcn_s_setprio(P_LOAD);
-                // -- the node of this lane: line, index in the line, name --
+                // -- the node of this lane: line, index in the line, name.  Every lane runs the same straight code on indices that
+                //    are safe to read (a lane beyond the pass looks at the pass's first mark); `live` says whose results count --
                 const bool act = lane < n_pass;
-                const uint32_t o = obase + p0 + lane;
-                uint32_t ln = 0, lnb = 0, lk = 0, j = 0, len = 0, oribit = 0, meta = 0, need_l = 0, need_r = 0, na0 = 0, d[8];
-                uint64_t h = 0;
-                bool live = false, probe = false;
-                if (act) {
-                    const uint32_t opl = OPL[o], opn = OPL[o + 1] & 0xFFFFu;
-                    const uint32_t opv = opl & 0xFFFFu;
-                    ln = (opl >> 16) - lbase;
-                    const uint4 rl = RL[ln];
-                    meta = rl.z;
-                    const uint32_t pend = rl.w;
-                    need_l = rl.x; need_r = rl.y;
-                    live = (meta >> 24) == ST_OK;
-                    lnb = (meta & 0xFFFFu) - p0; lk = (meta >> 16) & 0xFFu; j = lane - lnb;
-                    if (live) {
-                        const uint32_t a0 = opv + 1u;
-                        const uint32_t b0 = (j + 1 < lk) ? opn : pend;
-                        oribit = text[a0 - 1] == '<' ? 1u : 0u;
-                        len = b0 - a0;
-                        probe = len - 1u <= 31u;                         // names of 1..32 bytes; longer ones: exact path
-                        na0 = a0;
-                    }
-                }
-                // (wave-uniform choice: node names of the usual length fit six words)
-                if (__ballot(probe && len > 24u)) { if (probe) h = name_words<8>(text, na0, len, d); }
-                else if (probe) h = name_words<6>(text, na0, len, d);
-                if (!live) { j = 0; lk = 0; lnb = 0; }
-                const unsigned long long lmask = (lk >= 64u ? ~0ull : ((1ull << lk) - 1ull)) << (lnb & 63u);   // the lanes of this node's line
+                const uint32_t o = obase + p0 + (act ? lane : 0u);
+                const uint2 op2 = *(const uint2 *)(OPL + o);             // (8-byte aligned or not: two dwords)
+                const uint32_t opv = op2.x & 0xFFFFu;
+                const uint32_t ln = ((op2.x >> 16) - lbase) & (LRW - 1u);
+                const uint4 rl = RL[ln];
+                const uint32_t meta = rl.z, need_l = rl.x, need_r = rl.y;
+                bool live = act && (meta >> 24) == ST_OK;
+                uint32_t lnb = live ? (meta & 0xFFFFu) - p0 : 0u, lk = live ? (meta >> 16) & 0xFFu : 0u, j = live ? lane - lnb : 0u;
+                const uint32_t na0 = opv + 1u;
+                const uint32_t len = ((j + 1 < lk) ? (op2.y & 0xFFFFu) : rl.w) - na0;
+                const uint32_t oribit = text[opv] == '<' ? 1u : 0u;
+                const bool probe = live && len - 1u <= 31u;              // names of 1..32 bytes; longer ones: exact path
+                uint32_t d[8];
+                uint64_t h = name_words_head(text, na0, len, d);         // the first six words of the name
+                if (ballot64(probe && len > 24u)) h += name_words_tail(text, na0, len, d);   // (wave-uniform: node names of the usual length fit six words)
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
@@ -656,51 +654,48 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // id << 7 | flags << 5 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
                 if (probe && name_match(r0, r1, r2, d, len) && r1.z != 0xFFFFFFFFu && !(r1.z & 0x60u)) { id = r1.z >> 7; lbp = r1.w & 0x7FFFFFFFu; row_inline = (r1.w >> 31) != 0; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
-                // path (all nodes of a line sit in this pass: a ballot tells every lane of the line)
+                // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
+                // (all nodes of a line sit in this pass).  Ordinary text never gets here.
                 {
-                    const unsigned long long badm = __ballot(live && (id == NONE32 || lbp >= (1u << 25)));
-                    if (live && (badm & lmask)) {
-                        if (j == 0) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
-                        live = false;
+                    const bool bad = live && (id == NONE32 || lbp >= (1u << 25));
+                    if (ballot64(bad)) {
+                        if (bad) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
+                        wave_sync();
+                        if ((((const uint32_t *)&RL[ln])[2] >> 24) != ST_OK) live = false;
                     }
                 }
-                if (!live) { j = 0; lk = 0; id = NONE32; lbp = 0; }
+                if (!live) { j = 0; lk = 0; lnb = 0; id = NONE32; lbp = 0; }
                 tick(4);
                 // -- running path length of the line (inclusive) = wave prefix sum minus what precedes the line's first node --
                 const uint32_t gsum = wave_incl_scan(lbp);               // every lbp < 2^25: no overflow over 64 lanes
                 const uint32_t gfirst = (uint32_t)__shfl((int)(gsum - lbp), (int)lnb);
                 const uint32_t glast = (uint32_t)__shfl((int)gsum, (int)(lane + (lk ? lk - 1 - j : 0u)));
                 const uint32_t pre = gsum - gfirst, tot = glast - gfirst;
-                // -- first occurrence of every name in its line (the reference's list.index / str.split quirks).  Ids grow along
-                //    a forward path and fall along a reverse one: such lines cannot revisit a node and need no search --
+                // -- first occurrence of every name in its line (the reference's list.index / str.split quirks): every lane looks at
+                //    the lanes below it, one DPP wave shift per distance (no LDS round trips), as far as the longest line of the pass
+                //    reaches.  key = id | line << 26: lanes of other lines never compare equal --
                 uint32_t f = lane;
-                bool revisits = false;                                   // wave-uniform: some line of the pass had to be searched
                 {
-                    const uint32_t prev = lane_below(id);
-                    const unsigned long long up = __ballot(live && (j == 0 || id > prev)), dn = __ballot(live && (j == 0 || id < prev));
-                    const bool search = live && (up & lmask) != lmask && (dn & lmask) != lmask;
-                    revisits = __ballot(search) != 0;
-                    for (uint32_t dd = 1; __ballot(search && j >= dd); dd += 4) {       // four distances per trip: one wait for four shuffles
-                        const uint32_t y0 = (uint32_t)__shfl_up((int)id, dd), y1 = (uint32_t)__shfl_up((int)id, dd + 1);
-                        const uint32_t y2 = (uint32_t)__shfl_up((int)id, dd + 2), y3 = (uint32_t)__shfl_up((int)id, dd + 3);
-                        if (search && j >= dd && y0 == id) f = lane - dd;
-                        if (search && j >= dd + 1 && y1 == id) f = lane - dd - 1;
-                        if (search && j >= dd + 2 && y2 == id) f = lane - dd - 2;
-                        if (search && j >= dd + 3 && y3 == id) f = lane - dd - 3;
+                    const uint32_t key = live ? (id | (ln << 26)) : NONE32;
+                    uint32_t y = key;
+                    for (uint32_t dd = 1; ballot64(j >= dd); dd += 4) {
+                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd;
+                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 1u;
+                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 2u;
+                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 3u;
                     }
                 }
+                const bool revisits = ballot64(live && f != lane) != 0;  // wave-uniform: some line of the pass comes back to a node
                 tick(5);
                 // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
-                //    (str.split / list.index, filter-alignments.py:206, :269-271) --
-                uint32_t fl = lane, fr = lane + 1u, pre_l = pre, pre_rx = pre, idl = id, orl = oribit, idr, orr;
-                if (!revisits) {                                         // every node is its own first occurrence: the right node is the next lane
-                    const uint32_t nx = lane_above((id << 1) | oribit);
-                    idr = nx >> 1; orr = nx & 1u;
-                } else {
-                    fl = f; fr = (uint32_t)__shfl_down((int)f, 1);
+                //    (str.split / list.index, filter-alignments.py:206, :269-271); equal names have equal ids and hashes --
+                const uint32_t nxv = lane_above((id << 1) | oribit);
+                const uint32_t idl = id, idr = nxv >> 1;
+                uint32_t fl = lane, fr = lane + 1u, pre_l = pre, pre_rx = pre, orl = oribit, orr = nxv & 1u;
+                if (revisits) {
+                    fl = f; fr = lane_above(f);
                     pre_l = (uint32_t)__shfl((int)pre, (int)fl);
                     pre_rx = (uint32_t)__shfl((int)pre, (int)((fr - 1u) & 63u));
-                    idl = (uint32_t)__shfl((int)id, (int)fl); idr = (uint32_t)__shfl((int)id, (int)(fr & 63u));
                     orl = (uint32_t)__shfl((int)oribit, (int)fl); orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
                 }
                 bool go = false;
@@ -730,8 +725,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         }
                     }
                 }
-                if (__ballot(ask)) {
-                    const uint64_t hl = __shfl((unsigned long long)h, (int)fl), hr = __shfl((unsigned long long)h, (int)(fr & 63u));
+                if (ballot64(ask)) {
+                    const uint64_t hl = h;                               // (the first occurrence spells the same name)
+                    const uint64_t hr = ((uint64_t)lane_above((uint32_t)(h >> 32)) << 32) | lane_above((uint32_t)h);
                     if (ask) {
                         uint32_t sa, sb2;
                         link_slots(link_prehash(hl, orl, hr, orr), g.link_seed, g.link_mask, sa, sb2);
@@ -771,7 +767,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
                 const bool defer = lane < cnt && (RL[lane].z >> 24) == ST_DEFER;
-                unsigned long long db = __ballot(defer);
+                unsigned long long db = ballot64(defer);
                 if (db) {
                     unsigned long long dbase = 0;
                     if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)__popcll(db));

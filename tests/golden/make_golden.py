@@ -5,7 +5,9 @@ Runs only in the build container (needs /root/reference).  Nothing of the refere
 copied: the fixtures are inputs + the reference's outputs (and two of its own test *data* files,
 test.vcf / expected_genotype.vcf).  The GPU box never runs this script.
 
-    python tests/golden/make_golden.py            # regenerate everything
+    python tests/golden/make_golden.py            # regenerate the small groups below
+    python tests/golden/make_golden.py full       # BASELINE configs at full size (c2: minutes, c3: half an hour and 27 GB, c4slice: minutes)
+    python tests/golden/make_golden.py full:c4slice
 
 Fixture groups:
   testdir/   G1  graph of the reference's test-dir (edges JSON + GFA with ref sequences elided)
@@ -17,6 +19,10 @@ Fixture groups:
   vcf/       G5  VCF-parsing cases through the reference's decision_vcf()
   synth/     G6  medium synthetic case from tools/svjg_synth (inputs regenerated from the seed):
                  sha256 of the reference JSON/VCF + the full count vector
+  realshape/ G7  lines shaped like real minigraph output (read names, cg:Z: / ds:Z: tags, paths of up to 300 nodes,
+                 UCSC contig names) on a 600-SV graph, with the reference's JSON and VCF
+             full  c2_full.json / c3_full.json / c4slice_full.json: sha256 of the reference's JSON and VCF for the
+                 BASELINE configurations at full size, with its run time (make_full)
 """
 import hashlib
 import importlib.util
@@ -558,7 +564,208 @@ def make_synth():
     print("synth:", {k: v["ref_seconds"] for k, v in res.items()})
 
 
+# ----------------------------------------------------------------------------------------------
+# G7 lines shaped like real `minigraph -x lr` output (stand-in for BASELINE configs[4], which needs minigraph and HG002 reads)
+# ----------------------------------------------------------------------------------------------
+
+def make_realshape():
+    """~180 GAF lines on a 600-SV graph with UCSC-style contig names: PacBio / ONT read names, the tags minigraph writes
+    (tp cm s1 s2 dv, and cg:Z: / ds:Z: strings of kilobytes as with -c / --ds), paths of 2..300 nodes in both directions,
+    long reads threading dozens of SV sites, a GraphAligner-style id:f: tag.  Inputs + the reference's JSON are committed."""
+    out = f"{HERE}/realshape"
+    os.makedirs(out, exist_ok=True)
+    sys.path.insert(0, f"{ROOT}/tools")
+    import synth
+    tmp = tempfile.mkdtemp()
+    inf = synth.generate(f"{tmp}/r", 160, 600, 3, "mixed", 20260515 + 7, return_gaf=True)
+    ren = {"chr2": "chrUn_KI270742v1", "chr3": "chr22_KI270879v1_alt"}
+
+    def rename(t):
+        for a, b in ren.items():
+            t = t.replace(a + ":", b + ":").replace(a + "\t", b + "\t").replace("#" + a, "#" + b).replace("\t" + a + "\t", "\t" + b + "\t")
+        return t
+    for ext in (".gfa", "_svs_edges.json", ".vcf"):
+        with open(f"{tmp}/r{ext}") as fi, open(f"{out}/r{ext}", "w") as fo:
+            fo.write(rename(fi.read()))
+    rng = np.random.default_rng(7)
+
+    def read_name(i):
+        k = i % 4
+        if k == 0:
+            return "m64011_190830_220126/%d/ccs" % int(rng.integers(1, 180000000))
+        if k == 1:
+            h = "".join("0123456789abcdef"[int(x)] for x in rng.integers(0, 16, 32))
+            return f"{h[:8]}-{h[8:12]}-{h[12:16]}-{h[16:20]}-{h[20:]}"
+        if k == 2:
+            return "SRR%d.%d" % (int(rng.integers(9000000, 9999999)), int(rng.integers(1, 4000000)))
+        return "HG002_ONT_UL_%06d_ch%d_read%d" % (i, int(rng.integers(1, 512)), int(rng.integers(1, 90000)))
+
+    def cigar(n):
+        parts, left = [], n
+        while left > 0:
+            m = int(min(left, rng.integers(20, 900)))
+            parts.append(f"{m}M")
+            left -= m
+            if left > 0 and rng.random() < 0.8:
+                parts.append(f"{int(rng.integers(1, 12))}{'ID'[int(rng.integers(0, 2))]}")
+        return "".join(parts)
+
+    def ds(n):
+        parts, left = [], n
+        while left > 0:
+            m = int(min(left, rng.integers(30, 1200)))
+            parts.append(f":{m}")
+            left -= m
+            if left > 0:
+                parts.append("*" + "acgt"[int(rng.integers(0, 4))] + "acgt"[int(rng.integers(0, 4))] if rng.random() < 0.5
+                             else "+-"[int(rng.integers(0, 2))] + "".join("acgt"[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 30)))))
+        return "".join(parts)
+
+    lines = []
+    for i, ln in enumerate(rename(inf["gaf"].tobytes().decode()).splitlines()):
+        c = ln.split("\t")
+        c[0] = read_name(i)
+        alen = int(c[10])
+        tags = c[12:]
+        if i % 3 == 0:
+            tags.append("cg:Z:" + cigar(alen))
+        if i % 5 == 0:
+            tags.append("ds:Z:" + ds(alen))
+        if i % 41 == 0:
+            tags.insert(2, "id:f:0.9871")                               # GraphAligner writes it; float() accepts it
+        lines.append("\t".join(c[:12] + tags) + "\n")
+    # long reads: many consecutive reference nodes, forward and reverse (13..300 nodes; more than 64 nodes: the exact path)
+    names = {}
+    for ln in open(f"{out}/r.gfa"):
+        if ln.startswith("S"):
+            nm = ln.split("\t")[1]
+            if "." not in nm.split(":")[-1]:
+                names.setdefault(nm.rsplit(":", 1)[0], []).append(nm)
+    for chrom in names:
+        names[chrom].sort(key=lambda n: int(n.rsplit(":", 1)[1].split("-")[0]))
+
+    def nlen(n):
+        a, b = n.rsplit(":", 1)[1].split("-")
+        return int(b) - int(a) + 1
+    for q, (chrom, start, k) in enumerate((("chr1", 3, 13), ("chr1", 20, 33), ("chrUn_KI270742v1", 5, 64), ("chr22_KI270879v1_alt", 9, 65),
+                                           ("chr1", 40, 80), ("chrUn_KI270742v1", 2, 128), ("chr22_KI270879v1_alt", 1, 160), ("chr1", 0, 300))):
+        path = names[chrom][start:start + k]
+        assert len(path) == k, (chrom, len(names[chrom]))
+        tlen = sum(nlen(n) for n in path)
+        for rev in (False, True):
+            p = "".join(("<" if rev else ">") + n for n in (reversed(path) if rev else path))
+            ts, te = int(rng.integers(0, 300)), tlen - int(rng.integers(0, 300))
+            al = te - ts
+            tags = ["tp:A:P", f"cm:i:{al // 14}", f"s1:i:{al * 3 // 4}", "s2:i:0", "dv:f:0.0031"]
+            if q % 2 == 0:
+                tags.append("cg:Z:" + cigar(al))
+            lines.append("\t".join([read_name(1000 + 2 * q + rev), str(al + 40), "17", str(al + 17), "+", p, str(tlen), str(ts), str(te),
+                                     str(al - al // 300), str(al), "60"] + tags) + "\n")
+    with open(f"{out}/r.gaf", "w") as fh:
+        fh.write("".join(lines))
+    rc, err = run_ref_filter(f"{out}/r.gaf", f"{out}/r.gfa", f"{out}/r")
+    assert rc == 0, err
+    rc, so = run_ref_genotype(f"{out}/r_informative_aln.json", f"{out}/r.vcf", f"{out}/r.ref_genotype.vcf", ms=1)
+    assert rc == 0
+    D = json.load(open(f"{out}/r_informative_aln.json"))
+    import gzip                                                         # (a long line sits in the lists of every SV it crosses: 8 MB of very repetitive text)
+    with open(f"{out}/r_informative_aln.json", "rb") as fi, open(f"{out}/r.ref.json.gz", "wb") as fo:
+        with gzip.GzipFile(fileobj=fo, mode="wb", mtime=0, compresslevel=9) as gz:
+            shutil.copyfileobj(fi, gz)
+    os.remove(f"{out}/r_informative_aln.json")
+    shutil.rmtree(tmp)
+    print(f"realshape: {len(lines)} lines, {max(len(l) for l in lines)} bytes the longest, {len(D)} informative SVs, {so.strip()}")
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE configs at full size: the reference itself on the generated files (minutes to half an hour of one core each)
+# ----------------------------------------------------------------------------------------------
+
+def _sha_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for b in iter(lambda: fh.read(1 << 24), b""):
+            h.update(b)
+    return h.hexdigest()
+
+
+def _timed(cmd):
+    """-> (returncode, stdout, seconds, peak RSS in MB of the child)"""
+    import resource
+    import time
+    before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    t = time.time()
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    dt = time.time() - t
+    after = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    return p.returncode, p.stdout, dt, max(before, after) // 1024
+
+
+def _full_case(cfg, n_aln=None, vcf_rows=None, scratch=None):
+    """tools/synth.py configuration `cfg` (optionally only its first n_aln alignments, and only the first vcf_rows data rows of its
+    VCF for the genotyper, whose key test is quadratic) through the reference's two scripts."""
+    sys.path.insert(0, f"{ROOT}/tools")
+    import synth
+    base = scratch or ("/dev/shm" if os.path.isdir("/dev/shm") else None)
+    tmp = tempfile.mkdtemp(prefix=f"svjg_golden_{cfg}_", dir=base)
+    pre = f"{tmp}/{cfg}"
+    try:
+        n, n_sv, n_chrom, mix, seed = synth.CONFIGS[cfg]
+        n = n_aln or n
+        synth.generate(pre, n, n_sv, n_chrom, mix, seed)
+        rc_f, _, t_f, rss_f = _timed([sys.executable, f"{REF}/filter-alignments.py", "-a", pre + ".gaf", "-g", pre + ".gfa", "-p", pre])
+        assert rc_f == 0
+        vcf = pre + ".vcf"
+        if vcf_rows:
+            vcf = pre + "_head.vcf"
+            k = 0
+            with open(pre + ".vcf") as fi, open(vcf, "w") as fo:
+                for ln in fi:
+                    if not ln.startswith("#"):
+                        k += 1
+                        if k > vcf_rows:
+                            break
+                    fo.write(ln)
+        rc_g, so, t_g, rss_g = _timed([sys.executable, f"{REF}/predict-genotype.py", "-d", pre + "_informative_aln.json", "-v", vcf,
+                                       "-o", pre + "_genotype.vcf"])
+        assert rc_g == 0
+        res = {
+            "config": f"tools/synth.py {cfg}: {n} alignments x {n_sv} SVs ({mix}, {n_chrom} chromosomes, seed {seed})"
+                      + (f"; genotyper on the first {vcf_rows} VCF rows" if vcf_rows else ""),
+            "n_aln": n, "vcf_rows": vcf_rows,
+            "filter_s": round(t_f, 1), "filter_rc": rc_f, "genotype_s": round(t_g, 1), "genotype_rc": rc_g, "genotype_stdout": so,
+            "sha256_json": _sha_file(pre + "_informative_aln.json"), "json_bytes": os.path.getsize(pre + "_informative_aln.json"),
+            "sha256_vcf": _sha_file(pre + "_genotype.vcf"),
+            "max_rss_mb_children": max(rss_f, rss_g),
+            "host": "build container, 1 core of an Intel Xeon @ 2.1 GHz, Python 3.10.12",
+            "alignments_per_s": int(n / t_f),
+            "how": "python3 /root/reference/filter-alignments.py / predict-genotype.py on the generated files "
+                   "(tests/golden/make_golden.py full: the reference is only ever run in the build container)",
+        }
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def make_full(which=("c2", "c3", "c4slice")):
+    """synth/c2_full.json, c3_full.json (BASELINE configs[1], configs[2] whole) and c4slice_full.json (the configs[3] graph —
+    500 k SVs on 24 chromosomes — with the first million alignments; the genotyper on the first 5 000 VCF rows)."""
+    out = f"{HERE}/synth"
+    os.makedirs(out, exist_ok=True)
+    for w in which:
+        if w == "c4slice":
+            res = _full_case("c4", n_aln=1_000_000, vcf_rows=5000)
+        else:
+            res = _full_case(w)
+        with open(f"{out}/{w}_full.json", "w") as fh:
+            json.dump(res, fh, indent=1)
+        print(w, {k: res[k] for k in ("filter_s", "genotype_s", "sha256_json", "sha256_vcf")})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["testdir", "quirks", "lik", "vcf", "synth"]
     for w in which:
-        globals()["make_" + w]()
+        if w.startswith("full"):                   # full | full:c2,c3,c4slice
+            make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))
+        else:
+            globals()["make_" + w]()

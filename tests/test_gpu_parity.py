@@ -51,6 +51,50 @@ def test_quirks(ctx, golden, name, all_slow, tmp_path):
         assert type(ei.value).__name__ == man["error"]
 
 
+@pytest.mark.parametrize("all_slow", [False, True])
+def test_realshape_lines(ctx, golden, all_slow, tmp_path):
+    """Lines shaped like real `minigraph -x lr` output (golden/realshape: PacBio / ONT read names, cg:Z: and ds:Z: strings of
+    kilobytes, paths of up to 300 nodes in both directions, UCSC contig names up to 36 bytes, an id:f: tag), main kernel and
+    exact path: counts, _informative_aln.json and the genotyped VCF are the reference's."""
+    import gzip
+    from svjg import capi, filter as flt, genotype
+    from svjg.graph import Graph
+    r = f"{golden}/realshape"
+    g = Graph.from_files(f"{r}/r_svs_edges.json", f"{r}/r.gfa", all_slow=all_slow)
+    counts, recs, data = flt.classify_file(ctx, g, f"{r}/r.gaf")
+    ref_text = gzip.open(f"{r}/r.ref.json.gz", "rt").read()
+    ref = json.loads(ref_text)
+    assert _counts_dict(g, counts) == {k: [len(v[0]), len(v[1])] for k, v in ref.items()}
+    capi.write_informative_json(str(tmp_path / "o.json"), data, recs, g.sv_ids)
+    assert open(tmp_path / "o.json").read() == ref_text
+    n = genotype.genotype_with_counts(ctx, f"{r}/r.vcf", g.slot_of, str(tmp_path / "o.vcf"), min_support=1)
+    assert open(tmp_path / "o.vcf").read() == open(f"{r}/r.ref_genotype.vcf").read() and n > 400
+    if not all_slow:
+        st = ctx.stats()
+        n_lines = sum(1 for _ in open(f"{r}/r.gaf"))
+        # exact path: paths of more than 64 nodes, node names beyond 32 bytes, and every line of a stripe that holds an id:f: tag
+        assert st["n_lines"] == n_lines and 0 < st["n_deferred"] < 0.7 * n_lines
+
+
+def test_two_gpus_one_rccl_allreduce(tmp_path):
+    """The drop-in filter on two GPUs of one process: byte ranges per GPU, the per-SV count vectors summed by the library's RCCL
+    all-reduce (svjg_comm_init_all / svjg_allreduce_counts_all).  Skipped on a one-GPU box."""
+    import synth
+    from svjg import capi, filter as flt
+    from svjg.graph import Graph
+    if capi.load_library().svjg_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    pre = str(tmp_path / "m")
+    synth.generate(pre, 300000, 3000, 4, "mixed", 77)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    c1, r1, _ = flt.classify_sharded(g, pre + ".gaf", devices=[0])
+    c2, r2, _ = flt.classify_sharded(g, pre + ".gaf", devices=[0, 1])
+    assert np.array_equal(c1, c2) and c1.sum() > 0 and len(r1) == len(r2)
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    want, _, _ = orc.filter(np.fromfile(pre + ".gaf", dtype=np.uint8), want_hits=False)
+    assert _counts_dict(g, c2) == _oracle_dict(orc, want)
+
+
 def test_testdir_files(ctx, golden, tmp_path):
     """BASELINE configs[0] plumbing: the reference's own test graph, a GAF whose counts reproduce the 40
     expected rows, through the drop-in filter + genotyper: both output files byte-identical."""
@@ -522,5 +566,69 @@ def test_full_size_files_equal_the_reference(tmp_path, cfg):
         n = genotype.run(pre + "_informative_aln.json", pre + ".vcf", pre + "_genotype.vcf")
         assert f"Genotyped svs: {n}\n" == want["genotype_stdout"]
         assert sha(pre + "_genotype.vcf") == want["sha256_vcf"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def test_c4_graph_two_million_alignments(tmp_path):
+    """BASELINE configs[3]'s graph (500 k mixed SVs on 24 chromosomes: 990 k nodes, 525 k count slots, the 134 MB link table)
+    with the first two million alignments of its stream.  Counts equal the C oracle's over the whole vector with no line on
+    the exact path, the genotyped VCF equals the Python oracle's on all 500 k rows, and — the reference itself having run on
+    the first million alignments in the build container (golden/synth/c4slice_full.json) — _informative_aln.json and the VCF
+    of the first 5 000 rows have the reference's sha256."""
+    import shutil
+    import tempfile
+    import synth
+    from svjg import capi, filter as flt, genotype
+    from svjg.graph import Graph
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    if shutil.disk_usage(base).free < (8 << 30):
+        pytest.skip("not enough scratch space")
+    work = tempfile.mkdtemp(prefix="svjg_c4_", dir=base)
+    pre = os.path.join(work, "c4")
+    try:
+        n_aln, n_sv, n_chrom, mix, seed = synth.CONFIGS["c4"]
+        synth.generate(pre, 2_000_000, n_sv, n_chrom, mix, seed)
+        g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+        assert g.n_nodes > 900_000 and g.n_slots > 500_000
+        orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+        gaf = np.fromfile(pre + ".gaf", dtype=np.uint8)
+        want, _, n_lines = orc.filter(gaf, want_hits=False)
+        c = capi.Context(0)
+        try:
+            c.load_graph(g)
+            c.classify(gaf)
+            st = c.stats()
+            assert st["n_lines"] == n_lines == 2_000_000 and st["n_deferred"] == 0
+            got = c.counts()
+            assert _counts_dict(g, got) == _oracle_dict(orc, want) and int(want.sum()) > 5_000_000
+            n = genotype.genotype_with_counts(c, pre + ".vcf", g.slot_of, pre + "_all.vcf")
+        finally:
+            c.close()
+        D = {sv: [["x"] * int(want[i, 0]), ["y"] * int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
+        text, n_ref = O.genotype_vcf(open(pre + ".vcf").readlines(), D)
+        assert n == n_ref and open(pre + "_all.vcf").read() == text
+        # the reference's own output for the first million alignments (the stream is a function of seed and line number)
+        gold = os.path.join(os.path.dirname(__file__), "golden", "synth", "c4slice_full.json")
+        if os.path.exists(gold):
+            ref = json.load(open(gold))
+            nl = np.flatnonzero(gaf == 10)
+            gaf[: int(nl[ref["n_aln"] - 1]) + 1].tofile(pre + "_1m.gaf")
+            for ext in (".gfa", "_svs_edges.json"):
+                os.symlink(pre + ext, pre + "_1m" + ext)
+            flt.run(pre + "_1m.gaf", pre + "_1m.gfa", pre + "_1m")
+            assert os.path.getsize(pre + "_1m_informative_aln.json") == ref["json_bytes"]
+            assert hashlib.sha256(open(pre + "_1m_informative_aln.json", "rb").read()).hexdigest() == ref["sha256_json"]
+            k = 0
+            with open(pre + ".vcf") as fi, open(pre + "_head.vcf", "w") as fo:
+                for ln in fi:
+                    if not ln.startswith("#"):
+                        k += 1
+                        if k > ref["vcf_rows"]:
+                            break
+                    fo.write(ln)
+            n = genotype.run(pre + "_1m_informative_aln.json", pre + "_head.vcf", pre + "_head_genotype.vcf")
+            assert f"Genotyped svs: {n}\n" == ref["genotype_stdout"]
+            assert hashlib.sha256(open(pre + "_head_genotype.vcf", "rb").read()).hexdigest() == ref["sha256_vcf"]
     finally:
         shutil.rmtree(work, ignore_errors=True)

@@ -37,6 +37,17 @@ def test_quirks(golden, name, tables, wave):
         assert type(ei.value).__name__ == man["error"]
 
 
+@pytest.mark.parametrize("tables,wave", [(True, 0), (True, 2)], ids=["name_table", "wave_two_phase"])
+def test_realshape_lines(golden, tables, wave):
+    """the exact per-line routine on the lines shaped like real minigraph output (paths of up to 300 nodes, kilobyte tags)"""
+    import gzip
+    r = f"{golden}/realshape"
+    g = Graph.from_files(f"{r}/r_svs_edges.json", f"{r}/r.gfa")
+    counts, n_lines = sim.classify(g, open(f"{r}/r.gaf", "rb").read(), tables, wave)
+    ref = json.loads(gzip.open(f"{r}/r.ref.json.gz", "rt").read())
+    assert _as_dict(g, counts) == {k: [len(v[0]), len(v[1])] for k, v in ref.items()}
+
+
 def test_testdir(golden):
     t = f"{golden}/testdir"
     g = Graph.from_files(f"{t}/test_svs_edges.json", f"{t}/test.gfa")

@@ -136,3 +136,24 @@ def test_c_synth_g6(golden, tag, tmp_path):
     assert hashlib.sha256(text.encode()).hexdigest() == g6["sha256_vcf"]
     assert text == open(f"{golden}/synth/{tag}.ref_genotype.vcf").read()
     assert f"Genotyped svs: {n}\n" == g6["stdout"]
+
+
+def test_realshape_lines(golden):
+    """golden/realshape (lines shaped like real minigraph output, make_golden.py realshape): both oracles reproduce the
+    reference's JSON / counts and its genotyped VCF."""
+    import gzip
+    from oracle import oracle_c as OC
+    r = f"{golden}/realshape"
+    edges = O.load_edges(f"{r}/r_svs_edges.json")
+    alt = O.load_alt_node_len(f"{r}/r.gfa")
+    ref_text = gzip.open(f"{r}/r.ref.json.gz", "rt").read()
+    D = O.classify(_read_lines(f"{r}/r.gaf"), edges, alt)
+    assert O.dump_informative(D) == ref_text
+    text, n = O.genotype_vcf(_read_lines(f"{r}/r.vcf"), D, 1)
+    assert text == open(f"{r}/r.ref_genotype.vcf").read() and n > 400
+    orc = OC.COracle(edges, alt)
+    counts, _, n_lines = orc.filter(open(f"{r}/r.gaf", "rb").read(), want_hits=False)
+    ref = json.loads(ref_text)
+    assert {sv: [int(counts[i, 0]), int(counts[i, 1])] for i, sv in enumerate(orc.sv_ids) if counts[i].sum()} == \
+        {k: [len(v[0]), len(v[1])] for k, v in ref.items()}
+    assert n_lines == len(_read_lines(f"{r}/r.gaf"))
