@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--aln", type=int, default=0, help="override alignments per rank")
     ap.add_argument("--svs", type=int, default=0, help="override the number of SVs (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the untimed end-to-end block (files -> JSON -> VCF through the drop-in scripts)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,6 +82,7 @@ def main():
     graph = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
     rows = genotype.VcfRows(pre + ".vcf", graph.slot_of)
     t_setup = time.time() - t0
+    cpu = cpu_rates(pre, gaf) if (not args.no_cpu_baseline and world == 1) else None   # (forks workers: before the GPU is touched)
 
     ctx = capi.Context(local_rank)
     ctx.load_graph(graph)
@@ -150,34 +152,107 @@ def main():
             "setup_s": {"generate_and_tables": round(t_setup, 1), "h2d_upload": round(t_h2d, 3),
                         "pcie_inclusive_alignments_per_s": n_aln / (t_h2d + ms_per_step * 1e-3)},
         }
-        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (profiles/<round>/traffic.json)
+        # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (profiles/<round>/traffic.json,
+        # the newest round that has one)
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json"))).get(args.workload)
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "traffic.json")))
+            tr_path = cands[-1]
+            tr = json.load(open(tr_path)).get(args.workload)
             if tr and tr["text_bytes"] == int(gaf.size) and world == 1:
+                rel = os.path.relpath(tr_path, ROOT)
                 res["roofline"]["traffic"] = tr["traffic_bytes"]
-                res["roofline"]["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
+                res["roofline"]["traffic_source"] = f"{rel} (rocprofv3 FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
                 if tr.get("valu_wave_instructions"):
-                    # what actually bounds the kernel: VALU issue (from the committed SQ_INSTS_VALU pass, 4 cycles per wave
-                    # instruction on 1024 SIMDs at 2.4 GHz), reported beside the HBM roofline the contract asks for
-                    issue_ms = tr["valu_wave_instructions"] * 4 / 1024 / 2.4e9 * 1e3
-                    res["roofline"]["valu_issue"] = {"wave_instructions_per_launch": tr["valu_wave_instructions"], "issue_ms": round(issue_ms, 3),
-                                                     "frac_of_launch": round(issue_ms / k_main, 3)}
-        except (OSError, ValueError, KeyError):
+                    # what actually bounds the kernel: VALU issue (from the committed SQ_INSTS_VALU pass; a wave instruction holds
+                    # its SIMD for 4 cycles, 1024 SIMDs), reported beside the HBM roofline the contract asks for
+                    clk = tr.get("clock_ghz", 2.4)
+                    issue_ms = tr["valu_wave_instructions"] * 4 / 1024 / (clk * 1e9) * 1e3
+                    res["roofline"]["valu_issue"] = {"wave_instructions_per_launch": tr["valu_wave_instructions"], "clock_ghz": clk,
+                                                     "issue_ms": round(issue_ms, 3), "frac_of_launch": round(issue_ms / k_main, 3)}
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         if not args.no_cpu_baseline and world == 1:            # reported on rank 0 at N = 1 only
-            res["cpu_baseline"] = cpu_baseline(pre, gaf, graph, counts, rows)
+            res["cpu_baseline"] = cpu_baseline(pre, graph, counts, cpu)
+        if not args.no_e2e and world == 1 and args.workload in ("c2", "c3") and not args.aln and not args.svs:
+            ctx.close()                                          # (the scripts open the GPU themselves)
+            ctx = None
+            res["e2e"] = end_to_end(args.workload, pre, gaf)
         print(json.dumps(res))
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(pre, gaf, graph, gpu_counts, rows):
-    """The CPU oracle (C restatement of the reference's per-line algorithm, 1 thread — the reference itself is
-    single-threaded Python) on a bounded sample of the same GAF, and a parity spot check of the GPU counts."""
+def end_to_end(workload, pre, gaf):
+    """Untimed for `value`: the same workload through the two drop-in scripts, files on a memory-backed file system:
+    GAF file -> filter-alignments.py -> _informative_aln.json -> predict-genotype.py -> _genotype.vcf, wall time per stage,
+    and whether both files have the sha256 of what the reference itself wrote (tests/golden/synth/<workload>_full.json)."""
+    import hashlib
+    import shutil
+    import subprocess
+    gold = os.path.join(ROOT, "tests", "golden", "synth", f"{workload}_full.json")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    try:
+        want = json.load(open(gold))
+        if base is None or shutil.disk_usage(base).free < want["json_bytes"] + 2 * int(gaf.size) + (1 << 30):
+            return {"skipped": "no memory-backed scratch space for the files"}
+        work = tempfile.mkdtemp(prefix="svjg_e2e_", dir=base)
+    except (OSError, ValueError, KeyError) as e:
+        return {"skipped": str(e)}
+    try:
+        p = os.path.join(work, "w")
+        for ext in (".gfa", "_svs_edges.json", ".vcf"):
+            shutil.copy(pre + ext, p + ext)
+        gaf.tofile(p + ".gaf")
+        amd = os.path.join(ROOT, "svjedi-graph_amd")
+
+        def sha(path):
+            h = hashlib.sha256()
+            with open(path, "rb") as fh:
+                for b in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(b)
+            return h.hexdigest()
+        t0 = time.perf_counter()
+        r1 = subprocess.run([sys.executable, os.path.join(amd, "filter-alignments.py"), "-a", p + ".gaf", "-g", p + ".gfa", "-p", p],
+                            capture_output=True, text=True)
+        t1 = time.perf_counter()
+        r2 = subprocess.run([sys.executable, os.path.join(amd, "predict-genotype.py"), "-d", p + "_informative_aln.json", "-v", p + ".vcf",
+                             "--minsupport", "3", "-o", p + "_genotype.vcf"], capture_output=True, text=True)
+        t2 = time.perf_counter()
+        if r1.returncode or r2.returncode:
+            return {"failed": (r1.stderr or r2.stderr)[-300:]}
+        ok_json = os.path.getsize(p + "_informative_aln.json") == want["json_bytes"] and sha(p + "_informative_aln.json") == want["sha256_json"]
+        ok_vcf = sha(p + "_genotype.vcf") == want["sha256_vcf"] and r2.stdout == want["genotype_stdout"]
+        return {"what": "GAF file -> filter-alignments.py -> predict-genotype.py (drop-in scripts, files on tmpfs; includes process start, "
+                        "HIP initialisation, graph tables, upload, JSON and VCF writing)",
+                "filter_s": round(t1 - t0, 2), "genotype_s": round(t2 - t1, 2), "total_s": round(t2 - t0, 2),
+                "gaf_bytes": int(gaf.size), "json_bytes": os.path.getsize(p + "_informative_aln.json"),
+                "sha_ok": bool(ok_json and ok_vcf), "sha_json_ok": bool(ok_json), "sha_vcf_ok": bool(ok_vcf),
+                "reference_s": {"filter": want.get("filter_s"), "genotype": want.get("genotype_s"), "where": want.get("host")}}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+_FORK_STATE = {}                    # what forked oracle workers inherit (the oracle's tables and the text)
+
+
+def _oracle_shard(rng):
+    lo, hi = rng
+    want, _, n = _FORK_STATE["orc"].filter(_FORK_STATE["gaf"][lo:hi], want_hits=False)
+    return n
+
+
+def cpu_rates(pre, gaf):
+    """The CPU side of cpu_baseline, run BEFORE this process touches the GPU (the all-cores leg forks workers): the C oracle
+    (restatement of the reference's per-line algorithm) on one core — the reference itself is single-threaded Python — and on
+    all the cores this process may use, and the pure-Python restatement, each on a bounded sample of the same GAF.
+    -> (dict for the JSON line, the oracle, the sample and its counts for the parity spot check)"""
     from oracle import oracle_c, oracle_py
-    orc = oracle_c.COracle(oracle_py.load_edges(pre + "_svs_edges.json"), oracle_py.load_alt_node_len(pre + ".gfa"))
+    edges, alt = oracle_py.load_edges(pre + "_svs_edges.json"), oracle_py.load_alt_node_len(pre + ".gfa")
+    orc = oracle_c.COracle(edges, alt)
     n_lines = 2_000_000
     nl = np.flatnonzero(gaf[: min(gaf.size, 700 * n_lines)] == 10)
     n_lines = min(n_lines, nl.size)
@@ -188,8 +263,44 @@ def cpu_baseline(pre, gaf, graph, gpu_counts, rows):
     base = {"value": got_lines / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
             "sample": f"first {got_lines} alignments of the same GAF ({sample.size} bytes), oracle/svjg_oracle.c, {dt:.1f} s; "
                       f"host has {os.cpu_count()} cores"}
-    # parity spot check: classify the same sample on the GPU path and compare the whole count vector
+    try:
+        import multiprocessing as mp
+        cores = min(len(os.sched_getaffinity(0)), 16)            # (a one-GPU share of the host: 16 cores)
+        nl_all = np.flatnonzero(gaf == 10)
+        per = min(n_lines, max(1, nl_all.size // cores))
+        cuts = [0] + [int(nl_all[min(nl_all.size, per * (i + 1)) - 1]) + 1 for i in range(cores)]
+        _FORK_STATE.update(orc=orc, gaf=gaf)
+        with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(_oracle_shard, [(0, 0)] * cores)               # (workers up before the clock starts)
+            t = time.perf_counter()
+            done = sum(pool.map(_oracle_shard, [(cuts[i], cuts[i + 1]) for i in range(cores)], chunksize=1))
+            dt = time.perf_counter() - t
+        base["all_cores"] = {"value": done / dt, "unit": "alignments/s", "cores": cores,
+                             "sample": f"{done} alignments of the same GAF in {cores} forked workers (one contiguous share each), {dt:.1f} s"}
+    except (OSError, ValueError, AttributeError) as e:
+        base["all_cores"] = {"skipped": str(e)}
+    try:
+        sl = bytes(gaf[: int(nl[min(100_000, n_lines) - 1]) + 1]).decode("utf-8").splitlines(True)
+        t = time.perf_counter()
+        oracle_py.classify(sl, edges, alt)
+        dt = time.perf_counter() - t
+        base["python_restatement"] = {"value": len(sl) / dt, "unit": "alignments/s", "cores": 1,
+                                      "sample": f"first {len(sl)} alignments, oracle/oracle_py.py, {dt:.1f} s"}
+    except (OSError, ValueError) as e:
+        base["python_restatement"] = {"skipped": str(e)}
+    try:                                                         # the reference itself cannot travel; its rate was measured in the build container
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "synth", "c2_full.json")))
+        base["reference_python"] = {"alignments_per_s": ref["alignments_per_s"], "where": ref["host"], "config": ref["config"]}
+    except (OSError, ValueError, KeyError):
+        pass
+    return base, orc, sample, want
+
+
+def cpu_baseline(pre, graph, gpu_counts, cpu):
+    """cpu_rates' figures plus a parity spot check of the GPU path on the same sample and the genotype leg."""
+    from oracle import oracle_py
     from svjg import capi
+    base, orc, sample, want = cpu
     c2 = capi.Context(int(os.environ.get("LOCAL_RANK", "0")))
     c2.load_graph(graph)
     c2.classify(sample)
@@ -198,11 +309,6 @@ def cpu_baseline(pre, gaf, graph, gpu_counts, rows):
     exp = {sv: (int(want[i, 0]), int(want[i, 1])) for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
     got = {graph.sv_ids[i]: (int(g[i, 0]), int(g[i, 1])) for i in range(graph.n_slots) if g[i].sum()}
     base["parity_on_sample"] = "bit-exact" if exp == got else "MISMATCH"
-    try:                                                         # the reference itself cannot travel; its rate was measured in the build container
-        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "synth", "c2_full.json")))
-        base["reference_python"] = {"alignments_per_s": ref["alignments_per_s"], "where": ref["host"], "config": ref["config"]}
-    except (OSError, ValueError, KeyError):
-        pass
     # genotype leg: pure-Python restatement on a sample of rows
     D = {graph.sv_ids[i]: [["x"] * int(gpu_counts[i, 0]), ["y"] * int(gpu_counts[i, 1])]
          for i in range(graph.n_slots) if gpu_counts[i].sum()}

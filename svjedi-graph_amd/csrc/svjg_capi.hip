@@ -28,7 +28,7 @@ struct svjg_ctx {
     int device = 0;
     int n_cu = 256;
     int occ_main = 0;                    // workgroups of k_classify_main one CU holds
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
     hipEvent_t ev[6] = {};
     std::string err;
     // graph
@@ -137,6 +137,7 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     for (auto &ev : c->stage_ev) if (ev) hipEventDestroy(ev);
     for (auto &st : c->stage_stream) if (st) hipStreamDestroy(st);
     for (auto &ev : c->ev) if (ev) hipEventDestroy(ev);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -231,7 +232,7 @@ static int gaf_reserve(svjg_ctx *c, uint64_t n, uint64_t *need_out) {
 }
 
 // bytes [offset, offset + n) of the open file -> d_gaf through the pinned staging buffers
-static int staged_upload(svjg_ctx *c, int fd, uint64_t offset, uint64_t n) {
+static int staged_upload(svjg_ctx *c, int fd, uint64_t offset, uint64_t n, uint64_t dst_off = 0) {
     for (int i = 0; i < STAGE_THREADS * 2; ++i) {
         if (!c->h_stage[i]) HIPCHK(c, hipHostMalloc((void **)&c->h_stage[i], STAGE_PIECE, hipHostMallocDefault));
         if (!c->stage_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
@@ -255,7 +256,7 @@ static int staged_upload(svjg_ctx *c, int fd, uint64_t offset, uint64_t n) {
                 if (r <= 0) return fail(SVJG_E_IO, r == 0 ? "the GAF file is shorter than announced" : std::string("pread: ") + strerror(errno));
                 got += (uint64_t)r;
             }
-            if (hipMemcpyAsync(c->d_gaf + a, c->h_stage[b], len, hipMemcpyHostToDevice, c->stage_stream[t]) != hipSuccess ||
+            if (hipMemcpyAsync(c->d_gaf + dst_off + a, c->h_stage[b], len, hipMemcpyHostToDevice, c->stage_stream[t]) != hipSuccess ||
                 hipEventRecord(c->stage_ev[b], c->stage_stream[t]) != hipSuccess) return fail(SVJG_E_HIP, "hipMemcpyAsync (ingest)");
             used[k & 1] = true;
         }
@@ -317,11 +318,11 @@ static int ensure(svjg_ctx *c, void **p, uint64_t *cap, uint64_t want, size_t el
     return 0;
 }
 
-extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int want_hits) {
-    if (!c || !c->have_graph || !c->have_gaf) { if (c) c->err = "classify needs a graph and an uploaded GAF"; return SVJG_E_ARG; }
+// the lines of the resident text that lie in [begin, end): begin is a line start, end the byte behind a terminator (or the text's end)
+static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t base_offset, int want_hits) {
     HIPCHK(c, hipSetDevice(c->device));
-    const uint64_t n = c->gaf_bytes;
-    if (n == 0) return 0;
+    if (end <= begin) return 0;
+    const uint64_t n = end - begin;
     const bool all_slow = (c->gflags & SVJG_GRAPH_ALL_SLOW) != 0;
     uint64_t def_want = all_slow ? n / 24 + 64 : (n / 4096 + 65536);
     uint64_t rec_want = want_hits ? c->hs().n_recs + n / 64 + 65536 : 0;
@@ -334,7 +335,7 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
         DevStatus before = c->hs();
         if ((rc = reset_status(c, false))) return rc;
         ClassifyArgs a{};
-        a.gaf = c->d_gaf; a.n_bytes = n; a.base_offset = base_offset; a.g = c->gv;
+        a.gaf = c->d_gaf; a.begin = begin; a.n_bytes = end; a.base_offset = base_offset; a.g = c->gv;
         a.all_slow = all_slow; a.want_hits = want_hits != 0;
 #ifdef SVJG_ABLATE
         { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob (measurement builds only)
@@ -412,16 +413,115 @@ extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int wan
     return 0;
 }
 
-extern "C" int svjg_classify(svjg_ctx *c, const char *gaf, uint64_t n, uint64_t base_offset, int want_hits) {
-    int rc = svjg_gaf_upload(c, gaf, n);
+extern "C" int svjg_classify_resident(svjg_ctx *c, uint64_t base_offset, int want_hits) {
+    if (!c || !c->have_graph || !c->have_gaf) { if (c) c->err = "classify needs a graph and an uploaded GAF"; return SVJG_E_ARG; }
+    return classify_range(c, 0, c->gaf_bytes, base_offset, want_hits);
+}
+
+// Upload and classify overlapped: the text goes to HBM in pieces of PIPE_BYTES cut behind line terminators; while the kernels
+// work on piece k (this thread, the context's stream), a helper thread copies piece k + 1 (its own streams).  Every piece gets
+// PIPE_GAP zero bytes behind it in the device buffer (the kernels read past the end of their text without bounds tests), so
+// piece k sits at device offset cut[k] + k * PIPE_GAP and offsets are reported through a per-piece base.
+// `fetch(dst_off, src_off, len)` moves bytes [src_off, src_off + len) of the source to d_gaf + dst_off and returns when
+// they are there; `last_cut(lo, hi)` = offset behind the last terminator in [lo, hi) of the source, or lo if there is none.
+constexpr uint64_t PIPE_BYTES = 128ull << 20;
+constexpr uint64_t PIPE_GAP = ((uint64_t)TEXT + 64 + 15) & ~15ull;
+template <class Fetch, class Cut>
+static int classify_pipelined(svjg_ctx *c, uint64_t n, uint64_t base_offset, int want_hits, Fetch fetch, Cut last_cut) {
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> cuts{0};
+    while (cuts.back() < n) {
+        const uint64_t lo = cuts.back(), hi = lo + PIPE_BYTES < n ? lo + PIPE_BYTES : n;
+        uint64_t cut = hi == n ? n : last_cut(lo, hi);
+        if (cut <= lo) cut = hi == n ? n : last_cut(lo, n);               // a line longer than a piece: up to the next terminator behind it
+        if (cut <= lo) cut = n;
+        cuts.push_back(cut);
+    }
+    const size_t n_pieces = cuts.size() - 1;
+    auto dev_off = [&](size_t k) { return ((cuts[k] + 15) & ~15ull) + k * PIPE_GAP; };   // 16-byte aligned, >= PIPE_GAP - 15 zero bytes in front
+    uint64_t need;
+    int rc = gaf_reserve(c, dev_off(n_pieces - 1) + (cuts[n_pieces] - cuts[n_pieces - 1]), &need);
     if (rc) return rc;
-    return svjg_classify_resident(c, base_offset, want_hits);
+    c->have_gaf = false;
+    for (size_t k = 0; k < n_pieces; ++k) {                                // zero padding behind every piece
+        const uint64_t e = dev_off(k) + (cuts[k + 1] - cuts[k]);
+        const uint64_t upto = k + 1 < n_pieces ? dev_off(k + 1) : need;
+        HIPCHK(c, hipMemsetAsync(c->d_gaf + e, 0, upto - e, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = fetch(dev_off(0), 0, cuts[1]))) return rc;
+    for (size_t k = 0; k < n_pieces; ++k) {
+        int rc_up = 0;
+        std::thread up;
+        if (k + 1 < n_pieces) up = std::thread([&, k] { rc_up = fetch(dev_off(k + 1), cuts[k + 1], cuts[k + 2] - cuts[k + 1]); });
+        // (reported offsets = base + device offset: the base of a piece takes its place in the buffer out again; unsigned wrap-around is fine)
+        rc = classify_range(c, dev_off(k), dev_off(k) + (cuts[k + 1] - cuts[k]), base_offset + cuts[k] - dev_off(k), want_hits);
+        if (up.joinable()) up.join();
+        if (rc) return rc;
+        if (rc_up) return rc_up;
+    }
+    // (the buffer now holds the pieces with gaps: not a resident text for svjg_classify_resident)
+    c->gaf_bytes = 0;
+    return 0;
+}
+
+extern "C" int svjg_classify(svjg_ctx *c, const char *gaf, uint64_t n, uint64_t base_offset, int want_hits) {
+    if (!c || (n && !gaf)) return SVJG_E_ARG;
+    if (!c->have_graph) { c->err = "classify needs a graph"; return SVJG_E_ARG; }
+    if (n == 0) return svjg_gaf_upload(c, gaf, 0);
+    std::string uerr;
+    auto fetch = [&](uint64_t dst, uint64_t src, uint64_t len) -> int {
+        if (hipSetDevice(c->device) != hipSuccess) { uerr = "hipSetDevice (upload thread)"; return SVJG_E_HIP; }
+        if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { uerr = "hipStreamCreate (upload)"; return SVJG_E_HIP; }
+        if (hipMemcpyAsync(c->d_gaf + dst, gaf + src, len, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+            hipStreamSynchronize(c->copy_stream) != hipSuccess) { uerr = "hipMemcpyAsync (upload)"; return SVJG_E_HIP; }
+        return 0;
+    };
+    auto last_cut = [&](uint64_t lo, uint64_t hi) -> uint64_t {
+        if (hi == n) {                                                     // forward: the first terminator at or behind lo
+            for (uint64_t p = lo; p < n; ++p) if (gaf[p] == '\n') return p + 1;
+            return lo;
+        }
+        const void *q = memrchr(gaf + lo, '\n', hi - lo);
+        return q ? (uint64_t)((const char *)q - gaf) + 1 : lo;
+    };
+    const int rc = classify_pipelined(c, n, base_offset, want_hits, fetch, last_cut);
+    if (rc && !uerr.empty()) c->err = uerr;
+    return rc;
 }
 
 extern "C" int svjg_classify_file(svjg_ctx *c, const char *path, uint64_t offset, uint64_t n, int want_hits) {
-    int rc = svjg_gaf_upload_file(c, path, offset, n);
-    if (rc) return rc;
-    return svjg_classify_resident(c, offset, want_hits);
+    if (!c || !path) return SVJG_E_ARG;
+    if (!c->have_graph) { c->err = "classify needs a graph"; return SVJG_E_ARG; }
+    if (n == 0) return svjg_gaf_upload(c, nullptr, 0);
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { c->err = std::string("open ") + path + ": " + strerror(errno); return SVJG_E_IO; }
+    auto fetch = [&](uint64_t dst, uint64_t src, uint64_t len) -> int { return staged_upload(c, fd, offset + src, len, dst); };
+    auto last_cut = [&](uint64_t lo, uint64_t hi) -> uint64_t {
+        std::vector<char> buf(1 << 20);
+        if (hi == n && lo) {                                               // forward: the first terminator at or behind lo
+            for (uint64_t p = lo; p < n;) {
+                const ssize_t r = pread(fd, buf.data(), buf.size(), (off_t)(offset + p));
+                if (r <= 0) break;
+                const void *q = memchr(buf.data(), '\n', (size_t)r);
+                if (q) return p + (uint64_t)((const char *)q - buf.data()) + 1;
+                p += (uint64_t)r;
+            }
+            return lo;
+        }
+        for (uint64_t e = hi; e > lo;) {                                   // backward from hi
+            const uint64_t b = e - lo > buf.size() ? e - buf.size() : lo;
+            const ssize_t r = pread(fd, buf.data(), e - b, (off_t)(offset + b));
+            if (r != (ssize_t)(e - b)) break;
+            const void *q = memrchr(buf.data(), '\n', (size_t)r);
+            if (q) return b + (uint64_t)((const char *)q - buf.data()) + 1;
+            e = b;
+        }
+        return lo;
+    };
+    const int rc = classify_pipelined(c, n, offset, want_hits, fetch, last_cut);
+    close(fd);
+    return rc;
 }
 
 extern "C" int svjg_get_stats(svjg_ctx *c, svjg_stats *out) {

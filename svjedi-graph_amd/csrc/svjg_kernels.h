@@ -61,7 +61,8 @@ struct DevStatus {
 
 struct ClassifyArgs {
     const uint8_t *gaf;                  // resident text, allocation padded with >= TEXT + 64 zero bytes
-    uint64_t n_bytes;
+    uint64_t begin;                      // first byte to classify (a line start); what lies in front of it belongs to another launch
+    uint64_t n_bytes;                    // end of the text to classify; >= TEXT + 64 zero bytes follow it in the buffer
     uint64_t base_offset;
     GraphView g;                         // global-memory views
     uint32_t all_slow;
@@ -357,7 +358,7 @@ constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST =
 #define DIAG(bit) false
 #endif
 #ifndef SVJG_MINW
-#define SVJG_MINW 2
+#define SVJG_MINW 3          /* three waves per SIMD = the twelve workers per CU the LDS admits: at most 168 VGPRs */
 #endif
 __device__ inline unsigned long long low_bits64(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
 __device__ inline uint32_t clamp64(uint32_t hi, uint32_t lo) { return hi > lo ? (hi - lo < 64u ? hi - lo : 64u) : 0u; }   // min(max(hi - lo, 0), 64)
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     const uint32_t lane = threadIdx.x;
     const GraphView g = a.g;
 
-    unsigned long long pos = (unsigned long long)blockIdx.x * a.region;   // first byte not worked off yet (wave-uniform)
+    unsigned long long pos = a.begin + (unsigned long long)blockIdx.x * a.region;   // first byte not worked off yet (wave-uniform)
     if (pos >= a.n_bytes) return;
     const unsigned long long rend = pos + a.region < a.n_bytes ? pos + a.region : a.n_bytes;   // lines starting before it are this worker's
 
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(src + i * WG));
             pf[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
-        pf_head = c0 ? a.gaf[c0 - 1] : (uint32_t)'\n';
+        pf_head = c0 > a.begin ? a.gaf[c0 - 1] : (uint32_t)'\n';     // (the text begins at a line start whatever lies in front of it)
     };
     prefetch(pos & ~15ull);
 

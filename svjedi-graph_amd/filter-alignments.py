@@ -2,7 +2,8 @@
 """Drop-in for SVJedi-graph's filter-alignments.py (same flags, same files) running on an MI355X.
 
     filter-alignments.py -a P.gaf -g P.gfa -p P        (svjedi-graph.py:114)
-reads  P_svs_edges.json, writes P_informative_aln.json.  Any input the reference would die on makes this
+reads  P_svs_edges.json, writes P_informative_aln.json.  `-a -` reads the GAF from standard input and classifies it while it
+arrives (minigraph ... | filter-alignments.py -a - ...).  Any input the reference would die on makes this
 script exit with code 1 as well (uncaught exception), which is what svjedi-graph.py:117 tests for.
 """
 import argparse

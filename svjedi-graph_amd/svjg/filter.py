@@ -285,12 +285,69 @@ def read_handoff(json_path):
         return None
 
 
+STREAM_BLOCK = 8 << 20          # bytes asked of a stream at once
+STREAM_CHUNK = int(os.environ.get("SVJG_STREAM_CHUNK", 64 << 20))   # whole lines are classified as soon as this much new text has arrived
+
+
+def classify_stream(graph, stream, want_hits=True, device=0, _t=None):
+    """-a - : the GAF comes through a pipe (`minigraph ... | filter-alignments.py -a - ...`, svjedi-graph.py:100-105 appends
+    minigraph's output to a file first).  Whole lines are classified while the producer is still writing: every
+    STREAM_CHUNK bytes the text up to the last line terminator goes through the GPU; the bytes are kept (the JSON holds the
+    line texts) and returned like classify_sharded's mapped file.  -> (counts, hit records, the stream's bytes)"""
+    t = _t or [time.perf_counter()]
+    buf = bytearray()
+    done = 0                                         # bytes of buf already classified (a line boundary)
+    ctx = capi.Context(device)
+    try:
+        ctx.load_graph(graph)
+
+        def flush(upto):
+            nonlocal done
+            if upto > done:
+                view = np.frombuffer(buf, dtype=np.uint8, count=upto - done, offset=done)
+                try:
+                    ctx.classify(view, base_offset=done, want_hits=want_hits)
+                finally:
+                    del view                       # (a bytearray with a live export cannot grow)
+                done = upto
+        try:
+            while True:
+                b = stream.read(STREAM_BLOCK)
+                if not b:
+                    break
+                buf += b
+                if len(buf) - done >= STREAM_CHUNK:
+                    cut = buf.rfind(b"\n", done) + 1          # (a lone \r ends a line too, but never needs to end a chunk)
+                    flush(cut)
+            flush(len(buf))
+        except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+            # the reference would have met this line only after reading everything in front of it; read on so that a
+            # non-UTF-8 byte before it still wins (reference_error), then report
+            for b in iter(lambda: stream.read(STREAM_BLOCK), b""):
+                buf += b
+            raise reference_error(np.frombuffer(bytes(buf), dtype=np.uint8), e)
+        data = np.frombuffer(buf, dtype=np.uint8)
+        _stamp(t, "stream -> device, classified while it arrived")
+        if ctx.stats()["non_ascii"]:
+            check_utf8(data)
+        capi.allreduce_counts_all([ctx])          # one GPU: the overflow guard
+        return ctx.counts(), (ctx.hits() if want_hits else None), data
+    finally:
+        ctx.close()
+
+
 def run(gaf_path, gfa_path, prefix, output_dir=None, device=None):
     """filter-alignments.py main()."""
     out_json, edges_json = output_names(prefix, output_dir)
     t = [time.perf_counter()]
     graph = Graph.from_files(edges_json, gfa_path)
     _stamp(t, "edges JSON + GFA -> graph")
+    if gaf_path == "-":
+        counts, recs, data = classify_stream(graph, sys.stdin.buffer, want_hits=True, device=device or 0, _t=t)
+        capi.write_informative_json(out_json, data, recs, graph.sv_ids)
+        _stamp(t, "write _informative_aln.json")
+        write_handoff(out_json, graph.sv_ids, counts)
+        return counts, graph
     counts, recs, data = classify_sharded(graph, gaf_path, want_hits=True, devices=None if device is None else [device], _t=t)
     capi.write_informative_json(out_json, data, recs, graph.sv_ids)
     _stamp(t, "write _informative_aln.json")

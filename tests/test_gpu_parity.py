@@ -632,3 +632,39 @@ def test_c4_graph_two_million_alignments(tmp_path):
             assert hashlib.sha256(open(pre + "_head_genotype.vcf", "rb").read()).hexdigest() == ref["sha256_vcf"]
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def test_gaf_through_a_pipe(tmp_path):
+    """`filter-alignments.py -a -`: BASELINE configs[1]'s GAF (1 M alignments, 190 MB) written into the script's standard input in
+    64 KB pieces; whole lines are classified while the rest is still arriving.  The JSON has the sha256 of the file the reference
+    wrote from the same alignments (golden/synth/c2_full.json)."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    import synth
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "synth", "c2_full.json")))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    if shutil.disk_usage(base).free < 3 * want["json_bytes"]:
+        pytest.skip("not enough scratch space for the JSON")
+    work = tempfile.mkdtemp(prefix="svjg_pipe_", dir=base)
+    pre = os.path.join(work, "c2")
+    try:
+        n_aln, n_sv, n_chrom, mix, seed = synth.CONFIGS["c2"]
+        inf = synth.generate(pre, n_aln, n_sv, n_chrom, mix, seed, write_gaf=False, return_gaf=True)
+        raw = inf["gaf"].tobytes()
+        amd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svjedi-graph_amd")
+        env = dict(os.environ, SVJG_STREAM_CHUNK=str(16 << 20))
+        p = subprocess.Popen([sys.executable, f"{amd}/filter-alignments.py", "-a", "-", "-g", pre + ".gfa", "-p", pre], stdin=subprocess.PIPE, env=env)
+        for a in range(0, len(raw), 65536):
+            p.stdin.write(raw[a:a + 65536])
+        p.stdin.close()
+        assert p.wait() == 0
+        assert os.path.getsize(pre + "_informative_aln.json") == want["json_bytes"]
+        h = hashlib.sha256()
+        with open(pre + "_informative_aln.json", "rb") as fh:
+            for b in iter(lambda: fh.read(1 << 24), b""):
+                h.update(b)
+        assert h.hexdigest() == want["sha256_json"]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
