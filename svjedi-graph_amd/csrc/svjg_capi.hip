@@ -162,6 +162,7 @@ static int reset_status(svjg_ctx *c, bool all) {
 extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     if (!c || !g || !g->nodes || !g->chrom_off || !g->chrom_node_lo) return SVJG_E_ARG;
     if (g->n_nodes >= 0x7FFFFFFFull || g->n_edges >= 0x7FFFFFFFull || g->n_chrom >= 65535) { c->err = "graph too large"; return SVJG_E_ARG; }
+    if (g->d_over >= 0x80000000u) { c->err = "d_over too large"; return SVJG_E_ARG; }   // (the overlap sums of the main kernel are 32 bits wide)
     HIPCHK(c, hipSetDevice(c->device));
     free_graph(c);
     int rc;

@@ -136,6 +136,11 @@ enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per
 // (svjg_line.h: name_prehash), in two parts: words 0..5 (enough for names of up to 24 bytes; d[6] = d[7] = 0) and, for
 // longer names, words 6 and 7 and what they add to the hash.
 // words in front of word L / 4 are name bytes only, that word keeps its first L % 4 bytes, the ones behind it are zero
+// the low min(max(bits, 0), 32) bits set (bits = name bits left from this word on): high half of 0x00000000FFFFFFFF << that
+__device__ inline uint32_t name_word_mask(int32_t bits) {
+    const uint32_t n = (uint32_t)(bits < 0 ? 0 : bits > 32 ? 32 : bits);       // (one v_med3_i32)
+    return (uint32_t)((0xFFFFFFFFull << n) >> 32);
+}
 __device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
     const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
     const uint32_t sh = a0 & 3u;
@@ -143,12 +148,12 @@ __device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uin
     uint64_t h = (uint64_t)L * 0x7FEB352Du;
     const uint32_t C[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du};
     d[6] = 0u; d[7] = 0u;
-    const uint32_t fw = L >> 2, pm = ~(0xFFFFFFFFu << ((8u * (L & 3u)) & 31u));
+    const int32_t bits = (int32_t)(8u * L);
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
         const uint32_t nx = w[i + 1];
         const uint32_t x = __builtin_amdgcn_alignbyte(nx, prev, sh);
-        d[i] = i < fw ? x : (i == fw ? (x & pm) : 0u);
+        d[i] = x & name_word_mask(bits - 32 * (int32_t)i);
         prev = nx;
         h += (uint64_t)d[i] * C[i];
     }
@@ -158,10 +163,10 @@ __device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uin
     const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
     const uint32_t sh = a0 & 3u;
     const uint32_t w6 = w[6], w7 = w[7], w8 = w[8];
-    const uint32_t fw = L >> 2, pm = ~(0xFFFFFFFFu << ((8u * (L & 3u)) & 31u));
+    const int32_t bits = (int32_t)(8u * L);
     const uint32_t x6 = __builtin_amdgcn_alignbyte(w7, w6, sh), x7 = __builtin_amdgcn_alignbyte(w8, w7, sh);
-    d[6] = 6u < fw ? x6 : (6u == fw ? (x6 & pm) : 0u);
-    d[7] = 7u < fw ? x7 : (7u == fw ? (x7 & pm) : 0u);
+    d[6] = x6 & name_word_mask(bits - 192);
+    d[7] = x7 & name_word_mask(bits - 224);
     return (uint64_t)d[6] * 0xFD7046C5u + (uint64_t)d[7] * 0xB55A4F09u;
 }
 
@@ -308,6 +313,16 @@ __device__ inline uint32_t field_val(const uint8_t *text, uint32_t a, uint32_t n
     return r;
 }
 
+// the same column is zero (every digit a '0')
+__device__ inline bool field_is_zero(const uint8_t *text, uint32_t a, uint32_t n) {
+    const uint32_t *w = (const uint32_t *)(text + (a & ~3u));
+    const uint32_t sh = a & 3u, d0 = w[0], d1 = w[1], d2 = w[2];
+    const uint32_t lo0 = __builtin_amdgcn_alignbyte(d1, d0, sh) & 0x0F0F0F0Fu, hi0 = __builtin_amdgcn_alignbyte(d2, d1, sh) & 0x0F0F0F0Fu;
+    const uint32_t n8 = n < 8 ? n : 8;
+    const unsigned long long x = (((unsigned long long)hi0 << 32) | lo0) << ((8 * (8 - n8)) & 63u);
+    return x == 0 && (n < 9 || ((uint32_t)text[a + 8] & 0xFu) == 0);
+}
+
 // no bit set in bits [a, a + n) of a bitmap, n <= 64 (three words are read: the bitmap is padded)
 __device__ inline bool bits_clear(const uint32_t *bm, uint32_t a, uint32_t n) {
     const uint32_t *w = bm + (a >> 5);
@@ -347,7 +362,7 @@ __device__ inline void idf_piece(const uint4 v, uint32_t &acc_id, uint32_t &acc_
 #define SVJG_P_REST 2        /* rest of the node pass */
 #endif
 #ifndef SVJG_P_A
-#define SVJG_P_A 1          /* registers -> LDS */
+#define SVJG_P_A 2          /* registers -> LDS (waits for the prefetch: high, so that the next dense phase starts early; measured) */
 #endif
 constexpr int P_A = SVJG_P_A;
 constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST = SVJG_P_REST;
@@ -524,6 +539,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             continue;
         }
 
+        if (DIAG(32u)) { wave_lines += n_own; if (last_stripe) break; pos = next_pos; continue; }   // measurement only: stop after B1
         __builtin_amdgcn_s_setprio(P_B2);
         // ---- B2: rank-indexed lists ----------------------------------------------------------------------
         if (lane == 0) {
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             j = tb;
             for (unsigned long long m = TAB[h]; m; m &= m - 1, ++j) TP[j] = (uint16_t)(sp + (uint32_t)__builtin_ctzll(m));
             j = ob;
-            for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {
+            for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {       // (32-bit halves were measured: more loops, more instructions)
                 const uint32_t b = (uint32_t)__builtin_ctzll(m);
                 // line that holds the mark; 0xFFFF: tail of a line of the previous stripe
                 OPL[j] = (sp + b) | ((sb + (uint32_t)__popcll(NL[h] & ((1ull << b) - 1ull)) - 1u) << 16);
@@ -586,8 +602,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     ok &= (t9 - t8 - 2u <= 8u) & (t10 - t9 - 2u <= 8u) & (t11 - t10 - 2u <= 8u);
                     if (ok) {
                         ok = bits_clear(ndbm, t0 + 1, t3 - t0 - 1) & bits_clear(ndbm, t5 + 1, t11 - t5 - 1);
-                        const uint32_t alen = field_val(text, t9 + 1, t10 - t9 - 1);
-                        ok &= alen != 0;                                 // ZeroDivisionError (no id:f: tag in this stripe): exact path decides
+                        ok &= !field_is_zero(text, t9 + 1, t10 - t9 - 1);   // Alen == 0: ZeroDivisionError (no id:f: tag in this stripe): exact path decides
                         // path column (t4, t5): every orientation mark of the line sits in it, the first one right after t4
                         k = kall;
                         ok &= k >= 1 && k <= KMAX && t5 > t4 + 1;
@@ -597,10 +612,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                             // check_bkpt_overlap (filter-alignments.py:258-273) for a link of this line reads
                             //   sum(len up to the left node) - Ts >= d_over  and  sum(len from the right node) - (Tlen - Te - 1) >= d_over:
                             // the two right-hand sides are fixed per line (clamped to 32 bits: the sums stay below 2^31)
-                            const long long tlen = field_val(text, t5 + 1, t6 - t5 - 1), ts = field_val(text, t6 + 1, t7 - t6 - 1), te = field_val(text, t7 + 1, t8 - t7 - 1);
-                            const long long need_l = ts + (long long)g.d_over, need_r = (long long)g.d_over + tlen - te - 1;
-                            r_need_l = need_l > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)need_l;
-                            r_need_r = need_r < 0 ? 0u : need_r > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)need_r;
+                            // (columns of at most nine digits and d_over < 2^31, svjg_load_graph: everything fits 32 bits)
+                            const uint32_t tlen = field_val(text, t5 + 1, t6 - t5 - 1), ts = field_val(text, t6 + 1, t7 - t6 - 1), te = field_val(text, t7 + 1, t8 - t7 - 1);
+                            r_need_l = ts + g.d_over;
+                            r_need_r = tlen + g.d_over > te + 1u ? tlen + g.d_over - te - 1u : 0u;
                             r_pend = t5;
                         }
                     }
@@ -644,7 +659,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
                 if (probe) dsp = g.name_disp[name_bucket(h, g.name_buckets)];
-                uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0xFFFFFFFFu, 0), r2 = make_uint4(0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0), r3 = make_uint4(0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0);
+                // (lanes without a name load nothing: their record registers hold whatever was there and are looked at under `probe` only —
+                //  a later `go` implies a matched node)
+                uint4 r0, r1, r2, r3;
+                asm volatile("" : "=v"(r0.x), "=v"(r0.y), "=v"(r0.z), "=v"(r0.w), "=v"(r1.x), "=v"(r1.y), "=v"(r1.z), "=v"(r1.w));
+                asm volatile("" : "=v"(r2.x), "=v"(r2.y), "=v"(r2.z), "=v"(r2.w), "=v"(r3.x), "=v"(r3.y), "=v"(r3.z), "=v"(r3.w));
                 if (probe) {
                     const uint4 *e = (const uint4 *)(g.name_tab + (size_t)name_slot(h, dsp, g.name_slots) * 16);
                     r0 = e[0]; r1 = e[1]; r2 = e[2]; r3 = e[3];

@@ -58,9 +58,20 @@ SVJG_HD uint64_t name_prehash(const uint32_t d[8], uint32_t len) {
     for (int i = 0; i < 8; ++i) h += (uint64_t)d[i] * C[i];
     return h;
 }
-SVJG_HD uint32_t name_bucket(uint64_t h, uint32_t n_buckets) { return mulhi32(fmix32((uint32_t)(h >> 32) ^ ((uint32_t)h * 0x85EBCA77u)), n_buckets); }
+// The pre-hash is a multiply-and-add with 32-bit factors: its words are only lightly mixed (names that differ in a digit or
+// two have nearby high words), so bucket and slot each put it through one multiply / xor-shift round of their own (measured:
+// without it hash-and-displace finds no placement for a DEL-only single-chromosome graph; two full finalisers — what this
+// replaced — cost about three times the instructions of the whole lookup's compare).
+SVJG_HD uint32_t name_bucket(uint64_t h, uint32_t n_buckets) {
+    uint32_t z = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u;
+    z ^= z >> 15;
+    return mulhi32(z * 0x846CA68Bu, n_buckets);
+}
 SVJG_HD uint32_t name_slot(uint64_t h, uint32_t disp, uint32_t n_slots) {
-    return mulhi32(fmix32(((uint32_t)h ^ ((uint32_t)(h >> 32) * 0x9E3779B1u)) + disp * 0x632BE5ABu), n_slots);
+    const uint32_t x = ((uint32_t)h * 0x85EBCA77u) ^ (uint32_t)(h >> 32);
+    uint32_t y = x * ((disp * 0x632BE5ABu + 0x7FEB352Du) | 1u);
+    y ^= y >> 15;
+    return mulhi32(y * 0x2C1B3C6Du, n_slots);
 }
 // Link table (two-choice): the slots of a link follow from the 64-bit name pre-hashes of its two nodes and the strands
 // (1 = '-'), so a lookup needs no node ids; with 64 bits no three links share their pair of slots.
