@@ -29,25 +29,27 @@ constexpr uint32_t TEXT = NHALF * HALF;          // 8 KB staged in LDS per strip
 // The lists are sized for ordinary line shapes (a 12-column line with a handful of tags is >= ~100 bytes); a stripe whose text
 // is denser than that is first cut down to its first half and only then sent to the exact path as a whole.
 constexpr uint32_t MAXL = 64;                       // line starts per stripe = lines of one round (one line per lane in the line phase)
-constexpr uint32_t CAP_T = 832;                     // tab positions per stripe
-constexpr uint32_t CAP_O = 256;                     // orientation marks ('<' '>') per stripe
+#ifndef SVJG_CAP_O
+#define SVJG_CAP_O 216
+#endif
+constexpr uint32_t CAP_O = SVJG_CAP_O;              // orientation marks ('<' '>') per stripe
 constexpr uint32_t KMAX = 64;                    // path nodes per alignment handled by the main kernel: one wave pass (longer paths: exact path)
 constexpr uint32_t LRW = MAXL;                   // lines per round
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
-// LDS of one worker (bytes); the hardware hands LDS out in units of 1280 bytes: 12 800 bytes = twelve workers per CU
+// LDS of one worker (bytes); the hardware hands LDS out in units of 1280 bytes
 constexpr uint32_t L_TEXT = 0;                                             // staged text + slack for the word reads behind a name / column
 constexpr uint32_t L_NDBM = L_TEXT + TEXT + 64;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab (line phase only)
 constexpr uint32_t L_RL = L_NDBM;                                          // uint4[LRW] per line, written at the END of the line phase (the bitmap is dead by then):
                                                                            //   need_l, need_r, first mark (rel.) | k << 16 | status << 24, tab behind the path
-constexpr uint32_t L_TP = L_NDBM + TEXT / 8 + 16;                          // u16[CAP_T + 16]  position of tab #t of the stripe
-constexpr uint32_t L_OPL = L_TP + (CAP_T + 16) * 2;                        // u32[CAP_O + 8]   orientation mark #o: position | line (ordinal in the stripe) << 16
-constexpr uint32_t L_LINE = L_OPL + (CAP_O + 8) * 4;                       // u16[4][MAXL + 8] line #l: start, tabs in front of it, marks in front of it, -- ; [n].start = 0xFFFF
-constexpr uint32_t LDS_MAIN = L_LINE + (MAXL + 8) * 8;
+constexpr uint32_t L_TBM = L_NDBM + TEXT / 8 + 16;                         // u32[TEXT/32 + 4] one bit per byte: a tab (the line phase walks a line's columns on it)
+constexpr uint32_t L_OPL = L_TBM + TEXT / 8 + 16;                          // u32[CAP_O + 8]   orientation mark #o: position | line (ordinal in the stripe) << 16
+constexpr uint32_t L_LINE = L_OPL + (CAP_O + 8) * 4;                       // u16[2][MAXL + 8] line #l: start, marks in front of it ; [n].start = 0xFFFF
+constexpr uint32_t LDS_MAIN = L_LINE + (MAXL + 8) * 4;
 constexpr uint32_t LDS_GRANULE = 1280;
 static_assert(LRW * 16 <= TEXT / 8 + 16, "the per-line records fit the bitmap they replace");
-static_assert(LDS_MAIN <= 10 * LDS_GRANULE, "twelve workers per CU");
-static_assert(L_NDBM % 16 == 0 && L_TP % 16 == 0 && L_OPL % 16 == 0 && L_LINE % 16 == 0 && L_RL % 16 == 0, "LDS alignment");
+static_assert(LDS_MAIN <= 9 * LDS_GRANULE, "fourteen workers per CU");
+static_assert(L_NDBM % 16 == 0 && L_TBM % 16 == 0 && L_OPL % 16 == 0 && L_LINE % 16 == 0 && L_RL % 16 == 0, "LDS alignment");
 
 // status words (device)
 struct DevStatus {
@@ -236,8 +238,8 @@ __device__ inline uint32_t xad(uint32_t a, uint32_t b, uint32_t c) {
 // ASCII text (every byte < 0x80): (byte ^ c) + 0x7F has bit 7 set exactly where the byte differs from c, with no carries
 // between the byte lanes; (byte ^ '0') + 0x76 has it set exactly where the byte is no digit.
 template <bool ASCII>
-__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t slot, uint64_t c0, uint32_t V,
-                                     unsigned long long &NL, unsigned long long &TAB, unsigned long long &ORI) {
+__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t *tbm, uint32_t slot, uint64_t c0, uint32_t V,
+                                     unsigned long long &NL, unsigned long long &ORI) {
     const uint32_t sp = slot * SPAN;
     // rotated piece order: the 16-byte LDS reads of a wave hit different banks.  The 16-bit masks are collected in loop
     // order and the four of a class rotated into place at the end (one 64-bit rotate instead of four shifts).
@@ -278,11 +280,13 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
             while (cr) {
                 uint32_t b = __builtin_ctz(cr); cr &= cr - 1;
                 uint32_t q = pb + b;
-                uint8_t nx = (q + 1 < TEXT) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
+                const uint32_t staged = (slot / WG + 1u) * HALF;          // (the half behind this one may not be in LDS yet)
+                uint8_t nx = (q + 1 < staged) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
                 if (nx != '\n') nl |= 1u << b;
             }
         }
         nlm[c] = nl; tabm[c] = tab; orim[c] = ori; ndm[c] = nd;
+        asm volatile("" : "+v"(nlm[c]), "+v"(tabm[c]), "+v"(orim[c]), "+v"(ndm[c]));   // (a piece's masks are finished before the next piece's flag words pile up in registers)
     }
     auto place = [&](const uint32_t (&m)[PIECES]) -> unsigned long long {      // piece c of the loop sits at 16-bit position (c + rot) & 3
         const unsigned long long x = (unsigned long long)(m[0] | (m[1] << 16)) | ((unsigned long long)(m[2] | (m[3] << 16)) << 32);
@@ -292,7 +296,8 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
     const unsigned long long tab64 = place(tabm), ori64 = place(orim), nd64 = place(ndm);
     if (sp + SPAN > V) nl64 &= sp >= V ? 0ull : ((1ull << (V - sp)) - 1ull);   // ignore anything at or beyond the valid length
     *(uint2 *)(ndbm + slot * 2) = make_uint2((uint32_t)nd64, (uint32_t)(nd64 >> 32));
-    NL = nl64; TAB = tab64; ORI = ori64;
+    *(uint2 *)(tbm + slot * 2) = make_uint2((uint32_t)tab64, (uint32_t)(tab64 >> 32));
+    NL = nl64; ORI = ori64;
 }
 
 // decimal column text[a, a + n), 1 <= n <= 9, known to hold digits only -> value.  Straight-line SWAR on three aligned
@@ -334,6 +339,27 @@ __device__ inline bool bits_clear(const uint32_t *bm, uint32_t a, uint32_t n) {
     return (x & m) == 0;
 }
 
+// Columns of a line on the tab bitmap (one bit per byte of the staged text).  tab_window: the 32 bits from position p on;
+// take_tab: the first tab of a window whose bit 0 is position p -> its position (TEXT = none) and the window without it.
+// Three decimal columns of at most nine characters and their tabs fit one window.  tab_from: first tab in [p, lim), any distance.
+// (p <= TEXT + 1: the bitmap has two words of slack, kept zero.)
+__device__ inline uint32_t tab_window(const uint32_t *tbm, uint32_t p) {
+    const uint32_t *w = tbm + (p >> 5);
+    return __builtin_amdgcn_alignbit(w[1], w[0], p & 31u);
+}
+__device__ inline uint32_t take_tab(uint32_t &win, uint32_t p) {
+    const uint32_t t = win ? p + (uint32_t)__builtin_ctz(win) : TEXT;
+    win &= win - 1u;
+    return t;
+}
+__device__ inline uint32_t tab_from(const uint32_t *tbm, uint32_t p, uint32_t lim) {
+    for (uint32_t q = p; q < lim; q += 32) {
+        const uint32_t win = tab_window(tbm, q);
+        if (win) { const uint32_t t = q + (uint32_t)__builtin_ctz(win); return t < lim ? t : TEXT; }
+    }
+    return TEXT;
+}
+
 // "id:f:" anywhere in a line changes what the reference does with it (filter-alignments.py:193-196: float() of the tag value may
 // raise, Alen == 0 no longer does): such lines take the exact path.  Wherever the five bytes start, one of the two-byte
 // pieces "id" (even offset) or "d:" (odd offset) sits at an EVEN offset of the text, i.e. fills one aligned half of a word.  The
@@ -373,7 +399,7 @@ constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST =
 #define DIAG(bit) false
 #endif
 #ifndef SVJG_MINW
-#define SVJG_MINW 3          /* three waves per SIMD = the twelve workers per CU the LDS admits: at most 168 VGPRs */
+#define SVJG_MINW 4          /* four waves per SIMD: at most 128 VGPRs (fourteen workers per CU by LDS) */
 #endif
 __device__ inline unsigned long long low_bits64(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
 __device__ inline uint32_t clamp64(uint32_t hi, uint32_t lo) { return hi > lo ? (hi - lo < 64u ? hi - lo : 64u) : 0u; }   // min(max(hi - lo, 0), 64)
@@ -382,9 +408,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *text = lds + L_TEXT;
     uint32_t *ndbm = (uint32_t *)(lds + L_NDBM);
-    uint16_t *TP = (uint16_t *)(lds + L_TP);
+    uint32_t *tbm = (uint32_t *)(lds + L_TBM);
     uint32_t *OPL = (uint32_t *)(lds + L_OPL);
-    uint2 *LINE = (uint2 *)(lds + L_LINE);                              // .x = start | tabs in front << 16, .y = marks in front
+    uint32_t *LINE = (uint32_t *)(lds + L_LINE);                        // start | marks in front << 16
     uint4 *RL = (uint4 *)(lds + L_RL);                                  // (the bitmap's bytes: see L_RL)
 
     const uint32_t lane = threadIdx.x;
@@ -394,6 +420,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     if (pos >= a.n_bytes) return;
     const unsigned long long rend = pos + a.region < a.n_bytes ? pos + a.region : a.n_bytes;   // lines starting before it are this worker's
 
+    if (lane < 4) tbm[TEXT / 32 + lane] = 0;                            // slack of the tab bitmap (tab_near reads one word past a position)
     unsigned long long wave_lines = 0;
     // measurement only (build with -DSVJG_TIMING, run with SVJG_DIAG & 16): time this wave spends per phase
 #ifdef SVJG_TIMING
@@ -406,18 +433,23 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     auto tick = [](int) {};
 #endif
 
-    // stripe prefetch registers: piece i of the lane = bytes [(i * 64 + lane) * 16, + 16) of the staged text
-    constexpr uint32_t NPF = TEXT / (WG * 16);
+    // stripe prefetch registers: the FIRST HALF of a stripe waits in registers while the stripe in front of it is worked off (piece i
+    // of the lane = bytes [(i * 64 + lane) * 16, + 16)); its second half is asked for when the first has gone to LDS and arrives
+    // while the first half's bytes are classified — half the registers for the same overlap.
+    constexpr uint32_t NPF = HALF / (WG * 16);
     uint4 pf[NPF];
     uint32_t pf_head = '\n';                                           // byte right before the stripe (decides whether it starts a line)
-    auto prefetch = [&](unsigned long long c0) {                     // no bounds tests: the buffer is zero padded by TEXT + 64 bytes
-        const uint4 *src = (const uint4 *)(a.gaf + c0) + lane;
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    auto fetch_half = [&](unsigned long long at) {                   // no bounds tests: the buffer is zero padded by TEXT + 64 bytes
+        const uint4 *src = (const uint4 *)(a.gaf + at) + lane;
 #pragma unroll
         for (uint32_t i = 0; i < NPF; ++i) {                             // non-temporal: the text is streamed once and should not displace the node records in L2
             const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(src + i * WG));
             pf[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
+    };
+    auto prefetch = [&](unsigned long long c0) {
+        fetch_half(c0);
         pf_head = c0 > a.begin ? a.gaf[c0 - 1] : (uint32_t)'\n';     // (the text begins at a line start whatever lies in front of it)
     };
     prefetch(pos & ~15ull);
@@ -428,38 +460,36 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (unsigned long long)TEXT) ? (a.n_bytes - c0) : (unsigned long long)TEXT);   // valid bytes staged
         const bool at_eof = c0 + V == a.n_bytes;
 
-        // ---- A: registers -> LDS; bytes >= 0x80 and the "id:f:" filter on the registers -------------------------
-        __builtin_amdgcn_s_setprio(P_A);
-        uint32_t hi_bits = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < NPF; ++i) {
-            hi_bits |= pf[i].x | pf[i].y | pf[i].z | pf[i].w;
-            *(uint4 *)(text + (i * WG + lane) * 16) = pf[i];
-        }
+        // ---- A / B1, half by half: registers -> LDS; bytes >= 0x80 and the "id:f:" filter on the registers; byte classes --------
         const uint32_t head_byte = pf_head;
-        const bool ascii = ballot64((hi_bits & 0x80808080u) != 0) == 0;   // wave-uniform: the cheaper SWAR classes apply
-        if (!ascii && lane == 0) a.st->non_ascii = 1;
         uint32_t idf_id = 0xFFFFFFFFu, idf_dc = 0xFFFFFFFFu;
-#pragma unroll
-        for (uint32_t i = 0; i < NPF; ++i) idf_piece(pf[i], idf_id, idf_dc);
-        // a 16-bit half of a running minimum is zero <=> some aligned halfword matched
-        const bool idf = ballot64(((((idf_id - 0x00010001u) & ~idf_id) | ((idf_dc - 0x00010001u) & ~idf_dc)) & 0x80008000u) != 0) != 0;
-        wave_sync();
-        __builtin_amdgcn_s_setprio(0);
-        tick(0);
-
-        // ---- B1: byte classes ---------------------------------------------------------------------------------
-        unsigned long long NL[NHALF], TAB[NHALF], ORI[NHALF];
+        unsigned long long NL[NHALF], ORI[NHALF];
 #pragma unroll
         for (uint32_t h = 0; h < NHALF; ++h) {
-            if (ascii) classify_span<true>(a, text, ndbm, h * WG + lane, c0, V, NL[h], TAB[h], ORI[h]);
-            else classify_span<false>(a, text, ndbm, h * WG + lane, c0, V, NL[h], TAB[h], ORI[h]);
+            __builtin_amdgcn_s_setprio(P_A);
+            uint32_t hi_bits = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < NPF; ++i) {
+                hi_bits |= pf[i].x | pf[i].y | pf[i].z | pf[i].w;
+                *(uint4 *)(text + h * HALF + (i * WG + lane) * 16) = pf[i];
+                idf_piece(pf[i], idf_id, idf_dc);
+            }
+            if (h + 1 < NHALF) fetch_half(c0 + (h + 1) * HALF);           // the next half travels while this one is classified
+            const bool ascii = ballot64((hi_bits & 0x80808080u) != 0) == 0;   // wave-uniform: the cheaper SWAR classes apply
+            if (!ascii && lane == 0) a.st->non_ascii = 1;
+            wave_sync();
+            __builtin_amdgcn_s_setprio(0);
+            if (ascii) classify_span<true>(a, text, ndbm, tbm, h * WG + lane, c0, V, NL[h], ORI[h]);
+            else classify_span<false>(a, text, ndbm, tbm, h * WG + lane, c0, V, NL[h], ORI[h]);
         }
+        // a 16-bit half of a running minimum is zero <=> some aligned halfword matched
+        const bool idf = ballot64(((((idf_id - 0x00010001u) & ~idf_id) | ((idf_dc - 0x00010001u) & ~idf_dc)) & 0x80008000u) != 0) != 0;
+        tick(0);
         // does the stripe begin at a line start?  (wave-uniform)
         const uint32_t head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
         uint32_t Vh = V;                                                 // bytes of the staged text this stripe looks at: all of them, or (dense text) the first half
         bool eof_h = at_eof;
-        uint32_t lim2, n_s, n_own, tot_tab, tot_ori, l_first;
+        uint32_t lim2, n_s, n_own, tot_ori, l_first;
         bool last_stripe, long_line;
         unsigned long long next_pos;
         unsigned long long OWN[NHALF];
@@ -502,21 +532,21 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t hd = (h == 0 && lane == 0) ? head : 0u, hdo = (h == 0 && lane == 0) ? head_own : 0u;
                 if (h == 0) l_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((head & (uint32_t)(0 < own_lo)) + (uint32_t)__popcll(NL[0] & below_lo)));   // (own_lo < 16: only lane 0 can see such starts)
                 const uint32_t cA = ((uint32_t)__popcll(NL[h]) + hd) | (((uint32_t)__popcll(OWN[h]) + hdo) << 16);
-                const uint32_t cB = (uint32_t)__popcll(TAB[h]) | ((uint32_t)__popcll(ORI[h]) << 16);
+                const uint32_t cB = (uint32_t)__popcll(ORI[h]);
                 exA[h] = wave_excl_scan(cA, totA[h]); exB[h] = wave_excl_scan(cB, totB[h]);
             }
             const uint32_t totAs = totA[0] + totA[1], totBs = totB[0] + totB[1];
             n_s = totAs & 0xFFFFu; n_own = totAs >> 16;                  // line starts in the text looked at, and how many of them this stripe handles
-            tot_tab = totBs & 0xFFFFu; tot_ori = totBs >> 16;
-            if (attempt || Vh <= HALF || !(n_s > MAXL || tot_tab > CAP_T || tot_ori > CAP_O)) break;
+            tot_ori = totBs;
+            if (attempt || Vh <= HALF || !(n_s > MAXL || tot_ori > CAP_O)) break;
             // the lists cannot hold the whole stripe: look at its first half only (the next stripe begins inside this one)
-            NL[1] = 0; TAB[1] = 0; ORI[1] = 0;
+            NL[1] = 0; ORI[1] = 0;
             Vh = HALF; eof_h = false;
         }
         if (!last_stripe) prefetch(next_pos & ~15ull);
         tick(1);
 
-        if (a.all_slow || idf || long_line || n_s > MAXL || tot_tab > CAP_T || tot_ori > CAP_O) {
+        if (a.all_slow || idf || long_line || n_s > MAXL || tot_ori > CAP_O) {
             // the lists cannot hold this stripe / "id:f:" somewhere in it / the caller wants the exact path: every owned line is deferred as it is
             if (n_own) {
                 unsigned long long dbase = 0;
@@ -543,23 +573,20 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         __builtin_amdgcn_s_setprio(P_B2);
         // ---- B2: rank-indexed lists ----------------------------------------------------------------------
         if (lane == 0) {
-            if (head) LINE[0] = make_uint2(0u, 0u);
-            LINE[n_s] = make_uint2(0xFFFFu | (tot_tab << 16), tot_ori);
+            if (head) LINE[0] = 0u;
+            LINE[n_s] = 0xFFFFu | (tot_ori << 16);
         }
 #pragma unroll
         for (uint32_t h = 0; h < NHALF; ++h) {
             const uint32_t sp = (h * WG + lane) * SPAN;
-            const uint32_t bA = (h ? totA[0] : 0u) + exA[h], bB = (h ? totB[0] : 0u) + exB[h];
+            const uint32_t bA = (h ? totA[0] : 0u) + exA[h];
             const uint32_t sb = (bA & 0xFFFFu) + ((h == 0 && lane == 0) ? head : 0u);   // ordinal of the first line start this lane creates
-            const uint32_t tb = bB & 0xFFFFu, ob = bB >> 16;
+            const uint32_t ob = (h ? totB[0] : 0u) + exB[h];
             uint32_t j = sb;
             for (unsigned long long m = NL[h]; m; m &= m - 1, ++j) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                const unsigned long long below = (1ull << b) - 1ull;
-                LINE[j] = make_uint2((sp + b + 1) | ((tb + (uint32_t)__popcll(TAB[h] & below)) << 16), ob + (uint32_t)__popcll(ORI[h] & below));
+                LINE[j] = (sp + b + 1) | ((ob + (uint32_t)__popcll(ORI[h] & ((1ull << b) - 1ull))) << 16);
             }
-            j = tb;
-            for (unsigned long long m = TAB[h]; m; m &= m - 1, ++j) TP[j] = (uint16_t)(sp + (uint32_t)__builtin_ctzll(m));
             j = ob;
             for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {       // (32-bit halves were measured: more loops, more instructions)
                 const uint32_t b = (uint32_t)__builtin_ctzll(m);
@@ -575,49 +602,60 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         const uint32_t l_hi = l_first + n_own;
         for (uint32_t lbase = DIAG(1u) ? l_hi : l_first; lbase < l_hi; lbase += LRW) {   // wave-uniform trip count
             const uint32_t cnt = l_hi - lbase < LRW ? l_hi - lbase : LRW;
-            const uint32_t obase = LINE[lbase].y;
+            const uint32_t obase = LINE[lbase] >> 16;
             // ---- R1: one line per lane --------------------------------------------------------------
             uint32_t status = ST_NONE, k = 0, s = 0, rel = 0, kall = 0, r_need_l = 0, r_need_r = 0, r_pend = 0;
             if (lane < cnt) {
                 const uint32_t L = lbase + lane;
-                const uint2 l0 = LINE[L], l1 = LINE[L + 1];
-                s = l0.x & 0xFFFFu;
-                const uint32_t nx = l1.x & 0xFFFFu, tr = l0.x >> 16, tn = l1.x >> 16, o0 = l0.y, o1 = l1.y;
+                const uint32_t l0 = LINE[L], l1 = LINE[L + 1];
+                s = l0 & 0xFFFFu;
+                const uint32_t nx = l1 & 0xFFFFu, o0 = l0 >> 16, o1 = l1 >> 16;
                 kall = o1 - o0; rel = o0 - obase;
                 status = ST_DEFER;
                 if (nx != 0xFFFFu || eof_h) {                            // (always: the stripe handles only lines that end in it)
                     uint32_t e = nx != 0xFFFFu ? nx - 1 : Vh;
-                    uint32_t nt = tn - tr;
                     if (e > s && py_space(text[e - 1])) {                // line.rstrip(): blanks, a CR, trailing tabs
                         do --e; while (e > s && py_space(text[e - 1]));
-                        while (nt && TP[tr + nt - 1] >= e) --nt;
                     }
-                    const uint16_t *tp = TP + tr;
-                    const uint32_t t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3], t4 = tp[4], t5 = tp[5];
-                    const uint32_t t6 = tp[6], t7 = tp[7], t8 = tp[8], t9 = tp[9], t10 = tp[10], t11 = nt >= 12u ? (uint32_t)tp[11] : e;
-                    bool ok = nt >= 11u;                                 // twelve columns
+                    // the twelve column ends, one after the other on the tab bitmap: a decimal column has its tab within ten bytes
+                    // (one 32-bit window); read name, strand and path column may be any length
+                    const uint32_t t0 = tab_from(tbm, s, e);
+                    uint32_t wa = tab_window(tbm, t0 + 1);              // columns 2..4 (and, when they are short, the strand column's tab)
+                    const uint32_t t1 = take_tab(wa, t0 + 1), t2 = take_tab(wa, t0 + 1), t3 = take_tab(wa, t0 + 1);
+                    const uint32_t t4a = take_tab(wa, t0 + 1);
+                    const uint32_t t4 = t4a < TEXT ? (t4a < e ? t4a : TEXT) : tab_from(tbm, t0 + 33 < TEXT ? t0 + 33 : TEXT, e);   // (nothing in the window: look further)
+                    const uint32_t t5 = tab_from(tbm, t4 + 1, e);
+                    uint32_t wb = tab_window(tbm, t5 + 1);              // columns 7..9
+                    const uint32_t t6 = take_tab(wb, t5 + 1), t7 = take_tab(wb, t5 + 1), t8 = take_tab(wb, t5 + 1);
+                    uint32_t wc = tab_window(tbm, t8 + 1);              // columns 10..12
+                    const uint32_t t9 = take_tab(wc, t8 + 1), t10 = take_tab(wc, t8 + 1), t11n = take_tab(wc, t8 + 1);
+                    const uint32_t t11 = t11n < e ? t11n : e;
+                    bool ok = t10 < e;                                   // eleven tabs inside the (stripped) line: twelve columns
                     // the nine decimal columns: 1..9 characters each, nothing but digits in them
                     ok &= (t1 - t0 - 2u <= 8u) & (t2 - t1 - 2u <= 8u) & (t3 - t2 - 2u <= 8u);
                     ok &= (t6 - t5 - 2u <= 8u) & (t7 - t6 - 2u <= 8u) & (t8 - t7 - 2u <= 8u);
                     ok &= (t9 - t8 - 2u <= 8u) & (t10 - t9 - 2u <= 8u) & (t11 - t10 - 2u <= 8u);
+                    // From here on straight code on positions made harmless when the line is not `ok` (every LDS read goes out at
+                    // once instead of one dependent round trip per nested test).
+                    const uint32_t u0 = ok ? t0 : 0u, u3 = ok ? t3 : 1u, u4 = ok ? t4 : 0u, u5 = ok ? t5 : 0u, u6 = ok ? t6 : 2u, u7 = ok ? t7 : 4u;
+                    const uint32_t u8 = ok ? t8 : 6u, u9 = ok ? t9 : 8u, u10 = ok ? t10 : 10u, u11 = ok ? t11 : 12u;
+                    const bool digits = bits_clear(ndbm, u0 + 1, u3 - u0 - 1) & bits_clear(ndbm, u5 + 1, u11 - u5 - 1);
+                    const bool alen0 = field_is_zero(text, u9 + 1, u10 - u9 - 1);   // Alen == 0: ZeroDivisionError (no id:f: tag in this stripe): exact path decides
+                    // path column (t4, t5): every orientation mark of the line sits in it, the first one right after t4
+                    k = kall;
+                    const bool kfit = k >= 1 && k <= KMAX;
+                    const uint32_t m_first = OPL[o0] & 0xFFFFu, m_last = OPL[kfit ? o0 + k - 1 : o0] & 0xFFFFu;
+                    // check_bkpt_overlap (filter-alignments.py:258-273) for a link of this line reads
+                    //   sum(len up to the left node) - Ts >= d_over  and  sum(len from the right node) - (Tlen - Te - 1) >= d_over:
+                    // the two right-hand sides are fixed per line
+                    // (columns of at most nine digits and d_over < 2^31, svjg_load_graph: everything fits 32 bits)
+                    const uint32_t tlen = field_val(text, u5 + 1, u6 - u5 - 1), ts = field_val(text, u6 + 1, u7 - u6 - 1), te = field_val(text, u7 + 1, u8 - u7 - 1);
+                    ok = ok && digits && !alen0 && kfit && u5 > u4 + 1 && m_first == u4 + 1 && m_last < u5;
                     if (ok) {
-                        ok = bits_clear(ndbm, t0 + 1, t3 - t0 - 1) & bits_clear(ndbm, t5 + 1, t11 - t5 - 1);
-                        ok &= !field_is_zero(text, t9 + 1, t10 - t9 - 1);   // Alen == 0: ZeroDivisionError (no id:f: tag in this stripe): exact path decides
-                        // path column (t4, t5): every orientation mark of the line sits in it, the first one right after t4
-                        k = kall;
-                        ok &= k >= 1 && k <= KMAX && t5 > t4 + 1;
-                        if (ok) ok = (OPL[o0] & 0xFFFFu) == t4 + 1 && (OPL[o0 + k - 1] & 0xFFFFu) < t5;
-                        if (ok) {
-                            status = k >= 2 ? ST_OK : ST_NOHIT;
-                            // check_bkpt_overlap (filter-alignments.py:258-273) for a link of this line reads
-                            //   sum(len up to the left node) - Ts >= d_over  and  sum(len from the right node) - (Tlen - Te - 1) >= d_over:
-                            // the two right-hand sides are fixed per line (clamped to 32 bits: the sums stay below 2^31)
-                            // (columns of at most nine digits and d_over < 2^31, svjg_load_graph: everything fits 32 bits)
-                            const uint32_t tlen = field_val(text, t5 + 1, t6 - t5 - 1), ts = field_val(text, t6 + 1, t7 - t6 - 1), te = field_val(text, t7 + 1, t8 - t7 - 1);
-                            r_need_l = ts + g.d_over;
-                            r_need_r = tlen + g.d_over > te + 1u ? tlen + g.d_over - te - 1u : 0u;
-                            r_pend = t5;
-                        }
+                        status = k >= 2 ? ST_OK : ST_NOHIT;
+                        r_need_l = ts + g.d_over;
+                        r_need_r = tlen + g.d_over > te + 1u ? tlen + g.d_over - te - 1u : 0u;
+                        r_pend = t5;
                     }
                 }
             }
@@ -775,7 +813,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     if (!DIAG(8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
                     if (a.want_hits) {
                         if (rbase + jj < a.rec_cap) {
-                            svjg_hitrec r; r.line_start = a.base_offset + c0 + (LINE[lbase + ln].x & 0xFFFFu); r.slot = hv >> 1;
+                            svjg_hitrec r; r.line_start = a.base_offset + c0 + (LINE[lbase + ln] & 0xFFFFu); r.slot = hv >> 1;
                             r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
                             a.recs[rbase + jj] = r;
                         } else atomicOr(&a.st->overflow, 2u);
