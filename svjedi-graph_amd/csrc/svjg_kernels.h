@@ -352,6 +352,10 @@ __device__ inline uint32_t take_tab(uint32_t &win, uint32_t p) {
     win &= win - 1u;
     return t;
 }
+__device__ inline uint32_t tab_near(const uint32_t *tbm, uint32_t p) {     // first tab in [p, p + 32), or TEXT
+    const uint32_t win = tab_window(tbm, p);
+    return win ? p + (uint32_t)__builtin_ctz(win) : TEXT;
+}
 __device__ inline uint32_t tab_from(const uint32_t *tbm, uint32_t p, uint32_t lim) {
     for (uint32_t q = p; q < lim; q += 32) {
         const uint32_t win = tab_window(tbm, q);
@@ -624,7 +628,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t t1 = take_tab(wa, t0 + 1), t2 = take_tab(wa, t0 + 1), t3 = take_tab(wa, t0 + 1);
                     const uint32_t t4a = take_tab(wa, t0 + 1);
                     const uint32_t t4 = t4a < TEXT ? (t4a < e ? t4a : TEXT) : tab_from(tbm, t0 + 33 < TEXT ? t0 + 33 : TEXT, e);   // (nothing in the window: look further)
-                    const uint32_t t5 = tab_from(tbm, t4 + 1, e);
+                    // The path column ends at the first tab behind the line's LAST orientation mark (a node name has at most 32 bytes).  Should a tab sit in front of that mark (marks in later columns), the piece of text
+                    // between two marks that holds it is no node name, and the node pass sends the line to the exact path.
+                    k = kall;
+                    const bool kfit = k >= 1 && k <= KMAX;
+                    const uint32_t m_first = OPL[o0] & 0xFFFFu, m_last = OPL[kfit ? o0 + k - 1 : o0] & 0xFFFFu;
+                    uint32_t t5 = tab_near(tbm, m_last + 1);
+                    if (t5 == TEXT && (tab_window(tbm, m_last + 33 < TEXT ? m_last + 33 : TEXT) & 1u)) t5 = m_last + 33;   // (a 32-byte name)
                     uint32_t wb = tab_window(tbm, t5 + 1);              // columns 7..9
                     const uint32_t t6 = take_tab(wb, t5 + 1), t7 = take_tab(wb, t5 + 1), t8 = take_tab(wb, t5 + 1);
                     uint32_t wc = tab_window(tbm, t8 + 1);              // columns 10..12
@@ -641,10 +651,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t u8 = ok ? t8 : 6u, u9 = ok ? t9 : 8u, u10 = ok ? t10 : 10u, u11 = ok ? t11 : 12u;
                     const bool digits = bits_clear(ndbm, u0 + 1, u3 - u0 - 1) & bits_clear(ndbm, u5 + 1, u11 - u5 - 1);
                     const bool alen0 = field_is_zero(text, u9 + 1, u10 - u9 - 1);   // Alen == 0: ZeroDivisionError (no id:f: tag in this stripe): exact path decides
-                    // path column (t4, t5): every orientation mark of the line sits in it, the first one right after t4
-                    k = kall;
-                    const bool kfit = k >= 1 && k <= KMAX;
-                    const uint32_t m_first = OPL[o0] & 0xFFFFu, m_last = OPL[kfit ? o0 + k - 1 : o0] & 0xFFFFu;
+                    // path column (t4, t5): the first orientation mark of the line right after t4, the last one in front of t5
                     // check_bkpt_overlap (filter-alignments.py:258-273) for a link of this line reads
                     //   sum(len up to the left node) - Ts >= d_over  and  sum(len from the right node) - (Tlen - Te - 1) >= d_over:
                     // the two right-hand sides are fixed per line
