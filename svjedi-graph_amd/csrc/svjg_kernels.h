@@ -452,11 +452,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             pf[i] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    auto prefetch = [&](unsigned long long c0) {
-        fetch_half(c0);
-        pf_head = c0 > a.begin ? a.gaf[c0 - 1] : (uint32_t)'\n';     // (the text begins at a line start whatever lies in front of it)
-    };
-    prefetch(pos & ~15ull);
+    // (the text begins at a line start whatever lies in front of it; later stripes take the byte in front of them from the staged
+    //  text of the stripe before: a scalar load here would sit behind an s_waitcnt vmcnt(0) that also waits for the stripe's loads
+    //  just issued — the whole HBM latency, every stripe)
+    fetch_half(pos & ~15ull);
+    { const unsigned long long c0 = pos & ~15ull; pf_head = c0 > a.begin ? a.gaf[c0 - 1] : (uint32_t)'\n'; }
 
     for (;;) {
         const unsigned long long c0 = pos & ~15ull;
@@ -547,7 +547,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             NL[1] = 0; ORI[1] = 0;
             Vh = HALF; eof_h = false;
         }
-        if (!last_stripe) prefetch(next_pos & ~15ull);
+        if (!last_stripe) {
+            const uint32_t d0 = (uint32_t)((next_pos & ~15ull) - c0);    // the next stripe begins inside (or right behind) this one's staged text
+            pf_head = d0 ? (uint32_t)text[d0 - 1] : head_byte;
+            fetch_half(next_pos & ~15ull);
+        }
         tick(1);
 
         if (a.all_slow || idf || long_line || n_s > MAXL || tot_ori > CAP_O) {
