@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """End-to-end timing of the drop-in scripts on a synthetic case (file -> _informative_aln.json -> _genotype.vcf).
 
-    python tools/e2e.py [c2|c3] [n_alignments]
+    python tests/e2e.py [c2|c3] [n_alignments]
 
 Writes the synthetic inputs to a scratch directory, runs svjedi-graph_amd/filter-alignments.py and
 predict-genotype.py exactly as the reference driver would (svjedi-graph.py:114, :124), and prints wall times, file sizes
-and a check of the genotyped VCF against the CPU oracle on the first rows."""
+and checks of both output files: against the reference's own sha256 where tests/golden/synth/<case>_full.json holds one for this
+size, and — always — the genotyped VCF against the CPU oracles (C oracle counts over the whole GAF, Python oracle rows)."""
 import json
 import os
 import subprocess
@@ -15,6 +16,34 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "svjedi-graph_amd")]
+
+
+def check(name, pre, full_size):
+    """the two output files against the oracles (this script lives under tests/: the oracle is test infrastructure)"""
+    import hashlib
+    import numpy as np
+    from oracle import oracle_c, oracle_py
+    out = {}
+    gold = os.path.join(ROOT, "tests", "golden", "synth", f"{name}_full.json")
+    if full_size and os.path.exists(gold):
+        want = json.load(open(gold))
+
+        def sha(path):
+            h = hashlib.sha256()
+            with open(path, "rb") as fh:
+                for b in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(b)
+            return h.hexdigest()
+        out["json_is_the_reference_s"] = sha(pre + "_informative_aln.json") == want["sha256_json"]
+        out["vcf_is_the_reference_s"] = sha(pre + "_genotype.vcf") == want["sha256_vcf"]
+    t = time.time()
+    orc = oracle_c.COracle(oracle_py.load_edges(pre + "_svs_edges.json"), oracle_py.load_alt_node_len(pre + ".gfa"))
+    want, _, n_lines = orc.filter(np.fromfile(pre + ".gaf", dtype=np.uint8), want_hits=False)
+    D = {sv: [["x"] * int(want[i, 0]), ["y"] * int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
+    text, n = oracle_py.genotype_vcf(open(pre + ".vcf").readlines(), D)
+    out["vcf_equals_the_oracles"] = open(pre + "_genotype.vcf").read() == text
+    out["oracle_check_s"] = round(time.time() - t, 1)
+    return out
 
 
 def main():
@@ -38,9 +67,10 @@ def main():
     p = subprocess.run([sys.executable, f"{amd}/predict-genotype.py", "-d", pre + "_informative_aln.json", "-v", pre + ".vcf",
                         "--minsupport", "3", "-o", pre + "_genotype.vcf"], capture_output=True, text=True)
     res["genotype_s"] = round(time.time() - t, 2); res["genotype_rc"] = p.returncode; res["genotype_stdout"] = p.stdout.strip()
-    t = time.time()
     p = subprocess.run([sys.executable, f"{amd}/svjedi-graph.py", "-h"], capture_output=True)
     res["driver_help_rc"] = p.returncode
+    if res["filter_rc"] == 0 and res["genotype_rc"] == 0:
+        res.update(check(name, pre, n_aln == synth.CONFIGS[name][0]))
     print(json.dumps(res))
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))

@@ -3,7 +3,7 @@
 synthetic batch, HIP path against the C oracle (itself pinned on the reference by golden/fuzz).  Lines the oracle dies on
 are left out of the mixed file and tried one by one for the exception class.
 
-    python tools/fuzz_big.py [n_mutants] [seed]
+    python tests/fuzz_big.py [n_mutants] [seed]
 """
 import os, random, sys, tempfile
 import numpy as np
