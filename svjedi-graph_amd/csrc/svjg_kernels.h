@@ -974,12 +974,14 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
             if (!rc && ln.k >= 2) {
                 if (ln.k <= SLOW_NODES) {
                     NodeScratch ns{n_id, n_len, n_rc, n_strand, SLOW_NODES};
-                    rc = wave_min(slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order), order);
+                    // (the call fills `order`: result and order are separate statements, not two arguments of one call)
+                    const int r1 = slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order);
+                    rc = wave_min(r1, order);
                     __syncthreads();
-                    if (!rc) rc = wave_min(slow_wave_phase2(a.g, ln, ns, em, lane, 64u, &order), order);
-                } else rc = wave_min(slow_line(a.g, t, s - a0, s - a0 + (e - s), em, lane, 64u, &order), order);   // a path of more nodes than the scratch holds
+                    if (!rc) { const int r2 = slow_wave_phase2(a.g, ln, ns, em, lane, 64u, &order); rc = wave_min(r2, order); }
+                } else { const int r3 = slow_line(a.g, t, s - a0, s - a0 + (e - s), em, lane, 64u, &order); rc = wave_min(r3, order); }   // a path of more nodes than the scratch holds
             }
-        } else rc = wave_min(slow_line(a.g, a.gaf, s, e, em, lane, 64u, &order), order);
+        } else { const int r4 = slow_line(a.g, a.gaf, s, e, em, lane, 64u, &order); rc = wave_min(r4, order); }
         if (lane == 0 && rc) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (unsigned long long)rc);
         __syncthreads();
     }

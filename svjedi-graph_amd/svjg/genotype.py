@@ -136,7 +136,11 @@ def open_rows(vcf_path, slot_of, slot_is_presence=False):
 def genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support=3, err=0.00005, slot_is_presence=False):
     """Counts already live in the context (fused path, or set_counts): parse, run the kernel, write."""
     rows = open_rows(vcf_path, slot_of, slot_is_presence)
-    gt, pl, raw, done = ctx.genotype(rows.sv_type, rows.slot, rows.ok, min_support, err, reuse_outputs=True)   # views: written out right away
+    min_support = max(0, int(min_support))                       # (a negative threshold: `sum(nbAln) >= minNbAln` always holds, predict-genotype.py:310)
+    bad_err = not (0.0 < float(err) < 1.0)                       # math.log10(e) / math.log10(1 - e) raise in likelihood(), i.e. only once a row gets there
+    gt, pl, raw, done = ctx.genotype(rows.sv_type, rows.slot, rows.ok, min_support, 0.5 if bad_err else err, reuse_outputs=True)   # views: written out right away
+    if bad_err and np.asarray(done).any():
+        raise ValueError("math domain error")                   # (predict-genotype.py:295-297: the reference dies at the first genotyped row)
     if isinstance(rows, VcfRows):
         return write_vcf(out_path, rows, gt, pl, raw, done)
     try:

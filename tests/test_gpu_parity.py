@@ -201,6 +201,18 @@ def test_vcf_cases(golden, tmp_path, tag, ms, err):
     assert p.stdout == open(f"{v}/ref_{tag}.stdout").read()
 
 
+def test_out_of_domain_options(golden, tmp_path):
+    """-e 0 / -e 1 / -e 1.5: math.log10 raises in the reference's likelihood() (predict-genotype.py:295-297) as soon as a row is
+    genotyped; a negative --minsupport genotypes every row like --minsupport 0 (:310).  (Round-1 advice.)"""
+    from svjg import genotype
+    v = f"{golden}/vcf"
+    for e in (0.0, 1.0, 1.5, -0.1):
+        with pytest.raises(ValueError):
+            genotype.run(f"{v}/cases_informative_aln.json", f"{v}/cases.vcf", str(tmp_path / "x.vcf"), err=e)
+    genotype.run(f"{v}/cases_informative_aln.json", f"{v}/cases.vcf", str(tmp_path / "neg.vcf"), min_support=-5)
+    assert open(tmp_path / "neg.vcf").read() == open(f"{v}/ref_ms0.vcf").read()
+
+
 def test_vcf_crash_exit_code(golden, tmp_path):
     import subprocess
     import sys
