@@ -147,6 +147,7 @@ def classify_file(ctx, graph, gaf_path, want_hits=True):
         raise reference_error(data, e)
     if ctx.stats()["non_ascii"]:
         check_utf8(data)
+    capi.allreduce_counts_all([ctx])              # one GPU: only the overflow guard of the 32-bit count fields
     return ctx.counts(), (ctx.hits() if want_hits else None), data
 
 

@@ -19,6 +19,7 @@ Fixture groups:
   vcf/       G5  VCF-parsing cases through the reference's decision_vcf()
   synth/     G6  medium synthetic case from tools/svjg_synth (inputs regenerated from the seed):
                  sha256 of the reference JSON/VCF + the full count vector
+  utf8order/ G8  GAFs that are not UTF-8 and hold a malformed line: which exception the reference dies with
   realshape/ G7  lines shaped like real minigraph output (read names, cg:Z: / ds:Z: tags, paths of up to 300 nodes,
                  UCSC contig names) on a 600-SV graph, with the reference's JSON and VCF
              full  c2_full.json / c3_full.json / c4slice_full.json: sha256 of the reference's JSON and VCF for the
@@ -678,6 +679,42 @@ def make_realshape():
 
 
 # ----------------------------------------------------------------------------------------------
+# G8 which error comes first when the GAF is not UTF-8 (the reference reads it in text mode, block by block)
+# ----------------------------------------------------------------------------------------------
+
+def make_utf8order():
+    import base64
+    out = f"{HERE}/utf8order"
+    os.makedirs(out, exist_ok=True)
+    q = f"{HERE}/quirks"
+    good = open(f"{q}/alt_del.gaf", "rb").read().splitlines(True)[0]
+    bad = b"x\t1\t2\n"                                                # too few columns: ValueError
+    per = 8192 // len(good)
+    cases = {
+        "bad_line_first_block_byte_far": (bad + good * 200 + b"\xff" + good, 0),
+        "byte_same_block_behind_the_line": (bad + b"\xff" + good, 0),
+        "byte_in_front_of_the_line": (good * 3 + b"na\xffme" + good + bad, len(good) * 4 + 5),
+        "line_straddles_into_the_byte_s_block": (good * per + bad + good * 50 + b"\xff", len(good) * per),
+        "line_and_byte_in_the_second_block": (good * 100 + bad + good * 10 + b"\xff", len(good) * 100),
+        "line_in_the_first_block_byte_in_the_second": (good * 10 + bad + good * 100 + b"\xff", len(good) * 10),
+        "no_bad_line_only_the_byte": (good * 5 + b"r\xc3(x" + good, None),
+    }
+    res = {}
+    tmp = tempfile.mkdtemp()
+    for name, (raw, off) in cases.items():
+        with open(f"{tmp}/{name}.gaf", "wb") as fh:
+            fh.write(raw)
+        shutil.copy(f"{q}/q_svs_edges.json", f"{tmp}/{name}_svs_edges.json")
+        rc, err = run_ref_filter(f"{tmp}/{name}.gaf", f"{q}/q.gfa", f"{tmp}/{name}")
+        assert rc == 1
+        res[name] = {"gaf": base64.b64encode(raw).decode(), "bad_line_offset": off, "error": err.split(":")[0]}
+    shutil.rmtree(tmp)
+    with open(f"{out}/cases.json", "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+    print("utf8order:", {k: v["error"] for k, v in res.items()})
+
+
+# ----------------------------------------------------------------------------------------------
 # BASELINE configs at full size: the reference itself on the generated files (minutes to half an hour of one core each)
 # ----------------------------------------------------------------------------------------------
 
@@ -763,7 +800,7 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "lik", "vcf", "synth"]
+    which = sys.argv[1:] or ["testdir", "quirks", "lik", "vcf", "synth", "realshape", "utf8order"]
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))

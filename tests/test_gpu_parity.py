@@ -201,6 +201,25 @@ def test_vcf_cases(golden, tmp_path, tag, ms, err):
     assert p.stdout == open(f"{v}/ref_{tag}.stdout").read()
 
 
+def test_error_order_when_the_gaf_is_not_utf8(ctx, golden, tmp_path):
+    """golden/utf8order through the drop-in filter: the exception class is the reference's (UnicodeDecodeError of the text-mode read
+    against the error of a malformed line, whichever the reference meets first)."""
+    import base64
+    from svjg import filter as flt
+    from svjg.graph import Graph
+    q = f"{golden}/quirks"
+    g = Graph.from_files(f"{q}/q_svs_edges.json", f"{q}/q.gfa")
+    for name, c in json.load(open(f"{golden}/utf8order/cases.json")).items():
+        path = str(tmp_path / (name + ".gaf"))
+        open(path, "wb").write(base64.b64decode(c["gaf"]))
+        with pytest.raises(Exception) as ei:
+            flt.classify_file(ctx, g, path)
+        assert type(ei.value).__name__ == c["error"], name
+        with pytest.raises(Exception) as ei:
+            flt.classify_sharded(g, path, devices=[0])
+        assert type(ei.value).__name__ == c["error"], name
+
+
 def test_out_of_domain_options(golden, tmp_path):
     """-e 0 / -e 1 / -e 1.5: math.log10 raises in the reference's likelihood() (predict-genotype.py:295-297) as soon as a row is
     genotyped; a negative --minsupport genotypes every row like --minsupport 0 (:310).  (Round-1 advice.)"""

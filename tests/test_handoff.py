@@ -70,3 +70,23 @@ def test_handoff_is_bound_to_content_and_owner(golden, tmp_path, monkeypatch):
     assert flt.read_handoff(dst) is None
     flt.write_handoff(dst, sv_ids, counts)                     # ... and nothing is written into such a directory either
     os.chmod(os.path.dirname(p), 0o700)
+
+
+def test_error_order_of_a_file_that_is_not_utf8(golden):
+    """svjg/filter.py: reference_error against golden/utf8order (the reference itself on GAFs that are not UTF-8 and hold a malformed
+    line): it reads the file in text mode in blocks of 8192 bytes, so the UnicodeDecodeError of a block comes before the error of any
+    malformed line that ends in or behind that block, and after the errors of earlier lines."""
+    import base64
+    cases = json.load(open(f"{golden}/utf8order/cases.json"))
+    assert {c["error"] for c in cases.values()} == {"ValueError", "UnicodeDecodeError"}
+    for name, c in cases.items():
+        if c["bad_line_offset"] is None:
+            continue
+        data = np.frombuffer(base64.b64decode(c["gaf"]), dtype=np.uint8)
+        e = ValueError("malformed GAF line")
+        e.svjg_offset = c["bad_line_offset"]                    # (what libsvjg_hip reports through svjg_input_error)
+        assert type(flt.reference_error(data, e)).__name__ == c["error"], name
+    data = np.frombuffer(b"r\t1\t0\n" + b"x\t1\t2\n", dtype=np.uint8)   # pure ASCII: nothing changes
+    e = ValueError("x")
+    e.svjg_offset = 8
+    assert flt.reference_error(data, e) is e
