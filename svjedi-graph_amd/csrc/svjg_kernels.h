@@ -542,10 +542,38 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             const uint32_t totAs = totA[0] + totA[1], totBs = totB[0] + totB[1];
             n_s = totAs & 0xFFFFu; n_own = totAs >> 16;                  // line starts in the text looked at, and how many of them this stripe handles
             tot_ori = totBs;
-            if (attempt || Vh <= HALF || !(n_s > MAXL || tot_ori > CAP_O)) break;
-            // the lists cannot hold the whole stripe: look at its first half only (the next stripe begins inside this one)
-            NL[1] = 0; ORI[1] = 0;
-            Vh = HALF; eof_h = false;
+            if (attempt || !(n_s > MAXL || tot_ori > CAP_O)) break;
+            // The lists cannot hold the whole stripe (more than MAXL lines or CAP_O marks in 8 KB: short lines, paths of many nodes):
+            // the stripe ends at the last line start up to which they can (the next stripe begins there), or, if there is none,
+            // after its first half.  Both limits grow with the position, so the lane and bit to look for are the last that fit.
+            uint32_t best[NHALF];
+#pragma unroll
+            for (uint32_t h = 0; h < NHALF; ++h) {
+                const uint32_t sp = (h * WG + lane) * SPAN;
+                const uint32_t sb = (((h ? totA[0] : 0u) + exA[h]) & 0xFFFFu) + ((h == 0 && lane == 0) ? head : 0u), ob = (h ? totB[0] : 0u) + exB[h];
+                best[h] = 0;
+                for (unsigned long long m = NL[h]; m; m &= m - 1) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                    const uint32_t ord = sb + (uint32_t)__popcll(NL[h] & ((1ull << b) - 1ull));
+                    const uint32_t marks = ob + (uint32_t)__popcll(ORI[h] & ((2ull << b) - 1ull));
+                    if (ord + 1u <= MAXL && marks <= CAP_O && sp + b + 1u <= Vh) best[h] = sp + b + 1u;
+                }
+            }
+            uint32_t cut = 0;
+            {
+                const unsigned long long f1 = ballot64(best[1] != 0), f0 = ballot64(best[0] != 0);
+                if (f1) cut = rdlane(best[1], 63u - (uint32_t)__builtin_clzll(f1));
+                else if (f0) cut = rdlane(best[0], 63u - (uint32_t)__builtin_clzll(f0));
+            }
+            if (cut > own_lo && cut > 16u) Vh = cut;
+            else if (Vh > HALF) Vh = HALF;
+            else break;
+            eof_h = false;
+#pragma unroll
+            for (uint32_t h = 0; h < NHALF; ++h) {                       // nothing at or behind Vh is looked at (the terminator at Vh - 1 stays)
+                const unsigned long long keep = low_bits64(clamp64(Vh, (h * WG + lane) * SPAN));
+                NL[h] &= keep; ORI[h] &= keep;
+            }
         }
         if (!last_stripe) {
             const uint32_t d0 = (uint32_t)((next_pos & ~15ull) - c0);    // the next stripe begins inside (or right behind) this one's staged text
