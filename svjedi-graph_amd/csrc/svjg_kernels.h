@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "svjg_line.h"
+#include "svjg_planes.h"
 
 namespace svjg {
 
@@ -233,67 +234,54 @@ __device__ inline uint32_t xad(uint32_t a, uint32_t b, uint32_t c) {
     return r;
 }
 
-// Phase B1 for one lane: classes of the SPAN bytes at text + slot * SPAN (slot = half * 64 + lane).
+// Phase B1 for one lane: classes of the SPAN bytes at text + slot * SPAN (slot = half * 64 + lane), by bit planes (svjg_planes.h).
 // terminator = '\n', or a '\r' not followed by '\n' (Python universal newlines).
-// ASCII text (every byte < 0x80): (byte ^ c) + 0x7F has bit 7 set exactly where the byte differs from c, with no carries
-// between the byte lanes; (byte ^ '0') + 0x76 has it set exactly where the byte is no digit.
-template <bool ASCII>
+struct SpanFlags {
+    uint32_t high;          // some byte >= 0x80 (per lane)
+    uint32_t idf;           // the byte pair "d:" begins in this lane's spans (per lane)
+    uint32_t dee_last;      // half 0: the span's last byte is 'd' (the ':' would be the next lane's, or the next half's, first byte)
+};
+__device__ inline uint32_t lane_above_or0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }   // wave_shl:1, lane 63 gets 0
 __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t *tbm, uint32_t slot, uint64_t c0, uint32_t V,
-                                     unsigned long long &NL, unsigned long long &ORI) {
+                                     unsigned long long &NL, unsigned long long &ORI, SpanFlags &fl) {
     const uint32_t sp = slot * SPAN;
-    // rotated piece order: the 16-byte LDS reads of a wave hit different banks.  The 16-bit masks are collected in loop
-    // order and the four of a class rotated into place at the end (one 64-bit rotate instead of four shifts).
+    // rotated piece order: the 16-byte LDS reads of a wave hit different banks.  The planes are those of the span rotated by
+    // 16 * rot bytes, so every 64-bit mask is rotated back at the end: a halfword permutation, two v_perm_b32.
     const uint32_t rot = (slot >> 2) & 3u;
-    uint32_t nlm[PIECES], tabm[PIECES], orim[PIECES], ndm[PIECES];
+    uint32_t w[16];
 #pragma unroll
     for (uint32_t c = 0; c < PIECES; ++c) {
-        const uint32_t pc = (c + rot) & 3u;
-        const uint32_t pb = sp + pc * 16;
-        const uint4 v = *(const uint4 *)(text + pb);
-        uint32_t nl, tab, ori, nd;
-        bool has_cr;
-        if (ASCII) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            uint32_t fn[4], ft[4], fo[4], fd[4], crall = 0xFFFFFFFFu;
-            const uint32_t k7f = 0x7F7F7F7Fu, k76 = 0x76767676u;
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                const uint32_t tn = xad(w[k], 0x0A0A0A0Au, k7f), tt = xad(w[k], 0x09090909u, k7f);
-                const uint32_t to = xad(w[k] | 0x02020202u, 0x3E3E3E3Eu, k7f), td = xad(w[k], 0x30303030u, k76);
-                crall &= xad(w[k], 0x0D0D0D0Du, k7f);
-                fn[k] = ~tn & 0x80808080u; ft[k] = ~tt & 0x80808080u; fo[k] = ~to & 0x80808080u;
-                fd[k] = td & tt & 0x80808080u;                             // neither a digit nor a tab
-            }
-            nl = gather16(fn[0], fn[1], fn[2], fn[3]); tab = gather16(ft[0], ft[1], ft[2], ft[3]);
-            ori = gather16(fo[0], fo[1], fo[2], fo[3]); nd = gather16(fd[0], fd[1], fd[2], fd[3]);
-            has_cr = (~crall & 0x80808080u) != 0;
-        } else {
-            nl = eq_mask16(v, 0x0A0A0A0Au); tab = eq_mask16(v, 0x09090909u);
-            ori = eq_mask16(make_uint4(v.x | 0x02020202u, v.y | 0x02020202u, v.z | 0x02020202u, v.w | 0x02020202u), 0x3E3E3E3Eu);
-            const uint32_t dig = gather16(digit_flags_any(v.x), digit_flags_any(v.y), digit_flags_any(v.z), digit_flags_any(v.w));
-            nd = ~(dig | tab) & 0xFFFFu;
-            has_cr = (zero_bytes(v.x ^ 0x0D0D0D0Du) | zero_bytes(v.y ^ 0x0D0D0D0Du) | zero_bytes(v.z ^ 0x0D0D0D0Du) | zero_bytes(v.w ^ 0x0D0D0D0Du)) != 0;
-        }
-        // carriage returns: cheap any-test first (no text file has them in practice)
-        if (has_cr) {
-            uint32_t cr = eq_mask16(v, 0x0D0D0D0Du);
-            while (cr) {
-                uint32_t b = __builtin_ctz(cr); cr &= cr - 1;
-                uint32_t q = pb + b;
-                const uint32_t staged = (slot / WG + 1u) * HALF;          // (the half behind this one may not be in LDS yet)
-                uint8_t nx = (q + 1 < staged) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
-                if (nx != '\n') nl |= 1u << b;
-            }
-        }
-        nlm[c] = nl; tabm[c] = tab; orim[c] = ori; ndm[c] = nd;
-        asm volatile("" : "+v"(nlm[c]), "+v"(tabm[c]), "+v"(orim[c]), "+v"(ndm[c]));   // (a piece's masks are finished before the next piece's flag words pile up in registers)
+        const uint4 v = *(const uint4 *)(text + sp + ((c + rot) & 3u) * 16);
+        w[c * 4 + 0] = v.x; w[c * 4 + 1] = v.y; w[c * 4 + 2] = v.z; w[c * 4 + 3] = v.w;
     }
-    auto place = [&](const uint32_t (&m)[PIECES]) -> unsigned long long {      // piece c of the loop sits at 16-bit position (c + rot) & 3
-        const unsigned long long x = (unsigned long long)(m[0] | (m[1] << 16)) | ((unsigned long long)(m[2] | (m[3] << 16)) << 32);
-        return __builtin_rotateleft64(x, 16u * rot);
+    span_planes(w);
+    const HalfClasses lo = half_classes(w), hi = half_classes(w + 8);
+    const uint32_t sel_lo = (0x0B0A0908u - 0x02020202u * rot) & 0x07070707u, sel_hi = sel_lo ^ 0x04040404u;   // halfword t of the result = halfword (t - rot) & 3
+    auto place = [&](uint32_t l, uint32_t h) -> unsigned long long {
+        return (unsigned long long)perm_b32(h, l, sel_lo) | ((unsigned long long)perm_b32(h, l, sel_hi) << 32);
     };
-    unsigned long long nl64 = place(nlm);
-    const unsigned long long tab64 = place(tabm), ori64 = place(orim), nd64 = place(ndm);
+    unsigned long long nl64 = place(lo.nl, hi.nl);
+    const unsigned long long tab64 = place(lo.tab, hi.tab), ori64 = place(lo.ori, hi.ori), nd64 = place(lo.nd, hi.nd);
+    fl.high |= lo.high | hi.high;
+    // "d:" — the pair may straddle the span's end: the next lane's first byte comes by DPP, the next half's is looked at by the caller
+    {
+        const unsigned long long dee = place(lo.dee, hi.dee), col = place(lo.colon, hi.colon);
+        const uint32_t nxt = lane_above_or0((uint32_t)col);
+        const uint32_t s_lo = __builtin_amdgcn_alignbit((uint32_t)(col >> 32), (uint32_t)col, 1), s_hi = __builtin_amdgcn_alignbit(nxt, (uint32_t)(col >> 32), 1);
+        fl.idf |= ((uint32_t)dee & s_lo) | ((uint32_t)(dee >> 32) & s_hi);
+        fl.dee_last = (uint32_t)(dee >> 63);
+    }
+    // carriage returns (no text file has them in practice)
+    if ((lo.cr | hi.cr) != 0) {
+        unsigned long long cr = place(lo.cr, hi.cr);
+        while (cr) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(cr); cr &= cr - 1;
+            const uint32_t q = sp + b;
+            const uint32_t staged = (slot / WG + 1u) * HALF;              // (the half behind this one may not be in LDS yet)
+            const uint8_t nx = (q + 1 < staged) ? text[q + 1] : ((c0 + q + 1 < a.n_bytes) ? a.gaf[c0 + q + 1] : 0);
+            if (nx != '\n') nl64 |= 1ull << b;
+        }
+    }
     if (sp + SPAN > V) nl64 &= sp >= V ? 0ull : ((1ull << (V - sp)) - 1ull);   // ignore anything at or beyond the valid length
     *(uint2 *)(ndbm + slot * 2) = make_uint2((uint32_t)nd64, (uint32_t)(nd64 >> 32));
     *(uint2 *)(tbm + slot * 2) = make_uint2((uint32_t)tab64, (uint32_t)(tab64 >> 32));
@@ -464,30 +452,27 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (unsigned long long)TEXT) ? (a.n_bytes - c0) : (unsigned long long)TEXT);   // valid bytes staged
         const bool at_eof = c0 + V == a.n_bytes;
 
-        // ---- A / B1, half by half: registers -> LDS; bytes >= 0x80 and the "id:f:" filter on the registers; byte classes --------
+        // ---- A / B1, half by half: registers -> LDS, then the byte classes of the staged half (which also tell bytes >= 0x80 and
+        //      the "id:f:" filter: every such tag holds the byte pair "d:"; a hit sends the stripe's lines to the exact path) ----------
         const uint32_t head_byte = pf_head;
-        uint32_t idf_id = 0xFFFFFFFFu, idf_dc = 0xFFFFFFFFu;
         unsigned long long NL[NHALF], ORI[NHALF];
+        SpanFlags fl = {0u, 0u, 0u};
+        uint32_t dee_end = 0;                                            // wave-uniform: the first half ends with 'd'
+        bool idf_x = false;                                              // ... and the second half begins with ':'
 #pragma unroll
         for (uint32_t h = 0; h < NHALF; ++h) {
             __builtin_amdgcn_s_setprio(P_A);
-            uint32_t hi_bits = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < NPF; ++i) {
-                hi_bits |= pf[i].x | pf[i].y | pf[i].z | pf[i].w;
-                *(uint4 *)(text + h * HALF + (i * WG + lane) * 16) = pf[i];
-                idf_piece(pf[i], idf_id, idf_dc);
-            }
+            for (uint32_t i = 0; i < NPF; ++i) *(uint4 *)(text + h * HALF + (i * WG + lane) * 16) = pf[i];
             if (h + 1 < NHALF) fetch_half(c0 + (h + 1) * HALF);           // the next half travels while this one is classified
-            const bool ascii = ballot64((hi_bits & 0x80808080u) != 0) == 0;   // wave-uniform: the cheaper SWAR classes apply
-            if (!ascii && lane == 0) a.st->non_ascii = 1;
             wave_sync();
             __builtin_amdgcn_s_setprio(0);
-            if (ascii) classify_span<true>(a, text, ndbm, tbm, h * WG + lane, c0, V, NL[h], ORI[h]);
-            else classify_span<false>(a, text, ndbm, tbm, h * WG + lane, c0, V, NL[h], ORI[h]);
+            classify_span(a, text, ndbm, tbm, h * WG + lane, c0, V, NL[h], ORI[h], fl);
+            if (h == 0) dee_end = rdlane(fl.dee_last, WG - 1);
+            else idf_x = dee_end != 0 && text[HALF] == ':';
         }
-        // a 16-bit half of a running minimum is zero <=> some aligned halfword matched
-        const bool idf = ballot64(((((idf_id - 0x00010001u) & ~idf_id) | ((idf_dc - 0x00010001u) & ~idf_dc)) & 0x80008000u) != 0) != 0;
+        if (ballot64(fl.high != 0) != 0 && lane == 0) a.st->non_ascii = 1;
+        const bool idf = idf_x || ballot64(fl.idf != 0) != 0;
         tick(0);
         // does the stripe begin at a line start?  (wave-uniform)
         const uint32_t head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');

@@ -6,6 +6,8 @@
 #define SVJG_HD inline
 #include "../../svjedi-graph_amd/csrc/svjg_line.h"
 #include "../../svjedi-graph_amd/csrc/svjg_host_tables.h"
+#include "../../svjedi-graph_amd/csrc/svjg_planes.h"
+#include <cstring>
 #include <vector>
 
 using namespace svjg;
@@ -155,4 +157,19 @@ extern "C" void hostsim_table_stats(const svjg_graph *g, uint64_t *out) {
     out[5] = kt.link_mask + 1ull; out[6] = kt.ihits.size();
     uint64_t mx = 0; for (uint16_t d : kt.disp) if (d > mx) mx = d;
     out[7] = mx;
+}
+
+// byte classes of n 64-byte spans by bit planes (svjg_planes.h, phase B1 of the main kernel): out = 8 masks of 64 bits per span
+// (nl, cr, tab, ori, nd, dee, colon, high)
+extern "C" void hostsim_span_classes(const uint8_t *text, uint64_t n_spans, uint64_t *out) {
+    for (uint64_t s = 0; s < n_spans; ++s) {
+        uint32_t w[16];
+        memcpy(w, text + s * 64, 64);
+        span_planes(w);
+        const HalfClasses lo = half_classes(w), hi = half_classes(w + 8);
+        uint64_t *o = out + s * 8;
+        o[0] = lo.nl | ((uint64_t)hi.nl << 32); o[1] = lo.cr | ((uint64_t)hi.cr << 32); o[2] = lo.tab | ((uint64_t)hi.tab << 32);
+        o[3] = lo.ori | ((uint64_t)hi.ori << 32); o[4] = lo.nd | ((uint64_t)hi.nd << 32); o[5] = lo.dee | ((uint64_t)hi.dee << 32);
+        o[6] = lo.colon | ((uint64_t)hi.colon << 32); o[7] = lo.high | ((uint64_t)hi.high << 32);
+    }
 }

@@ -14,6 +14,7 @@ def build():
     src = [os.path.join(HERE, "hostsim.cpp"),
            os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_line.h"),
            os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_host_tables.h"),
+           os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_planes.h"),
            os.path.join(HERE, "..", "..", "include", "svjg.h")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in src):
         subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-shared", "-fPIC", "-o", SO, src[0]], check=True)
@@ -64,3 +65,16 @@ def table_stats(graph):
     lib.hostsim_table_stats.restype = None
     lib.hostsim_table_stats(ctypes.byref(cg), out)
     return tuple(int(x) for x in out)
+
+
+def span_classes(text):
+    """Byte-class masks of the 64-byte spans of text (len % 64 == 0) by the main kernel's bit-plane routine:
+    uint64[n_spans, 8] = nl, cr, tab, ori, nd, dee, colon, high."""
+    lib = ctypes.CDLL(build())
+    buf = np.frombuffer(bytes(text), dtype=np.uint8)
+    assert buf.size % 64 == 0
+    out = np.zeros((buf.size // 64, 8), np.uint64)
+    lib.hostsim_span_classes.restype = None
+    lib.hostsim_span_classes.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    lib.hostsim_span_classes(buf.ctypes.data, buf.size // 64, out.ctypes.data)
+    return out

@@ -74,3 +74,24 @@ def test_synth(golden, tag, tmp_path):
     c_or, _, n2 = orc.filter(cut, want_hits=False)
     assert n_lines == n2
     assert _as_dict(g, counts) == {sv: [int(c_or[i, 0]), int(c_or[i, 1])] for i, sv in enumerate(orc.sv_ids) if c_or[i].sum()}
+
+
+def test_byte_classes_by_bit_planes():
+    """svjg_planes.h (phase B1 of the main kernel): the masks the transposed planes give are those of a byte loop —
+    every byte value at every position of a span, GAF-like text, random bytes."""
+    rng = np.random.default_rng(7)
+    every = np.concatenate([np.roll(np.arange(256, dtype=np.uint8), k) for k in range(64)])          # 256 spans: every value at every position
+    gaf = np.frombuffer((b"read/1\t1000\t10\t990\t+\t>chr1:0-5000<chr1:5000.1>chr1:5000-9000\t9000\t1\t981\t900\t980\t60\tid:f:0.9\tcg:Z:5=\r\n" * 40)[:64 * 60], dtype=np.uint8)
+    rnd = rng.integers(0, 256, 64 * 4096, dtype=np.uint8)
+    few = rng.choice(np.frombuffer(b"\n\r\t<>=;:d09/e", dtype=np.uint8), 64 * 1024)
+    text = np.concatenate([every, gaf, rnd, few])
+    got = sim.span_classes(text.tobytes())
+    b = text.reshape(-1, 64)
+    wt = np.uint64(1) << np.arange(64, dtype=np.uint64)
+
+    def mask(sel):
+        return (sel.astype(np.uint64) * wt).sum(axis=1, dtype=np.uint64)
+    digit = (b >= 0x30) & (b <= 0x39)
+    want = [b == 0x0A, b == 0x0D, b == 0x09, (b == 0x3C) | (b == 0x3E), ~(digit | (b == 0x09)), b == 0x64, b == 0x3A, b >= 0x80]
+    for k, sel in enumerate(want):
+        assert np.array_equal(got[:, k], mask(sel)), k
