@@ -108,16 +108,29 @@ template <bool ASCII> __device__ inline bool any_byte_t(uint4 v, uint32_t pat) {
 }
 
 // Wave prefix sums without LDS traffic: DPP row shifts inside the four rows of 16 lanes, then the row totals are
-// broadcast into the following rows (row_bcast:15 / row_bcast:31), six VALU operations in all.
+// broadcast into the following rows (row_bcast:15 / row_bcast:31): six v_add_u32_dpp.  Written out: from the builtins the compiler
+// makes three instructions per step (clear, v_mov_b32_dpp, add).  (s_nop: a DPP operand written by the instruction before needs
+// two wait states on gfx9, and the hazard pass does not look into inline assembly.)
 __device__ inline uint32_t wave_incl_scan(uint32_t v) {
     uint32_t x = v;
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);     // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);     // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);     // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);     // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(x));
     return x;
+}
+// two of them, interleaved (each fills one of the other's wait states)
+__device__ inline void wave_incl_scan2(uint32_t &x, uint32_t &y) {
+#define SVJG_STEP(ctl) "s_nop 0\n\tv_add_u32_dpp %0, %0, %0 " ctl "\n\tv_add_u32_dpp %1, %1, %1 " ctl "\n\t"
+    asm("s_nop 0\n\t"
+        SVJG_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") SVJG_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SVJG_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0") SVJG_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SVJG_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") SVJG_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(x), "+v"(y));
+#undef SVJG_STEP
 }
 // ballot without the bool -> int detour of __ballot (one v_cmp into an SGPR pair), value of a lane whose number is wave-uniform
 __device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -144,30 +157,24 @@ __device__ inline uint32_t name_word_mask(int32_t bits) {
     const uint32_t n = (uint32_t)(bits < 0 ? 0 : bits > 32 ? 32 : bits);       // (one v_med3_i32)
     return (uint32_t)((0xFFFFFFFFull << n) >> 32);
 }
+typedef uint32_t u32_any __attribute__((aligned(1)));                   // LDS words at any byte address (gfx950 reads them as they are: tools/ubench/lds_unaligned.hip)
 __device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
-    const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
-    const uint32_t sh = a0 & 3u;
-    uint32_t prev = w[0];
+    const u32_any *w = (const u32_any *)(text + a0);
     uint64_t h = (uint64_t)L * 0x7FEB352Du;
     const uint32_t C[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du};
     d[6] = 0u; d[7] = 0u;
     const int32_t bits = (int32_t)(8u * L);
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
-        const uint32_t nx = w[i + 1];
-        const uint32_t x = __builtin_amdgcn_alignbyte(nx, prev, sh);
-        d[i] = x & name_word_mask(bits - 32 * (int32_t)i);
-        prev = nx;
+        d[i] = w[i] & name_word_mask(bits - 32 * (int32_t)i);
         h += (uint64_t)d[i] * C[i];
     }
     return h;
 }
 __device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
-    const uint32_t *w = (const uint32_t *)(text + (a0 & ~3u));
-    const uint32_t sh = a0 & 3u;
-    const uint32_t w6 = w[6], w7 = w[7], w8 = w[8];
+    const u32_any *w = (const u32_any *)(text + a0);
     const int32_t bits = (int32_t)(8u * L);
-    const uint32_t x6 = __builtin_amdgcn_alignbyte(w7, w6, sh), x7 = __builtin_amdgcn_alignbyte(w8, w7, sh);
+    const uint32_t x6 = w[6], x7 = w[7];
     d[6] = x6 & name_word_mask(bits - 192);
     d[7] = x7 & name_word_mask(bits - 224);
     return (uint64_t)d[6] * 0xFD7046C5u + (uint64_t)d[7] * 0xB55A4F09u;
@@ -288,13 +295,12 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
     NL = nl64; ORI = ori64;
 }
 
-// decimal column text[a, a + n), 1 <= n <= 9, known to hold digits only -> value.  Straight-line SWAR on three aligned
-// LDS words: digits folded pairwise (no per-digit loop, no divergence).
+// decimal column text[a, a + n), 1 <= n <= 9, known to hold digits only -> value.  Straight-line SWAR on its first eight
+// bytes: digits folded pairwise (no per-digit loop, no divergence).
 __device__ inline uint32_t field_val(const uint8_t *text, uint32_t a, uint32_t n) {
-    const uint32_t *w = (const uint32_t *)(text + (a & ~3u));
-    const uint32_t sh = a & 3u, d0 = w[0], d1 = w[1], d2 = w[2];
-    const uint32_t lo0 = __builtin_amdgcn_alignbyte(d1, d0, sh) & 0x0F0F0F0Fu;        // chars a .. a+3 as digit values
-    const uint32_t hi0 = __builtin_amdgcn_alignbyte(d2, d1, sh) & 0x0F0F0F0Fu;        // chars a+4 .. a+7
+    const u32_any *w = (const u32_any *)(text + a);
+    const uint32_t lo0 = w[0] & 0x0F0F0F0Fu;                              // chars a .. a+3 as digit values
+    const uint32_t hi0 = w[1] & 0x0F0F0F0Fu;                              // chars a+4 .. a+7
     const uint32_t n8 = n < 8 ? n : 8;
     // the first n8 bytes move to the top of the 64-bit (hi:lo): what follows the column drops out, leading bytes are zero digits
     const unsigned long long x = (((unsigned long long)hi0 << 32) | lo0) << ((8 * (8 - n8)) & 63u);
@@ -308,9 +314,8 @@ __device__ inline uint32_t field_val(const uint8_t *text, uint32_t a, uint32_t n
 
 // the same column is zero (every digit a '0')
 __device__ inline bool field_is_zero(const uint8_t *text, uint32_t a, uint32_t n) {
-    const uint32_t *w = (const uint32_t *)(text + (a & ~3u));
-    const uint32_t sh = a & 3u, d0 = w[0], d1 = w[1], d2 = w[2];
-    const uint32_t lo0 = __builtin_amdgcn_alignbyte(d1, d0, sh) & 0x0F0F0F0Fu, hi0 = __builtin_amdgcn_alignbyte(d2, d1, sh) & 0x0F0F0F0Fu;
+    const u32_any *w = (const u32_any *)(text + a);
+    const uint32_t lo0 = w[0] & 0x0F0F0F0Fu, hi0 = w[1] & 0x0F0F0F0Fu;
     const uint32_t n8 = n < 8 ? n : 8;
     const unsigned long long x = (((unsigned long long)hi0 << 32) | lo0) << ((8 * (8 - n8)) & 63u);
     return x == 0 && (n < 9 || ((uint32_t)text[a + 8] & 0xFu) == 0);
@@ -481,8 +486,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         uint32_t lim2, n_s, n_own, tot_ori, l_first;
         bool last_stripe, long_line;
         unsigned long long next_pos;
-        unsigned long long OWN[NHALF];
-        uint32_t exA[NHALF], exB[NHALF], totA[NHALF], totB[NHALF];
+        uint32_t RK[NHALF];                                              // ordinal of the lane's first terminator | of its first mark << 16, per half
         uint32_t head_own;
         for (uint32_t attempt = 0;; ++attempt) {
             // the last line start in the text looked at (a terminator at b starts a line at b + 1)
@@ -510,23 +514,27 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             else long_line = true;                                       // a single line longer than the text looked at: exact path
             if (next_pos >= rend) last_stripe = true;
 
-            // counts and wave prefix sums; a terminator at sp + b starts a line at sp + b + 1, owned if that lies in [own_lo, lim2)
+            // terminators and marks per lane and half -> their ordinals in the stripe: two wave prefix sums of two 16-bit fields each
+            // (a half holds at most 4096 of either).  The line at the stripe's head is counted by lane 0.
+            uint32_t in0 = ((uint32_t)__popcll(NL[0]) + (lane == 0 ? head : 0u)) | ((uint32_t)__popcll(ORI[0]) << 16);
+            uint32_t in1 = (uint32_t)__popcll(NL[1]) | ((uint32_t)__popcll(ORI[1]) << 16);
+            const uint32_t c0v = in0, c1v = in1;
+            wave_incl_scan2(in0, in1);
+            const uint32_t tot0 = rdlane(in0, WG - 1), tots = tot0 + rdlane(in1, WG - 1);
+            RK[0] = in0 - c0v; RK[1] = tot0 + in1 - c1v;
+            n_s = tots & 0xFFFFu; tot_ori = tots >> 16;                  // line starts and marks in the text looked at
+            // line starts in front of position x (wave-uniform, x <= Vh): those this stripe handles lie in [own_lo, lim2)
+            auto starts_before = [&](uint32_t x) -> uint32_t {
+                if (x == 0) return 0u;
+                const uint32_t q = x - 1u, slot = q >> 6, hh = slot >> 6, L = slot & 63u;   // terminators in front of q count
+                const uint32_t rk = rdlane(hh ? RK[1] : RK[0], L) & 0xFFFFu;
+                const uint32_t mlo = rdlane((uint32_t)(hh ? NL[1] : NL[0]), L), mhi = rdlane((uint32_t)((hh ? NL[1] : NL[0]) >> 32), L);
+                const unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & ((1ull << (q & 63u)) - 1ull);
+                return rk + (uint32_t)__popcll(m) + (slot == 0 ? head : 0u);
+            };
+            l_first = starts_before(own_lo);
+            n_own = starts_before(lim2) - l_first;
             head_own = head & (uint32_t)(own_lo == 0 && 0 < lim2);
-            l_first = 0;
-#pragma unroll
-            for (uint32_t h = 0; h < NHALF; ++h) {
-                const uint32_t sp = (h * WG + lane) * SPAN;
-                const unsigned long long below_lo = low_bits64(clamp64(own_lo, sp + 1));
-                OWN[h] = NL[h] & low_bits64(clamp64(lim2, sp + 1)) & ~below_lo;
-                const uint32_t hd = (h == 0 && lane == 0) ? head : 0u, hdo = (h == 0 && lane == 0) ? head_own : 0u;
-                if (h == 0) l_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)((head & (uint32_t)(0 < own_lo)) + (uint32_t)__popcll(NL[0] & below_lo)));   // (own_lo < 16: only lane 0 can see such starts)
-                const uint32_t cA = ((uint32_t)__popcll(NL[h]) + hd) | (((uint32_t)__popcll(OWN[h]) + hdo) << 16);
-                const uint32_t cB = (uint32_t)__popcll(ORI[h]);
-                exA[h] = wave_excl_scan(cA, totA[h]); exB[h] = wave_excl_scan(cB, totB[h]);
-            }
-            const uint32_t totAs = totA[0] + totA[1], totBs = totB[0] + totB[1];
-            n_s = totAs & 0xFFFFu; n_own = totAs >> 16;                  // line starts in the text looked at, and how many of them this stripe handles
-            tot_ori = totBs;
             if (attempt || !(n_s > MAXL || tot_ori > CAP_O)) break;
             // The lists cannot hold the whole stripe (more than MAXL lines or CAP_O marks in 8 KB: short lines, paths of many nodes):
             // the stripe ends at the last line start up to which they can (the next stripe begins there), or, if there is none,
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
 #pragma unroll
             for (uint32_t h = 0; h < NHALF; ++h) {
                 const uint32_t sp = (h * WG + lane) * SPAN;
-                const uint32_t sb = (((h ? totA[0] : 0u) + exA[h]) & 0xFFFFu) + ((h == 0 && lane == 0) ? head : 0u), ob = (h ? totB[0] : 0u) + exB[h];
+                const uint32_t sb = (RK[h] & 0xFFFFu) + ((h == 0 && lane == 0) ? head : 0u), ob = RK[h] >> 16;
                 best[h] = 0;
                 for (unsigned long long m = NL[h]; m; m &= m - 1) {
                     const uint32_t b = (uint32_t)__builtin_ctzll(m);
@@ -573,12 +581,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 unsigned long long dbase = 0;
                 if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)n_own);
                 dbase = __shfl(dbase, 0);
+                if (lane == 0 && head_own) { if (dbase < a.deferred_cap) a.deferred[dbase] = c0; else atomicOr(&a.st->overflow, 1u); }   // (ordinal 0 = l_first)
 #pragma unroll
-                for (uint32_t h = 0; h < NHALF; ++h) {
+                for (uint32_t h = 0; h < NHALF; ++h) {                   // the owned starts are the ordinals [l_first, l_first + n_own)
                     const uint32_t sp = (h * WG + lane) * SPAN;
-                    unsigned long long d = dbase + (((h ? totA[0] : 0u) + exA[h]) >> 16);
-                    if (h == 0 && lane == 0 && head_own) { if (d < a.deferred_cap) a.deferred[d] = c0; else atomicOr(&a.st->overflow, 1u); ++d; }
-                    for (unsigned long long m = OWN[h]; m; m &= m - 1, ++d) {
+                    uint32_t j = (RK[h] & 0xFFFFu) + ((h == 0 && lane == 0) ? head : 0u) - l_first;
+                    for (unsigned long long m = NL[h]; m; m &= m - 1, ++j) {
+                        if (j >= n_own) continue;                        // (unsigned: also the starts in front of l_first)
+                        const unsigned long long d = dbase + j;
                         if (d < a.deferred_cap) a.deferred[d] = c0 + sp + (uint32_t)__builtin_ctzll(m) + 1u; else atomicOr(&a.st->overflow, 1u);
                     }
                 }
@@ -600,19 +610,27 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
 #pragma unroll
         for (uint32_t h = 0; h < NHALF; ++h) {
             const uint32_t sp = (h * WG + lane) * SPAN;
-            const uint32_t bA = (h ? totA[0] : 0u) + exA[h];
-            const uint32_t sb = (bA & 0xFFFFu) + ((h == 0 && lane == 0) ? head : 0u);   // ordinal of the first line start this lane creates
-            const uint32_t ob = (h ? totB[0] : 0u) + exB[h];
+            const uint32_t sb = (RK[h] & 0xFFFFu) + ((h == 0 && lane == 0) ? head : 0u);   // ordinal of the first line start this lane creates
+            const uint32_t ob = RK[h] >> 16;
             uint32_t j = sb;
             for (unsigned long long m = NL[h]; m; m &= m - 1, ++j) {
                 const uint32_t b = (uint32_t)__builtin_ctzll(m);
                 LINE[j] = (sp + b + 1) | ((ob + (uint32_t)__popcll(ORI[h] & ((1ull << b) - 1ull))) << 16);
             }
             j = ob;
-            for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {       // (32-bit halves were measured: more loops, more instructions)
-                const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                // line that holds the mark; 0xFFFF: tail of a line of the previous stripe
-                OPL[j] = (sp + b) | ((sb + (uint32_t)__popcll(NL[h] & ((1ull << b) - 1ull)) - 1u) << 16);
+            // line that holds the mark; 0xFFFF: tail of a line of the previous stripe.  (32-bit halves were measured: more loops, more instructions)
+            if (ballot64((NL[h] & (NL[h] - 1ull)) != 0) == 0) {            // wave-uniform: no span holds two terminators (lines of 64 bytes and more)
+                const uint32_t t1 = NL[h] ? (uint32_t)__builtin_ctzll(NL[h]) : 64u;
+                const uint32_t v0 = sp + ((sb - 1u) << 16);
+                for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                    OPL[j] = v0 + b + (b > t1 ? 0x10000u : 0u);
+                }
+            } else {
+                for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                    OPL[j] = (sp + b) | ((sb + (uint32_t)__popcll(NL[h] & ((1ull << b) - 1ull)) - 1u) << 16);
+                }
             }
         }
         wave_sync();
