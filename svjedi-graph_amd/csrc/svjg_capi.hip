@@ -375,9 +375,10 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         const uint64_t n_def = c->hs().n_deferred;
 #ifdef SVJG_TIMING
         if (a.diag & 16u) {
-            unsigned long long d[8];
+            unsigned long long d[12];
             HIPCHK(c, hipMemcpy(d, c->d_dbg, sizeof d, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A %llu  B1 %llu  B2 %llu  R1 %llu  NP-load %llu  NP-scan %llu  NP-link %llu  R6+end %llu\n", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+            fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A+B1 %llu  prefix %llu  B2 %llu  R1 %llu  NP: lists %llu  names+disp %llu  records %llu  scan+search %llu  links+atomics %llu  R6+end %llu\n",
+                    d[0], d[1], d[2], d[3], d[8], d[9], d[4], d[5], d[6], d[7]);
         }
 #endif
         c->ms_slow = 0;

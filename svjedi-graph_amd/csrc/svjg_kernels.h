@@ -2,8 +2,8 @@
 // work bounded by HBM reads.
 //
 //   k_classify_main  persistent single-wave workers over 8 KB stripes of GAF text (see the comment in front of the kernel):
-//                      coalesced HBM -> register -> LDS staging, SWAR byte classes, rank-indexed lists of line
-//                      starts / tabs / orientation marks, then loop-free per-line, per-node and per-link phases with
+//                      coalesced HBM -> register -> LDS staging, byte classes by bit planes (svjg_planes.h), rank-indexed
+//                      lists of line starts / orientation marks, then loop-free per-line, per-node and per-link phases with
 //                      a perfect-hash node-record table, packed 64-bit (ref | alt << 32) atomics into the per-SV count vector
 //   k_classify_slow  one lane per deferred line, exact string path (svjg::slow_line) on an LDS copy of the line
 //   k_logfact_*      log10(i!) table in double-double for the binomial term
@@ -79,32 +79,15 @@ struct ClassifyArgs {
     unsigned long long *dbg;             // measurement only (SVJG_DIAG & 16): per-phase cycle sums of lane 0 of every worker
 };
 
+// (the exact-path kernels look for a line's end with these)
 __device__ inline uint32_t zero_bytes(uint32_t t) {                    // 0x80 in every byte of t that is zero (exact)
     return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
 }
-__device__ inline uint32_t movemask4(uint32_t m) { return (((m >> 7) * 0x00204081u) >> 21) & 0xFu; }
 __device__ inline uint32_t eq_mask16(uint4 v, uint32_t pat) {          // 16-bit mask of bytes equal to pat's byte
     // byte flags (0x80 / 0x00) gathered with two chained v_dot4_u32_u8 per half: weights 1,2,4,8 / 16,32,64,128
     const uint32_t lo = __builtin_amdgcn_udot4(zero_bytes(v.x ^ pat), 0x08040201u, __builtin_amdgcn_udot4(zero_bytes(v.y ^ pat), 0x80402010u, 0u, false), false);
     const uint32_t hi = __builtin_amdgcn_udot4(zero_bytes(v.z ^ pat), 0x08040201u, __builtin_amdgcn_udot4(zero_bytes(v.w ^ pat), 0x80402010u, 0u, false), false);
     return (lo | (hi << 8)) >> 7;
-}
-
-// The same for text known to be pure ASCII (every byte < 0x80: no carries between the byte lanes of the SWAR add), four
-// operations per word instead of six.  `pat` bytes must be < 0x80 too.
-__device__ inline uint32_t ne_flags_ascii(uint32_t w, uint32_t pat) { return ((w ^ pat) + 0x7F7F7F7Fu) & 0x80808080u; }   // 0x80 where the byte differs
-__device__ inline uint32_t eq_mask16_ascii(uint4 v, uint32_t pat) {
-    const uint32_t lo = __builtin_amdgcn_udot4(ne_flags_ascii(v.x, pat), 0x08040201u, __builtin_amdgcn_udot4(ne_flags_ascii(v.y, pat), 0x80402010u, 0u, false), false);
-    const uint32_t hi = __builtin_amdgcn_udot4(ne_flags_ascii(v.z, pat), 0x08040201u, __builtin_amdgcn_udot4(ne_flags_ascii(v.w, pat), 0x80402010u, 0u, false), false);
-    return ~((lo | (hi << 8)) >> 7) & 0xFFFFu;
-}
-template <bool ASCII> __device__ inline uint32_t eq_mask16_t(uint4 v, uint32_t pat) { return ASCII ? eq_mask16_ascii(v, pat) : eq_mask16(v, pat); }
-template <bool ASCII> __device__ inline bool any_byte_t(uint4 v, uint32_t pat) {
-    if (ASCII) {
-        const uint32_t all = ((v.x ^ pat) + 0x7F7F7F7Fu) & ((v.y ^ pat) + 0x7F7F7F7Fu) & ((v.z ^ pat) + 0x7F7F7F7Fu) & ((v.w ^ pat) + 0x7F7F7F7Fu);
-        return (~all & 0x80808080u) != 0;
-    }
-    return (zero_bytes(v.x ^ pat) | zero_bytes(v.y ^ pat) | zero_bytes(v.z ^ pat) | zero_bytes(v.w ^ pat)) != 0;
 }
 
 // Wave prefix sums without LDS traffic: DPP row shifts inside the four rows of 16 lanes, then the row totals are
@@ -204,42 +187,24 @@ __device__ inline void wave_sync() {
 // are issued into registers as soon as its start is known (right after the byte classes), so the only HBM read of the text
 // overlaps the line and node phases.  Waves of a CU drift apart, so the dense byte classification of one fills the issue
 // slots another leaves while it waits for LDS / table round trips.  Per stripe:
-//   A   registers -> LDS (16 B per lane and piece, coalesced on the HBM side); on the registers: "any byte >= 0x80" and the
-//       "id:f:" filter (four sliding 4-byte SADs per piece against "d:f:")
-//   B1  two 64-byte SPANs per lane, branch-free SWAR classification of every byte: 64-bit masks of line terminators,
-//       tabs and orientation marks ('<' '>') in registers, the "neither digit nor tab" bitmap -> LDS; wave prefix sums
-//   B2  every terminator / tab / mark knows its ordinal in the stripe: rank-indexed lists -> LDS
-//         LINE[l] = start of line l, tabs and marks in front of it      TP[t]  position of tab t
+//   A   registers -> LDS (16 B per lane and piece, coalesced on the HBM side)
+//   B1  two 64-byte SPANs per lane: the span's sixteen words are transposed into eight bit planes (svjg_planes.h) and every byte
+//       class is a boolean function of the planes: 64-bit masks of line terminators and orientation marks ('<' '>') in registers,
+//       the bitmaps "tab" and "neither digit nor tab" -> LDS; also "any byte >= 0x80" and the "id:f:" filter (the pair "d:");
+//       wave prefix sums of the counts
+//   B2  every terminator / mark knows its ordinal in the stripe: rank-indexed lists -> LDS
+//         LINE[l] = start of line l, marks in front of it
 //         OPL[o]  = position of mark o | line that holds it << 16
 //   then in rounds of up to 64 lines
-//   (no loops over bytes or bits from here on: a line's j-th tab is TP[LT[l] + j], its j-th node starts at OP[LO[l] + j]):
-//   R1 one LINE per lane: twelve column boundaries, column lengths, digits-only test on the bitmap, the four decimal
-//      values that matter (Tlen, Ts, Te, Alen), path geometry
+//   (no loops over bytes or bits from here on: a line's columns are found on the tab bitmap, its j-th node starts at OPL[marks in front of the line + j]):
+//   R1 one LINE per lane: twelve column boundaries, column lengths, digits-only test on the bitmap, the decimal
+//      values that matter (Tlen, Ts, Te; Alen only as "zero or not"), path geometry
 //   NP node passes over up to 64 consecutive marks covering whole lines, one path NODE per lane, everything in registers:
 //      name -> the bucket's displacement -> the ONE record the name can be in (perfect hash); then id / length, running path
 //      length by a wave scan, first occurrence of every name (the reference's list.index / str.split
-//      quirks) by wave shuffles, overlap test, link among the record's inline links (link table on a miss), one 64-bit
+//      quirks) by DPP wave shifts, overlap test, link among the record's inline links (link table on a miss), one 64-bit
 //      atomic (ref | alt << 32) per hit, optional hit records
 //   R6 deferred-line offsets, one aggregated atomic per wave
-
-// 0x80 in every byte of w that is an ASCII digit (text that may hold bytes >= 0x80)
-__device__ inline uint32_t digit_flags_any(uint32_t w) {
-    const uint32_t t = w ^ 0x30303030u;                                                 // digit <=> high nibble 0 and low nibble < 10
-    return zero_bytes(t & 0xF0F0F0F0u) & ((~((t & 0x0F0F0F0Fu) + 0x06060606u) & 0x10101010u) << 3);
-}
-// 16-bit mask from four words of 0x80 / 0x00 byte flags
-__device__ inline uint32_t gather16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
-    const uint32_t lo = __builtin_amdgcn_udot4(f0, 0x08040201u, __builtin_amdgcn_udot4(f1, 0x80402010u, 0u, false), false);
-    const uint32_t hi = __builtin_amdgcn_udot4(f2, 0x08040201u, __builtin_amdgcn_udot4(f3, 0x80402010u, 0u, false), false);
-    return (lo | (hi << 8)) >> 7;
-}
-
-// (a ^ b) + c in one instruction (v_xad_u32; VOP3 takes no literals on gfx950: b travels in an SGPR, c in a VGPR)
-__device__ inline uint32_t xad(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
-    return r;
-}
 
 // Phase B1 for one lane: classes of the SPAN bytes at text + slot * SPAN (slot = half * 64 + lane), by bit planes (svjg_planes.h).
 // terminator = '\n', or a '\r' not followed by '\n' (Python universal newlines).
@@ -358,22 +323,8 @@ __device__ inline uint32_t tab_from(const uint32_t *tbm, uint32_t p, uint32_t li
 }
 
 // "id:f:" anywhere in a line changes what the reference does with it (filter-alignments.py:193-196: float() of the tag value may
-// raise, Alen == 0 no longer does): such lines take the exact path.  Wherever the five bytes start, one of the two-byte
-// pieces "id" (even offset) or "d:" (odd offset) sits at an EVEN offset of the text, i.e. fills one aligned half of a word.  The
-// filter therefore looks at aligned halfwords only: running 16-bit minima of word ^ "idid" and word ^ "d:d:"; a zero half
-// is a hit.  No tag minigraph writes and hardly any read name holds either piece at an even offset, and a false alarm only
-// costs the stripe's lines the exact path.  (v_qsad_pk_u16_u8, four sliding 4-byte windows per instruction, runs at a
-// quarter of the rate; a search at every byte offset needs an extra v_alignbyte per word.)
-typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-__device__ inline uint32_t pk_min_u16(uint32_t x, uint32_t y) {
-    const u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y));
-    return __builtin_bit_cast(uint32_t, r);
-}
-__device__ inline void idf_piece(const uint4 v, uint32_t &acc_id, uint32_t &acc_dc) {
-    constexpr uint32_t ID = 0x64696469u, DC = 0x3A643A64u;                // "idid", "d:d:" (little endian)
-    acc_id = pk_min_u16(pk_min_u16(acc_id, v.x ^ ID), pk_min_u16(v.y ^ ID, v.z ^ ID)); acc_id = pk_min_u16(acc_id, v.w ^ ID);
-    acc_dc = pk_min_u16(pk_min_u16(acc_dc, v.x ^ DC), pk_min_u16(v.y ^ DC, v.z ^ DC)); acc_dc = pk_min_u16(acc_dc, v.w ^ DC);
-}
+// raise, Alen == 0 no longer does): such lines take the exact path.  The filter is the byte pair "d:" (classify_span): no tag
+// minigraph writes and hardly any read name holds it, and a false alarm only costs the stripe's lines the exact path.
 
 // Static wave priorities (s_setprio): the byte classification of phases A / B1 is dense VALU work, the line and node phases
 // are chains of LDS and memory round trips.  A wave in the latency-bound phases wins the issue arbitration against the
@@ -421,13 +372,18 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     unsigned long long wave_lines = 0;
     // measurement only (build with -DSVJG_TIMING, run with SVJG_DIAG & 16): time this wave spends per phase
 #ifdef SVJG_TIMING
-    unsigned long long stamp = __builtin_readcyclecounter(), acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp = __builtin_readcyclecounter(), acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&](int ph) { const unsigned long long t = __builtin_readcyclecounter(); acc[ph] += t - stamp; stamp = t; };
+    // (8 .. 10 split the node pass's load phase: these wait for the loads they stamp, which the shipped kernel does not do there)
+#define tick_mem(ph) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tick(ph); } while (0)
 #elif defined(SVJG_MARK)
     // static census (tools/isa): the phase boundaries show up as comments in the -S output
 #define tick(ph) asm volatile("; MARK " #ph)
 #else
     auto tick = [](int) {};
+#endif
+#ifndef SVJG_TIMING
+#define tick_mem(ph) do { } while (0)
 #endif
 
     // stripe prefetch registers: the FIRST HALF of a stripe waits in registers while the stripe in front of it is worked off (piece i
@@ -733,12 +689,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t oribit = text[opv] == '<' ? 1u : 0u;
                 const bool probe = live && len - 1u <= 31u;              // names of 1..32 bytes; longer ones: exact path
                 uint32_t d[8];
+                tick_mem(8);                                             // (list and per-line record read)
                 uint64_t h = name_words_head(text, na0, len, d);         // the first six words of the name
                 if (ballot64(probe && len > 24u)) h += name_words_tail(text, na0, len, d);   // (wave-uniform: node names of the usual length fit six words)
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
                 if (probe) dsp = g.name_disp[name_bucket(h, g.name_buckets)];
+                tick_mem(9);                                             // (name bytes, hash, displacement)
                 // (lanes without a name load nothing: their record registers hold whatever was there and are looked at under `probe` only —
                 //  a later `go` implies a matched node)
                 uint4 r0, r1, r2, r3;
@@ -798,37 +756,27 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     pre_rx = (uint32_t)__shfl((int)pre, (int)((fr - 1u) & 63u));
                     orl = (uint32_t)__shfl((int)oribit, (int)fl); orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
                 }
-                bool go = false;
-                uint32_t klo = 0, khi = 0;
-                if (live && j + 1 < lk) {
-                    go = pre_l >= need_l && tot - (fr > lnb ? pre_rx : 0u) >= need_r;
-                    klo = (idr << 1) | orr; khi = (idl << 1) | orl;
-                }
-                // the link is looked for among the (up to four) that sit in the left node's record; the link table is asked only
-                // if it is not there and the node has more links (or for a revisited node: the link between the first occurrences)
-                uint32_t nh = 0, h0 = 0, h1 = 0;
+                // overlap test of the step (a lane without a step fails it); then the link is looked for among the (up to four)
+                // that sit in the left node's record — straight selects, no branches —; the link table is asked only if it is not
+                // there and the node has more links, or for a revisited node (the link between the first occurrences)
+                const bool go = live && j + 1 < lk && pre_l >= need_l && tot - (fr > lnb ? pre_rx : 0u) >= need_r;
+                const bool moved = revisits && (fl != lane || fr != lane + 1u);
+                const uint32_t want = (idr << 2) | orl | (orr << 1);
+                const bool m0 = len <= 24u && r2.x == want, m1 = r2.z == want, m2 = r3.x == want, m3 = r3.z == want;
+                const bool inl = m0 || m1 || m2 || m3;
+                const uint32_t v = m0 ? r2.y : m1 ? r2.w : m2 ? r3.y : r3.w;
+                const bool found = go && !moved && inl;
+                const bool ask = go && (moved || (!inl && !row_inline));
+                uint32_t nh = found ? 1u : 0u, h0 = v, h1 = 0;
                 const uint32_t *hp = nullptr;                             // more than two hits: the list
-                bool ask = false;
-                if (go) {
-                    if (fl != lane || fr != lane + 1u) ask = true;
-                    else {
-                        const uint32_t want = (idr << 2) | orl | (orr << 1);
-                        uint32_t v = 0; bool found = true;
-                        if (len <= 24u && r2.x == want) v = r2.y;
-                        else if (r2.z == want) v = r2.w;
-                        else if (r3.x == want) v = r3.y;
-                        else if (r3.z == want) v = r3.w;
-                        else { found = false; ask = !row_inline; }
-                        if (found) {
-                            if (v & 0x80000000u) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1]; }
-                            else { nh = 1; h0 = v; }
-                        }
-                    }
+                if (ballot64(found && (v & 0x80000000u))) {              // (wave-uniform: a link with several hits)
+                    if (found && (v & 0x80000000u)) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1]; }
                 }
                 if (ballot64(ask)) {
                     const uint64_t hl = h;                               // (the first occurrence spells the same name)
                     const uint64_t hr = ((uint64_t)lane_above((uint32_t)(h >> 32)) << 32) | lane_above((uint32_t)h);
                     if (ask) {
+                        const uint32_t klo = (idr << 1) | orr, khi = (idl << 1) | orl;
                         uint32_t sa, sb2;
                         link_slots(link_prehash(hl, orl, hr, orr), g.link_seed, g.link_mask, sa, sb2);
                         uint4 ek = *(const uint4 *)(g.link_tab + (size_t)sa * 4);
@@ -850,8 +798,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         rbase = __shfl(rbase, 0) + ex;
                     }
                 }
-                for (uint32_t jj = 0; jj < nh; ++jj) {
-                    const uint32_t hv = hp ? hp[jj] : (jj == 0 ? h0 : h1);
+                auto emit = [&](uint32_t hv, uint32_t jj) {
                     if (!DIAG(8u)) atomicAdd(&a.counts[hv >> 1], (hv & 1u) ? (1ull << 32) : 1ull);
                     if (a.want_hits) {
                         if (rbase + jj < a.rec_cap) {
@@ -860,6 +807,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                             a.recs[rbase + jj] = r;
                         } else atomicOr(&a.st->overflow, 2u);
                     }
+                };
+                if (nh && !hp) emit(h0, 0);                              // the usual case: one hit, held in a register
+                if (ballot64(nh > 1u || (nh && hp))) {
+                    for (uint32_t jj = hp ? 0u : 1u; jj < nh; ++jj) emit(hp ? hp[jj] : h1, jj);
                 }
                 tick(6);
             }
@@ -890,7 +841,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     if (lane == 0 && wave_lines) atomicAdd(&a.st->n_lines, wave_lines);
 #ifdef SVJG_TIMING
     if ((a.diag & 16u) && lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc[i]);
+        for (int i = 0; i < 12; ++i) atomicAdd(&a.dbg[i], acc[i]);
 #endif
 }
 
