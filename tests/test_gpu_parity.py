@@ -699,3 +699,44 @@ def test_gaf_through_a_pipe(tmp_path):
         assert h.hexdigest() == want["sha256_json"]
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def test_id_tag_across_span_and_half_boundaries(ctx, tmp_path):
+    """The main kernel sends a stripe to the exact path when the byte pair "d:" (every `id:f:` tag holds it) occurs in it; the
+    pair is looked for per 64-byte span, with the next lane's / the second half's first byte for a 'd' at a span's end.  Here the
+    'd' of an `id:f:abc` tag (float() raises in the reference, filter-alignments.py:193-196) sits at the last byte of a span, of
+    the first half of the stripe, at the first bytes of the second half and in mid-span: ValueError every time; with `id:f:0.9` the counts are the
+    oracle's."""
+    pre, gaf, g, orc = _synth_case(tmp_path, 400, 300, 2, "mixed", 17)
+    lines = gaf.tobytes().split(b"\n")[:-1]
+    ctx.load_graph(g)
+
+    def with_tag_at(p, tag):
+        """a file whose first stripe (it begins at offset 0) has the 'd' of `tag` at byte p"""
+        out, size, i = [], 0, 0
+        while True:
+            l = lines[i]; i += 1
+            room = p - 1 - size - (len(l) + 1)               # bytes of padding this line would need: `...\tid:f:` puts 'd' at its end + 2
+            if 0 <= room < 400:
+                name, rest = l.split(b"\t", 1)
+                t = name + b"x" * room + b"\t" + rest + b"\t" + tag
+                assert size + t.index(b"\tid:f:") + 2 == p
+                out.append(t); break
+            out.append(l); size += len(l) + 1
+        out += lines[i:i + 60]
+        return b"\n".join(out) + b"\n"
+
+    for p in (64 * 7 - 1, 64 * 13 - 1, 2047, 4095, 4096, 4097, 5000, 64 * 100 - 1):
+        bad = with_tag_at(p, b"id:f:abc")
+        assert bad[p:p + 2] == b"d:"
+        ctx.reset_counts()
+        with pytest.raises(ValueError):
+            ctx.classify(np.frombuffer(bad, dtype=np.uint8))
+        with pytest.raises(ValueError):
+            orc.filter(bad, want_hits=False)
+        good = with_tag_at(p, b"id:f:0.9")
+        want, _, n_lines = orc.filter(good, want_hits=False)
+        ctx.reset_counts()
+        ctx.classify(np.frombuffer(good, dtype=np.uint8))
+        assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want), p
+        assert ctx.stats()["n_deferred"] >= 1
