@@ -103,12 +103,13 @@ extern "C" int svjg_init(int device, svjg_ctx **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     for (auto &ev : c->ev) hipEventCreate(&ev);
     if (hipMalloc(&c->d_dbg, 16 * 8) != hipSuccess || hipMalloc(&c->d_st, sizeof(DevStatus)) != hipSuccess || hipMalloc(&c->d_maxn, sizeof(unsigned int)) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_stp, sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&c->h_stp, 2 * sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) {
         g_init_error = "hipMalloc failed";
         delete c;
         return SVJG_E_NOMEM;
     }
-    memset(c->h_stp, 0, sizeof(DevStatus));
+    memset(c->h_stp, 0, 2 * sizeof(DevStatus));
+    c->h_stp[1].err = ~0ull;                                  // [1]: a fresh status, never written again (reset_status copies from it without a sync)
     hipFuncSetAttribute((const void *)k_classify_main, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = c;
     return 0;
@@ -150,12 +151,14 @@ static int upload(svjg_ctx *c, T **dst, const T *src, uint64_t n, uint64_t extra
 }
 
 static int reset_status(svjg_ctx *c, bool all) {
-    DevStatus s = c->hs();
-    if (all) { memset(&s, 0, sizeof s); c->total_deferred = 0; }
-    s.n_deferred = 0; s.overflow = 0;
-    if (all) s.err = ~0ull;
-    c->hs() = s;
-    HIPCHK(c, hipMemcpyAsync(c->d_st, &c->hs(), sizeof s, hipMemcpyHostToDevice, c->stream));
+    if (all) {                                                // from the constant copy: the host's own status may be written again at once
+        c->hs() = c->h_stp[1]; c->total_deferred = 0;
+        HIPCHK(c, hipMemcpyAsync(c->d_st, &c->h_stp[1], sizeof(DevStatus), hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }
+    // (every earlier writer of hs() on the stream — the status read-backs — was followed by a synchronisation)
+    c->hs().n_deferred = 0; c->hs().overflow = 0;
+    HIPCHK(c, hipMemcpyAsync(c->d_st, &c->hs(), sizeof(DevStatus), hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 
@@ -213,10 +216,7 @@ extern "C" int svjg_reset_counts(svjg_ctx *c) {
     if (!c || !c->have_counts) return SVJG_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, ((uint64_t)c->n_slots + 2) * 8, c->stream));
-    int rc = reset_status(c, true);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return reset_status(c, true);                             // (nothing to wait for: the next call on the stream comes behind both)
 }
 
 // room for n bytes of text plus the zero padding the kernels read past the end without bounds tests
