@@ -50,7 +50,7 @@ SVJG_HD uint32_t bfi_b32(uint32_t m, uint32_t x, uint32_t y) {
 #define SVJG_B3(x, y, z, E) ([&]() -> uint32_t { constexpr uint32_t A = 0xF0u, B = 0xCCu, C = 0xAAu; constexpr uint32_t tbl = (uint32_t)(E) & 0xFFu; \
                                                  return (uint32_t)__builtin_amdgcn_bitop3_b32((x), (y), (z), tbl); }())
 #else
-#define SVJG_B3(x, y, z, E) ([&]() -> uint32_t { const uint32_t A = (x), B = (y), C = (z); return (uint32_t)(E); }())
+#define SVJG_B3(x, y, z, E) ([&]() -> uint32_t { const uint32_t A = (x), B = (y), C = (z); (void)A; (void)B; (void)C; return (uint32_t)(E); }())
 #endif
 
 // two registers trade the index bit "register a or b" for the index bit "bit position & D" (M = positions with that bit clear)
