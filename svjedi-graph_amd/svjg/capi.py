@@ -260,6 +260,12 @@ def load_library(path=None):
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise SvjgError(f"{p} not found: build it first (python __graft_entry__.py build, needs hipcc); there is no CPU fallback")
+    # Copies by shader, not by the copy engines: the ROCm runtime creates the queue of a copy engine the first time a copy happens
+    # to be handed to it (6-7 ms each, several engines, at unpredictable calls early in a process: one `svjg_genotype` call of
+    # 6.4 ms among 0.13 ms ones).  Must be in the environment before the runtime starts, i.e. before the first HIP call of the
+    # process; the price is a slower bulk upload (41 instead of 56 GB/s).  SVJG_SDMA=1 keeps the runtime's default.
+    if os.environ.get("SVJG_SDMA", "0") != "1":
+        os.environ.setdefault("HSA_ENABLE_SDMA", "0")
     lib = ctypes.CDLL(p)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
