@@ -150,6 +150,15 @@ static int upload(svjg_ctx *c, T **dst, const T *src, uint64_t n, uint64_t extra
     return 0;
 }
 
+#ifndef SVJG_SMALL_CHUNK
+#define SVJG_SMALL_CHUNK 65536
+#endif
+#ifndef SVJG_FIRST_SHARE
+#define SVJG_FIRST_SHARE 0.85
+#endif
+constexpr uint64_t SMALL_CHUNK = SVJG_SMALL_CHUNK;            // bytes (multiple of 16)
+constexpr double FIRST_CHUNK_SHARE = SVJG_FIRST_SHARE;       // of an even share of the text
+
 static int reset_status(svjg_ctx *c, bool all) {
     if (all) {                                                // from the constant copy: the host's own status may be written again at once
         c->hs() = c->h_stp[1]; c->total_deferred = 0;
@@ -157,7 +166,7 @@ static int reset_status(svjg_ctx *c, bool all) {
         return 0;
     }
     // (every earlier writer of hs() on the stream — the status read-backs — was followed by a synchronisation)
-    c->hs().n_deferred = 0; c->hs().overflow = 0;
+    c->hs().n_deferred = 0; c->hs().overflow = 0; c->hs().next_chunk = 0;
     HIPCHK(c, hipMemcpyAsync(c->d_st, &c->hs(), sizeof(DevStatus), hipMemcpyHostToDevice, c->stream));
     return 0;
 }
@@ -358,11 +367,17 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         }
         // one worker (wave) per resident slot; every worker owns the lines starting in its region of the text.  Small inputs:
         // regions of at least one stripe, fewer workers.
+        // A worker's first chunk is most of an even share, fixed; what is left goes in small chunks to whoever is free next
+        // (svjg_kernels.h: the workers of a CU do not run equally fast).  Inputs too small for that: even shares of at least a stripe.
         const uint64_t full = (uint64_t)c->n_cu * (uint64_t)c->occ_main;
-        uint64_t region = ((n + full - 1) / full + 15) & ~15ull;
+        const uint64_t share = (n + full - 1) / full;
+        uint64_t region = (share + 15) & ~15ull;
+        a.small = 0;
+        if (share >= 8 * SMALL_CHUNK) { region = ((uint64_t)(share * FIRST_CHUNK_SHARE) + 15) & ~15ull; a.small = SMALL_CHUNK; }
         if (region < TEXT) region = TEXT;
         a.region = region;
-        const uint32_t grid = (uint32_t)((n + region - 1) / region);
+        const uint64_t want_grid = (n + region - 1) / region;
+        const uint32_t grid = (uint32_t)(want_grid < full ? want_grid : full);
 #ifdef SVJG_TIMING
         if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
 #endif

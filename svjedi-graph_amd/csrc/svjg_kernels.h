@@ -60,6 +60,7 @@ struct DevStatus {
     unsigned long long err;              // min over (file offset << 3 | exception class); ~0 = none
     unsigned int non_ascii;
     unsigned int overflow;               // bit 0: deferred list, bit 1: hit-record buffer
+    unsigned long long next_chunk;       // k_classify_main: small chunks handed out so far (zero at launch)
 };
 
 struct ClassifyArgs {
@@ -70,7 +71,8 @@ struct ClassifyArgs {
     GraphView g;                         // global-memory views
     uint32_t all_slow;
     uint32_t want_hits;
-    uint64_t region;                     // bytes of text per worker (multiple of 16): worker w owns the lines that start in [w * region, (w + 1) * region)
+    uint64_t region;                     // bytes of text of a worker's FIRST chunk (multiple of 16): worker w owns the lines that start in [w * region, (w + 1) * region)
+    uint64_t small;                      // the text behind grid * region goes in chunks of this many bytes (multiple of 16) to whoever is free next; 0: there is none
     uint32_t diag;                       // measurement only (SVJG_DIAG): 1 stop after B, 2 stop after R1, 8 no atomics
     unsigned long long *counts;          // [n_slots] ref | alt << 32
     uint64_t *deferred;  uint64_t deferred_cap;
@@ -364,9 +366,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     const uint32_t lane = threadIdx.x;
     const GraphView g = a.g;
 
+    // Work is handed out in chunks of text; a worker owns the lines that START in its chunk.  The first chunk of every worker is
+    // fixed (most of an even share); the rest of the text goes in small chunks to whoever is free next: the fourteen workers of a CU
+    // sit four, four, three and three on its SIMDs and those that share an issue port with three others are a quarter slower
+    // (even shares: the last worker ended 15 % behind the average one).
     unsigned long long pos = a.begin + (unsigned long long)blockIdx.x * a.region;   // first byte not worked off yet (wave-uniform)
     if (pos >= a.n_bytes) return;
-    const unsigned long long rend = pos + a.region < a.n_bytes ? pos + a.region : a.n_bytes;   // lines starting before it are this worker's
+    unsigned long long rend = pos + a.region < a.n_bytes ? pos + a.region : a.n_bytes;   // lines starting before it belong to this chunk
 
     if (lane < 4) tbm[TEXT / 32 + lane] = 0;                            // slack of the tab bitmap (tab_near reads one word past a position)
     unsigned long long wave_lines = 0;
@@ -404,10 +410,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     // (the text begins at a line start whatever lies in front of it; later stripes take the byte in front of them from the staged
     //  text of the stripe before: a scalar load here would sit behind an s_waitcnt vmcnt(0) that also waits for the stripe's loads
     //  just issued — the whole HBM latency, every stripe)
+  for (;;) {                                                             // chunks
     fetch_half(pos & ~15ull);
     { const unsigned long long c0 = pos & ~15ull; pf_head = c0 > a.begin ? a.gaf[c0 - 1] : (uint32_t)'\n'; }
 
-    for (;;) {
+    for (;;) {                                                           // stripes of a chunk
         const unsigned long long c0 = pos & ~15ull;
         const uint32_t own_lo = (uint32_t)(pos - c0);                   // lines starting in [own_lo, lim2) belong to this stripe
         const uint32_t V = (uint32_t)((a.n_bytes - c0 < (unsigned long long)TEXT) ? (a.n_bytes - c0) : (unsigned long long)TEXT);   // valid bytes staged
@@ -840,6 +847,15 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         if (last_stripe) break;
         pos = next_pos;
     }
+    // the next small chunk (none for inputs that are even shares: 3 584 workers asking one counter at the same moment cost 40 us)
+    if (!a.small) break;
+    unsigned long long ci = 0;
+    if (lane == 0) ci = atomicAdd(&a.st->next_chunk, 1ull);
+    ci = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ci >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ci);
+    pos = a.begin + (unsigned long long)gridDim.x * a.region + ci * a.small;
+    if (pos >= a.n_bytes) break;
+    rend = pos + a.small < a.n_bytes ? pos + a.small : a.n_bytes;
+  }
     if (lane == 0 && wave_lines) atomicAdd(&a.st->n_lines, wave_lines);
 #ifdef SVJG_TIMING
     if ((a.diag & 16u) && lane == 0)
