@@ -34,7 +34,7 @@ struct svjg_ctx {
     // graph
     bool have_graph = false, have_counts = false;
     svjg_node *d_nodes = nullptr;  svjg_edge *d_edges = nullptr;  uint32_t *d_hits = nullptr;
-    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr, *d_links = nullptr, *d_cshort = nullptr, *d_clong = nullptr;
+    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr, *d_names = nullptr, *d_links = nullptr;  uint16_t *d_disp = nullptr;  uint32_t *d_ihits = nullptr;
     GraphView gv{};
     uint32_t names_len = 0, gflags = 0, n_slots = 0;
     unsigned long long *d_counts = nullptr, *d_snap = nullptr;
@@ -117,8 +117,8 @@ extern "C" int svjg_init(int device, svjg_ctx **out) {
 
 static void free_graph(svjg_ctx *c) {
     hipFree(c->d_nodes); hipFree(c->d_edges); hipFree(c->d_hits); hipFree(c->d_cnames); hipFree(c->d_coff);
-    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap); hipFree(c->d_links); hipFree(c->d_cshort); hipFree(c->d_clong);
-    c->d_links = nullptr; c->d_cshort = nullptr; c->d_clong = nullptr;
+    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap); hipFree(c->d_names); hipFree(c->d_links); hipFree(c->d_disp); hipFree(c->d_ihits);
+    c->d_names = nullptr; c->d_links = nullptr; c->d_disp = nullptr; c->d_ihits = nullptr;
     c->d_nodes = nullptr; c->d_edges = nullptr; c->d_hits = nullptr; c->d_cnames = nullptr; c->d_coff = nullptr;
     c->d_clo = nullptr; c->d_chash = nullptr; c->d_counts = nullptr; c->d_snap = nullptr;
     c->have_graph = false; c->have_counts = false;
@@ -189,15 +189,17 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     std::vector<uint32_t> hash = build_chrom_hash(*g);
     if ((rc = upload(c, &c->d_chash, hash.data(), hash.size()))) return rc;
     KernelTables kt = build_kernel_tables(*g);
+    if ((rc = upload(c, &c->d_names, kt.names.data(), kt.names.size()))) return rc;
     if ((rc = upload(c, &c->d_links, kt.links.data(), kt.links.size()))) return rc;
-    if ((rc = upload(c, &c->d_cshort, kt.cshort.data(), kt.cshort.size()))) return rc;
-    if ((rc = upload(c, &c->d_clong, kt.clong.data(), kt.clong.size()))) return rc;
+    if ((rc = upload(c, &c->d_disp, kt.disp.data(), kt.disp.size()))) return rc;
+    if ((rc = upload(c, &c->d_ihits, kt.ihits.data(), kt.ihits.size()))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));           // `hash` and `kt` are locals
     c->gv.nodes = c->d_nodes; c->gv.n_nodes = (uint32_t)g->n_nodes; c->gv.edges = c->d_edges; c->gv.hits = c->d_hits;
     c->gv.chrom_names = c->d_cnames; c->gv.chrom_off = c->d_coff; c->gv.chrom_lo = c->d_clo; c->gv.chrom_hash = c->d_chash;
     c->gv.n_chrom = g->n_chrom; c->gv.hash_mask = (uint32_t)hash.size() - 1; c->gv.d_over = g->d_over;
-    c->gv.ltab = c->d_links; c->gv.l_buckets = kt.l_buckets;
-    c->gv.ctab_short = c->d_cshort; c->gv.cs_mask = kt.cs_mask; c->gv.cs_mult = kt.cs_mult; c->gv.ctab_long = c->d_clong; c->gv.cl_mask = kt.cl_mask;
+    c->gv.name_tab = c->d_names; c->gv.name_ihits = c->d_ihits; c->gv.name_disp = c->d_disp; c->gv.name_slots = kt.name_slots; c->gv.name_buckets = kt.name_buckets;
+    c->gv.name_complete = (kt.names_left_out == 0 && kt.names_skipped == 0) ? 1u : 0u;
+    c->gv.link_tab = c->d_links; c->gv.link_mask = kt.link_mask; c->gv.link_seed = kt.link_seed;
     c->gflags = g->flags;
     if (kt.links_left_out) c->gflags |= SVJG_GRAPH_ALL_SLOW;   // a link the main kernel could not find would be a silent miss
     c->n_slots = g->n_slots;

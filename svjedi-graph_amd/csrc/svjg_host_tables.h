@@ -6,7 +6,6 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
-#include <string.h>
 #include <algorithm>
 #include <chrono>
 #include <vector>
@@ -38,107 +37,125 @@ inline std::vector<uint32_t> build_chrom_hash(const svjg_graph &g) {
 
 #include <algorithm>
 #include <string>
-#include <unordered_map>
 #include "svjg_line.h"
 
 namespace svjg {
 
 // ---- tables of the main kernel ---------------------------------------------------------------------------------
-// The kernel parses a path node "chrom:start-end" / "chrom:pos.n" into numbers and asks ONE table, keyed by the link
-// (svjg_line.h: link_key / link_hash / link_bucket1): one 64-byte bucket per path step, no node lookup (the reference has
-// none either: filter-alignments.py:141-153, :343-349).  Random 64-byte lines of a table of tens of MB come at ~66 G lines/s
-// on MI355X and at ~110 G/s from 8 MB (tools/ubench/randread.hip), so the table is small: canonical links only (a link
-// and its reversed form share an entry), 32 bytes each.
-//   CHROMOSOME TABLES: raw name bytes -> index, linear probing at load <= 1/4: names of up to 8 bytes (two words to
-//   compare; every usual name) and names of 9..24 bytes.  Longer names stay out: their lines take the exact path.
+// The kernel is bound by how many 64-byte lines it pulls from beyond the L2 (random lines of a table of tens of MB come
+// at ~66 G lines/s on MI355X, tools/ubench/randread.hip), so the tables are built for ONE line per path node:
+// NODE RECORDS: perfect hash (hash and displace, svjg_line.h: name_prehash / name_bucket / name_slot) of the canonical
+// node names (<= 32 bytes).  The kernel hashes the raw bytes of a path segment, reads the bucket's 2-byte displacement
+// (a small array that stays cached), fetches the one record the name can be in and compares the spelling: no number
+// parsing on the device, and only names spelled exactly like the graph's can match (anything else: exact path).
+//   record = 16 words (one 64-byte line):
+//     [0..5] name bytes 0..23   [6] node id << 7 | flags << 5 | (byte length - 1)   (flags: bit 0 hazard-prone name,
+//     bit 1 length unknown; all ones = empty slot)   [7] node length in bp | REC_ROW_INLINE if the node has no other links
+//     than the inline ones
+//     names of up to 24 bytes: [8..15] = four inline links;  longer names: [8..9] = name bytes 24..31, [10..15] = three
+//     inline links.  An inline link = two words: key = right id << 2 | left strand | right strand << 1 (all ones = none),
+//     value = the hit (slot << 1 | allele) of a one-hit link, or REC_MANY | index into the inline hit list
+//     (ihits[index] = number of hits, then the hits).  Reference-allele links come first.  Nearly every path step is
+//     answered from the record that the node lookup fetched anyway and never touches the link table.
+// LINK TABLE: (left id, left strand, right id, right strand) -> hits, same content as the CSR rows; two-choice (cuckoo)
+// table: every key sits in one of its TWO candidate slots.  The SLOTS of a link are hashed from the 64-bit name pre-hashes of
+// its two nodes and the strands (svjg_line.h: link_prehash / link_slots), not from the ids.
+//   entry = 4 words (one 16-byte load): [0] key low, [1] key high, [2] a, [3] b with
+//       1 hit : a = hit, b = LINK_NO_HIT        2 hits: a, b = the hits
+//       more  : a = LINK_MANY | index into hits[], b = number of hits
+//   key = left << 33 | left strand << 32 | right << 1 | right strand ; all ones = empty slot.
+constexpr uint32_t NAME_ENT_WORDS = 16, LINK_ENT_WORDS = 4;
+constexpr uint32_t LINK_NO_HIT = 0xFFFFFFFFu, LINK_MANY = 0x80000000u;
+constexpr uint32_t NAME_EMPTY = 0xFFFFFFFFu, NAME_MAX_ID = (1u << 25) - 2u;
+constexpr uint32_t REC_ROW_INLINE = 0x80000000u, REC_NO_LINK = 0xFFFFFFFFu, REC_MANY = 0x80000000u;
+inline bool name_ent_empty(const uint32_t *e) { return e[6] == NAME_EMPTY; }
+inline uint32_t name_ent_len(const uint32_t *e) { return (e[6] & 31u) + 1u; }
+inline uint32_t name_ent_id(const uint32_t *e) { return e[6] >> 7; }
+inline void name_ent_words(const uint32_t *e, uint32_t d[8]) { for (int w = 0; w < 6; ++w) d[w] = e[w]; const bool lg = name_ent_len(e) > 24u; d[6] = lg ? e[8] : 0u; d[7] = lg ? e[9] : 0u; }
+inline bool nm_len_gt24(uint32_t meta) { return (meta & 31u) + 1u > 24u; }
+inline uint32_t rec_first_link(const uint32_t *e) { return name_ent_len(e) > 24u ? 10u : 8u; }   // word of the first inline link
+
 struct KernelTables {
-    std::vector<uint32_t> links; uint32_t l_buckets = 0;      // LB_WORDS words per bucket
-    std::vector<uint32_t> cshort, clong; uint32_t cs_mask = 0, cl_mask = 0, cs_mult = 0x9E3779B1u;
-    uint64_t n_keys = 0, n_second = 0, n_exact = 0;           // canonical links, those in their second bucket, those flagged for the exact path
-    uint64_t links_left_out = 0;                              // links no bucket could take (never seen: the library then uses the exact path only)
-    uint32_t chroms_skipped = 0;                              // names longer than 24 bytes
+    std::vector<uint32_t> names; uint32_t name_slots = 0, name_buckets = 0;
+    std::vector<uint16_t> disp;                               // displacement of every bucket of the name hash
+    std::vector<uint32_t> ihits;                              // hit lists of inline links with more than one hit: count, hits...
+    std::vector<uint32_t> links; uint32_t link_mask = 0, link_seed = 0;
+    uint64_t names_left_out = 0, links_left_out = 0, links_unplaced = 0;   // links_unplaced: their left nodes are flagged for the exact path
+    uint32_t names_skipped = 0;                               // node names the table cannot hold (> 32 bytes, id too large)
+    std::vector<uint64_t> node_pre; std::vector<uint8_t> node_has;   // per node: name pre-hash, "is in the name table" (table checks)
+    std::vector<uint32_t> node_slot;                          // per node: its record (table checks)
 };
 
-struct CanonLink { LinkKey k; uint32_t f5, h0, h1; uint64_t h; };
-constexpr uint32_t MAIN_MAX_CHROM = TAG_CHROM;              // chromosome indices the main kernel's node tags hold
-
-#ifndef SVJG_LINK_LOAD
-#define SVJG_LINK_LOAD 0.75
-#endif
-
-inline void build_chrom_tables(const svjg_graph &g, KernelTables &kt) {
-    uint32_t n_s = 0, n_l = 0;
-    for (uint32_t c = 0; c < g.n_chrom; ++c) { const uint32_t n = g.chrom_off[c + 1] - g.chrom_off[c]; if (n >= 1 && n <= 8) ++n_s; else if (n <= 24) ++n_l; }
-    uint32_t ss = 64, sl = 16;
-    while (ss < 4 * n_s) ss *= 2;
-    while (sl < 4 * n_l) sl *= 2;
-    kt.cshort.assign((size_t)ss * 4, CT_EMPTY); kt.cs_mask = ss - 1;
-    // a multiplier under which no two short names share a slot: the kernel then needs no probing loop (cs_mult's bit 0 clear says so)
-    {
-        std::vector<std::pair<uint32_t, uint32_t>> names;
-        for (uint32_t c = 0; c < g.n_chrom; ++c) {
-            const uint32_t o = g.chrom_off[c], n = g.chrom_off[c + 1] - o;
-            if (n < 1 || n > 8) continue;
-            uint32_t w[2] = {0, 0};
-            for (uint32_t b = 0; b < n; ++b) w[b >> 2] |= (uint32_t)(uint8_t)g.chrom_names[o + b] << (8 * (b & 3));
-            names.emplace_back(w[0], w[1]);
-        }
-        std::vector<uint8_t> used(ss);
-        uint32_t m = 0x9E3779B1u;
-        bool found = false;
-        for (int attempt = 0; attempt < 4096 && !found; ++attempt, m = m * 0x2C1B3C6Du + 0x7F4A7C15u) {
-            std::fill(used.begin(), used.end(), 0);
-            found = true;
-            for (const auto &nm : names) {
-                const uint32_t j = chrom_short_slot(nm.first, nm.second, kt.cs_mask, m);
-                if (used[j]) { found = false; break; }
-                used[j] = 1;
+// Two-choice placement by random-walk eviction.  pre[i] = pre-hash of key i; returns owner[slot] = key index or -1.
+// Keys that cannot be placed under any of a few seeds are dropped (counted in left_out).
+inline std::vector<int64_t> cuckoo_place(const std::vector<uint64_t> &pre, uint32_t mask, uint32_t &seed_out, uint64_t &left_out,
+                                         std::vector<uint32_t> *left_keys = nullptr) {
+    std::vector<int64_t> best;
+    std::vector<uint32_t> best_keys;
+    uint64_t best_left = ~0ull;
+    for (uint32_t seed = 0x5bd1e995u, attempt = 0; attempt < 8; ++attempt, seed = seed * 0x9E3779B1u + 0x7F4A7C15u) {
+        std::vector<int64_t> owner((size_t)mask + 1, -1);
+        uint64_t left = 0, rng = 0x9E3779B97F4A7C15ull ^ seed;
+        std::vector<uint32_t> keys_out;
+        for (size_t i = 0; i < pre.size(); ++i) {
+            int64_t cur = (int64_t)i;
+            uint32_t avoid = 0xFFFFFFFFu;
+            bool placed = false;
+            for (int kick = 0; kick < 512; ++kick) {
+                uint32_t s1, s2;
+                link_slots(pre[(size_t)cur], seed, mask, s1, s2);
+                if (owner[s1] < 0) { owner[s1] = cur; placed = true; break; }
+                if (owner[s2] < 0) { owner[s2] = cur; placed = true; break; }
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                uint32_t victim = (rng >> 33) & 1u ? s1 : s2;
+                if (victim == avoid) victim = victim == s1 ? s2 : s1;
+                std::swap(cur, owner[victim]);
+                avoid = victim;
             }
-            if (found) kt.cs_mult = m & ~1u;
+            if (!placed) { ++left; keys_out.push_back((uint32_t)cur); }   // `cur` (whoever was evicted last) stays out
         }
-        if (!found) kt.cs_mult = 0x9E3779B1u;                  // (bit 0 set: probing loop)
+        if (left < best_left) { best_left = left; best.swap(owner); best_keys.swap(keys_out); seed_out = seed; }
+        if (best_left == 0) break;
     }
-    kt.clong.assign((size_t)sl * 8, CT_EMPTY); kt.cl_mask = sl - 1;
-    // classes of names of which one ends with another ("1" / "11"): only nodes of one class can be substrings of one another
-    // (SURVEY Q6); the kernel compares start | kind + class * constant when it looks for a line's repeated names
-    std::vector<uint32_t> cls(g.n_chrom);
-    for (uint32_t c = 0; c < g.n_chrom; ++c) cls[c] = c;
-    auto root = [&](uint32_t x) { while (cls[x] != x) x = cls[x] = cls[cls[x]]; return x; };
-    {
-        std::unordered_map<std::string, uint32_t> by_name;
-        for (uint32_t c = 0; c < g.n_chrom; ++c) by_name.emplace(std::string(g.chrom_names + g.chrom_off[c], g.chrom_off[c + 1] - g.chrom_off[c]), c);
-        for (uint32_t d = 0; d < g.n_chrom; ++d) {
-            const std::string nm(g.chrom_names + g.chrom_off[d], g.chrom_off[d + 1] - g.chrom_off[d]);
-            for (size_t cut = 1; cut < nm.size(); ++cut) {               // every proper suffix of the name that is a name itself
-                const auto it = by_name.find(nm.substr(cut));
-                if (it == by_name.end()) continue;
-                const uint32_t a = root(it->second), b = root(d);
-                if (a != b) cls[a > b ? a : b] = a > b ? b : a;
-            }
-        }
-    }
-    for (uint32_t c = 0; c < g.n_chrom; ++c) {
-        const uint32_t o = g.chrom_off[c], n = g.chrom_off[c + 1] - o;
-        if (n == 0 || n > 24) { ++kt.chroms_skipped; continue; }
-        uint32_t w[6] = {0, 0, 0, 0, 0, 0}, flags = 0;
-        for (uint32_t b = 0; b < n; ++b) { w[b >> 2] |= (uint32_t)(uint8_t)g.chrom_names[o + b] << (8 * (b & 3)); if (g.chrom_names[o + b] == ':') flags |= CT_ODD; }
-        const uint32_t meta = c | (flags << 16) | (n << 24), hc = root(c);
-        if (n <= 8) {
-            uint32_t j = chrom_short_slot(w[0], w[1], kt.cs_mask, kt.cs_mult);
-            while (kt.cshort[(size_t)j * 4 + 2] != CT_EMPTY) j = (j + 1) & kt.cs_mask;
-            kt.cshort[(size_t)j * 4] = w[0]; kt.cshort[(size_t)j * 4 + 1] = w[1]; kt.cshort[(size_t)j * 4 + 2] = meta; kt.cshort[(size_t)j * 4 + 3] = hc;
-        } else {
-            uint32_t j = chrom_long_slot(w, kt.cl_mask);
-            while (kt.clong[(size_t)j * 8 + 6] != CT_EMPTY) j = (j + 1) & kt.cl_mask;
-            for (int q = 0; q < 6; ++q) kt.clong[(size_t)j * 8 + q] = w[q];
-            kt.clong[(size_t)j * 8 + 6] = meta; kt.clong[(size_t)j * 8 + 7] = hc;
-        }
-    }
+    left_out = best_left;
+    if (left_keys) left_keys->swap(best_keys);
+    return best;
 }
 
-inline void node_fields(const svjg_node &nd, uint32_t &c, uint32_t &a, uint32_t &b, uint32_t &k) {
-    c = (uint32_t)(nd.key >> 48); a = (uint32_t)(nd.key >> 16); k = (uint32_t)(nd.key >> 15) & 1u;
-    b = k ? (uint32_t)nd.key & 0x7FFFu : nd.aux;
+// Hash and displace: keys h[i] (64-bit pre-hashes, distinct) -> a slot of its own for every key.  Buckets are worked
+// off largest first; a bucket's displacement is the first value that sends all its keys to free, distinct slots.
+// false: some bucket found no displacement below 65536 (the caller retries with more room).
+inline bool chd_place(const std::vector<uint64_t> &h, uint32_t n_slots, uint32_t n_buckets, std::vector<uint16_t> &disp, std::vector<uint32_t> &slot_of) {
+    std::vector<std::vector<uint32_t>> bk(n_buckets);
+    for (uint32_t i = 0; i < h.size(); ++i) bk[name_bucket(h[i], n_buckets)].push_back(i);
+    std::vector<uint32_t> order(n_buckets);
+    for (uint32_t b = 0; b < n_buckets; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bk[x].size() > bk[y].size(); });
+    std::vector<uint8_t> used(n_slots, 0);
+    disp.assign(n_buckets, 0);
+    slot_of.assign(h.size(), 0);
+    std::vector<uint32_t> tmp;
+    for (uint32_t b : order) {
+        const std::vector<uint32_t> &keys = bk[b];
+        if (keys.empty()) break;
+        uint32_t d = 0;
+        for (; d < 65536; ++d) {
+            tmp.clear();
+            bool ok = true;
+            for (uint32_t k : keys) {
+                const uint32_t s = name_slot(h[k], d, n_slots);
+                if (used[s]) { ok = false; break; }
+                for (uint32_t t : tmp) if (t == s) { ok = false; break; }
+                if (!ok) break;
+                tmp.push_back(s);
+            }
+            if (ok) break;
+        }
+        if (d == 65536) return false;
+        disp[b] = (uint16_t)d;
+        for (size_t j = 0; j < keys.size(); ++j) { used[tmp[j]] = 1; slot_of[keys[j]] = tmp[j]; }
+    }
+    return true;
 }
 
 inline KernelTables build_kernel_tables(const svjg_graph &g) {
@@ -151,110 +168,140 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
         fprintf(stderr, "[svjg] kernel tables, %s: %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
         t_last = now;
     };
-    build_chrom_tables(g, kt);
-    // lookup forms of the links: the CSR rows hold d[K] ++ d[R] under K and d[R] ++ d[K] under R (the same multiset: the order of the
-    // appends of one line to different lists does not show in the output)
-    std::vector<CanonLink> keys;
-    keys.reserve((size_t)g.n_edges / 2 + 16);
-    for (uint64_t n = 0; n < g.n_nodes; ++n) {
-        const uint32_t ra = g.nodes[n].row & 0x7FFFFFFFu, rb = g.nodes[n + 1].row & 0x7FFFFFFFu;
-        if (ra == rb) continue;
-        uint32_t cl, al, bl, kl;
-        node_fields(g.nodes[n], cl, al, bl, kl);
-        for (uint32_t i = ra; i < rb; ++i) {
-            const svjg_edge &ed = g.edges[i];
-            const uint32_t nh = ed.meta >> 2;
-            if (!nh) continue;
-            uint32_t cr, ar, br, kr;
-            node_fields(g.nodes[ed.right], cr, ar, br, kr);
-            bool flipped;
-            CanonLink cl_;
-            const uint32_t sl = ed.meta & 1u, sr = (ed.meta >> 1) & 1u;
-            cl_.k = link_key(al, bl, cl | (kl ? TAG_KIND : 0u) | (sl ? TAG_STRAND : 0u), ar, br, cr | (kr ? TAG_KIND : 0u) | (sr ? TAG_STRAND : 0u), flipped);
-            // lookup form = this row's own form (left strand '+'), or — a (-,+) row — its reversed form, which is another (-,+) row's
-            // own spelling; the reversed form of a (-,-) row is a (+,+) row, entered there
-            if (flipped && sr) continue;
-            // the alt node's length travels with the link (the kernel has no node table): unknown / too long / two alt nodes -> exact path
-            uint32_t alt = LK_ALT_NONE, f5 = 0;
-            if (kl && kr) f5 |= LKF_EXACT;
-            else if (kl || kr) {   // (which side the alt node is on in the entry: the tags' kind bits)
-                const uint32_t len = kl ? g.nodes[n].aux : g.nodes[ed.right].aux;
-                if (len == SVJG_LEN_UNKNOWN || len >= (1u << 25)) f5 |= LKF_EXACT; else alt = len;
+    std::vector<uint64_t> node_pre((size_t)g.n_nodes, 0);    // name pre-hash of every node the name table holds
+    std::vector<uint8_t> node_has((size_t)g.n_nodes, 0);
+    std::vector<uint32_t> node_slot((size_t)g.n_nodes, 0);
+    {
+        std::vector<uint32_t> ent;                            // 10 words per key: d[0..7], meta, len_bp
+        std::vector<uint64_t> hs;
+        std::vector<uint32_t> key_node;
+        for (uint64_t i = 0; i < g.n_nodes; ++i) {
+            const svjg_node &nd = g.nodes[i];
+            uint32_t c = (uint32_t)(nd.key >> 48), pos = (uint32_t)(nd.key >> 16), kind = (uint32_t)(nd.key >> 15) & 1u, cnt = (uint32_t)nd.key & 0x7FFFu;
+            std::string nm(g.chrom_names + g.chrom_off[c], g.chrom_off[c + 1] - g.chrom_off[c]);
+            nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
+            if (nm.size() > 32 || i > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path
+            uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t b = 0; b < nm.size(); ++b) d[b >> 2] |= (uint32_t)(uint8_t)nm[b] << (8 * (b & 3));
+            uint32_t flags = ((nd.row & 0x80000000u) ? 1u : 0u) | ((kind && nd.aux == SVJG_LEN_UNKNOWN) ? 2u : 0u);
+            uint32_t len_bp = kind ? nd.aux : nd.aux - pos + 1;
+            if (len_bp & REC_ROW_INLINE) flags |= 2u;         // (no node is 2 Gbp long; keeps the flag bit free)
+            for (int w = 0; w < 8; ++w) ent.push_back(d[w]);
+            ent.push_back(((uint32_t)i << 7) | (flags << 5) | ((uint32_t)nm.size() - 1u));
+            ent.push_back(len_bp & ~REC_ROW_INLINE);
+            hs.push_back(name_prehash(d, (uint32_t)nm.size()));
+            key_node.push_back((uint32_t)i);
+        }
+        // two names with one 64-bit pre-hash cannot be told apart by any displacement: both stay out (exact path)
+        {
+            std::vector<uint32_t> idx(hs.size());
+            for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
+            std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return hs[x] < hs[y]; });
+            std::vector<uint8_t> drop(hs.size(), 0);
+            for (size_t i = 1; i < idx.size(); ++i) if (hs[idx[i]] == hs[idx[i - 1]]) { drop[idx[i]] = drop[idx[i - 1]] = 1; }
+            size_t w = 0;
+            for (size_t i = 0; i < hs.size(); ++i) {
+                if (drop[i]) { ++kt.names_left_out; continue; }
+                if (w != i) { hs[w] = hs[i]; key_node[w] = key_node[i]; for (int q = 0; q < 10; ++q) ent[w * 10 + q] = ent[i * 10 + q]; }
+                ++w;
             }
-            cl_.f5 = f5 | (alt << LK_ALT_SHIFT);
-            if (nh == 1) { cl_.h0 = ed.h0; cl_.h1 = LINK_NO_HIT; }
-            else if (nh == 2) { cl_.h0 = ed.h0; cl_.h1 = ed.h1; }
-            else { cl_.h0 = LINK_MANY | ed.h0; cl_.h1 = nh; }
-            cl_.h = link_hash(cl_.k);
-            if (f5 & LKF_EXACT) ++kt.n_exact;
-            keys.push_back(cl_);
+            hs.resize(w); key_node.resize(w); ent.resize(w * 10);
+        }
+        lap("name words and pre-hashes");
+        const uint64_t n = hs.size();
+        std::vector<uint32_t> slot_of;
+        uint64_t slots = n + n / 4 + 16;                      // load <= 0.8
+        for (int grow = 0;; ++grow) {
+            kt.name_slots = (uint32_t)slots;
+            kt.name_buckets = (uint32_t)(n / 3 + 1);
+            if (chd_place(hs, kt.name_slots, kt.name_buckets, kt.disp, slot_of)) break;
+            if (grow == 6) { kt.names_left_out += n; hs.clear(); key_node.clear(); slot_of.clear(); break; }   // never seen: everything takes the exact path
+            slots += slots / 4;
+        }
+        lap("hash and displace");
+        kt.names.assign((size_t)kt.name_slots * NAME_ENT_WORDS, 0);
+        for (uint64_t j = 0; j < kt.name_slots; ++j) {
+            uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
+            e[6] = NAME_EMPTY; e[8] = e[10] = e[12] = e[14] = REC_NO_LINK;
+        }
+        for (uint64_t k = 0; k < hs.size(); ++k) {
+            const uint32_t *src = &ent[(size_t)k * 10];
+            uint32_t *e = &kt.names[(size_t)slot_of[k] * NAME_ENT_WORDS];
+            for (int w = 0; w < 6; ++w) e[w] = src[w];
+            e[6] = src[8]; e[7] = src[9];
+            if (nm_len_gt24(src[8])) { e[8] = src[6]; e[9] = src[7]; }
+            const uint32_t node = key_node[k];
+            node_pre[node] = hs[k]; node_has[node] = 1; node_slot[node] = slot_of[k];
+            // inline links: up to two rows of the node, those whose hits are all reference-allele first
+            const uint32_t a = g.nodes[node].row & 0x7FFFFFFFu, b = g.nodes[node + 1].row & 0x7FFFFFFFu;
+            std::vector<uint32_t> rows;
+            for (int pass = 0; pass < 2; ++pass)
+                for (uint32_t i = a; i < b; ++i) {
+                    const svjg_edge &ed = g.edges[i];
+                    const uint32_t nh = ed.meta >> 2;
+                    if (!nh || ed.right > NAME_MAX_ID) continue;
+                    bool alt = false;
+                    for (uint32_t q = 0; q < nh; ++q) alt |= ((nh <= 2 ? (q ? ed.h1 : ed.h0) : g.hits[ed.h0 + q]) & 1u) != 0;
+                    if ((int)alt == pass) rows.push_back(i);
+                }
+            uint32_t n_live = 0;
+            for (uint32_t i = a; i < b; ++i) n_live += (g.edges[i].meta >> 2) != 0;
+            const uint32_t w0 = nm_len_gt24(src[8]) ? 10u : 8u, cap = (16u - w0) / 2u;
+            for (uint32_t w = w0; w < 16; w += 2) e[w] = REC_NO_LINK, e[w + 1] = 0;
+            for (size_t q = 0; q < rows.size() && q < cap; ++q) {
+                const svjg_edge &ed = g.edges[rows[q]];
+                const uint32_t nh = ed.meta >> 2;
+                uint32_t *l = e + w0 + 2 * q;
+                l[0] = (ed.right << 2) | (ed.meta & 3u);
+                if (nh == 1) l[1] = ed.h0;
+                else {
+                    l[1] = REC_MANY | (uint32_t)kt.ihits.size();
+                    kt.ihits.push_back(nh);
+                    for (uint32_t j = 0; j < nh; ++j) kt.ihits.push_back(nh <= 2 ? (j ? ed.h1 : ed.h0) : g.hits[ed.h0 + j]);
+                }
+            }
+            if (n_live <= cap && rows.size() == n_live) e[7] |= REC_ROW_INLINE;
         }
     }
-    kt.n_keys = keys.size();
-    lap("lookup forms of the links");
-    const char *ld = getenv("SVJG_LINK_LOAD");                       // measurement only: keys per bucket
-    double load = ld ? atof(ld) : SVJG_LINK_LOAD;
-    if (!(load > 0.05 && load <= 1.5)) load = SVJG_LINK_LOAD;
-    uint64_t nb = (uint64_t)((double)keys.size() / load) + 16;
-    for (int grow = 0;; ++grow) {
-        // every key goes to its first bucket while that has room; the others to their second bucket, evicting (random walk between
-        // the two buckets of the evicted key) when that is full too: at <= 1 key per two-entry bucket a handful of moves at most
-        kt.l_buckets = (uint32_t)nb;
-        std::vector<int64_t> owner((size_t)nb * 2, -1);
-        std::vector<uint32_t> later;
-        auto b1_of = [&](int64_t i) { return link_bucket1(keys[(size_t)i].h, kt.l_buckets); };
-        auto b2_of = [&](int64_t i) { return link_bucket2(keys[(size_t)i].h, kt.l_buckets, b1_of(i)); };
-        auto try_put = [&](uint32_t b, int64_t i) { for (int q = 0; q < 2; ++q) if (owner[(size_t)b * 2 + q] < 0) { owner[(size_t)b * 2 + q] = i; return true; } return false; };
-        for (size_t i = 0; i < keys.size(); ++i) if (!try_put(b1_of((int64_t)i), (int64_t)i)) later.push_back((uint32_t)i);
-        uint64_t left = 0, rng = 0x9E3779B97F4A7C15ull;
-        for (uint32_t i0 : later) {
-            int64_t cur = (int64_t)i0;
-            uint32_t at = b1_of(cur);                              // the bucket `cur` has just failed in / been evicted from
-            bool placed = false;
-            for (int kick = 0; kick < 256 && !placed; ++kick) {
-                const uint32_t b1 = b1_of(cur), b2 = b2_of(cur), to = at == b1 ? b2 : b1;
-                if (try_put(to, cur)) { placed = true; break; }
-                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-                int64_t &victim = owner[(size_t)to * 2 + ((rng >> 33) & 1u)];
-                std::swap(cur, victim);
-                at = to;
+    // A link that cannot be placed (never seen with 64-bit pre-hashes at load <= 0.4) would be a silent miss in the
+    // kernel: its left node is flagged hazard-prone instead, which sends the lines that touch it to the exact path.  links_left_out counts links lost for good (never seen: the library then uses the exact path only).
+    lap("node records with inline links");
+    uint64_t lsz = 16;
+    while (lsz < 5 * g.n_edges / 2 + 2) lsz *= 2;
+    {
+        kt.links.assign(lsz * LINK_ENT_WORDS, 0xFFFFFFFFu);
+        kt.link_mask = (uint32_t)lsz - 1;
+        std::vector<uint32_t> ent, left_node;                 // 4 words per candidate
+        std::vector<uint64_t> pre;
+        for (uint64_t n = 0; n < g.n_nodes; ++n) {
+            uint32_t a = g.nodes[n].row & 0x7FFFFFFFu, b = g.nodes[n + 1].row & 0x7FFFFFFFu;
+            for (uint32_t i = a; i < b; ++i) {
+                const svjg_edge &ed = g.edges[i];
+                if (!node_has[n] || !node_has[ed.right]) continue;   // a node outside the name table sends its lines to the exact path anyway
+                uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
+                const uint32_t nh = ed.meta >> 2;
+                ent.push_back((uint32_t)key); ent.push_back((uint32_t)(key >> 32));
+                if (nh == 1) { ent.push_back(ed.h0); ent.push_back(LINK_NO_HIT); }
+                else if (nh == 2) { ent.push_back(ed.h0); ent.push_back(ed.h1); }
+                else { ent.push_back(LINK_MANY | ed.h0); ent.push_back(nh); }
+                pre.push_back(link_prehash(node_pre[n], ed.meta & 1u, node_pre[ed.right], (ed.meta >> 1) & 1u));
+                left_node.push_back((uint32_t)n);
             }
-            if (!placed) ++left;
         }
-        if (left && grow < 8) { nb += nb / 2; continue; }
-        kt.links_left_out = left + (g.n_chrom > MAIN_MAX_CHROM ? 1u : 0u);   // (more chromosomes than a node tag holds: exact path only)
-        kt.links.assign((size_t)nb * LB_WORDS, 0xFFFFFFFFu);
-        kt.n_second = 0;
-        for (size_t sl = 0; sl < owner.size(); ++sl) {
-            if (owner[sl] < 0) continue;
-            const CanonLink &c = keys[(size_t)owner[sl]];
-            uint32_t *e = &kt.links[sl * LK_WORDS];
-            e[0] = c.k.w0; e[1] = c.k.w1; e[2] = c.k.w2; e[3] = c.k.w3; e[4] = c.k.w4; e[5] = c.f5; e[6] = c.h0; e[7] = c.h1;
+        lap("link candidates");
+        std::vector<uint32_t> unplaced;
+        uint64_t n_unplaced = 0;
+        std::vector<int64_t> owner = cuckoo_place(pre, kt.link_mask, kt.link_seed, n_unplaced, &unplaced);
+        for (uint64_t j = 0; j < lsz; ++j) {
+            if (owner[j] < 0) continue;
+            for (int w = 0; w < 4; ++w) kt.links[j * LINK_ENT_WORDS + w] = ent[(size_t)owner[j] * 4 + w];
         }
-        for (size_t sl = 0; sl < owner.size(); ++sl) {
-            if (owner[sl] < 0) continue;
-            const uint32_t b1 = b1_of(owner[sl]);
-            if (sl / 2 != b1) { kt.links[(size_t)b1 * LB_WORDS + 5] |= LKF_OVER; ++kt.n_second; }   // (a key is evicted from full buckets only: entry 0 of its first bucket is in use)
-        }
-        break;
+        kt.links_unplaced = n_unplaced;
+        for (uint32_t k : unplaced) kt.names[(size_t)node_slot[left_node[k]] * NAME_ENT_WORDS + 6] |= 1u << 5;
     }
     lap("link table placement");
+    kt.node_pre.swap(node_pre); kt.node_has.swap(node_has); kt.node_slot.swap(node_slot);
     return kt;
-}
-
-// the kernel's lookup, on the host (table checks, tests/hostsim): entry of the directed link or nullptr; flipped as link_key says
-inline const uint32_t *link_find(const KernelTables &kt, const LinkKey &k) {
-    const uint64_t h = link_hash(k);
-    const uint32_t b1 = link_bucket1(h, kt.l_buckets);
-    const uint32_t *e = &kt.links[(size_t)b1 * LB_WORDS];
-    if (e[4] != 0xFFFFFFFFu && link_match(e, k)) return e;
-    if (e[LK_WORDS + 4] != 0xFFFFFFFFu && link_match(e + LK_WORDS, k)) return e + LK_WORDS;
-    if (e[4] == 0xFFFFFFFFu || !(e[5] & LKF_OVER)) return nullptr;
-    const uint32_t b2 = link_bucket2(h, kt.l_buckets, b1);
-    e = &kt.links[(size_t)b2 * LB_WORDS];
-    if (e[4] != 0xFFFFFFFFu && link_match(e, k)) return e;
-    if (e[LK_WORDS + 4] != 0xFFFFFFFFu && link_match(e + LK_WORDS, k)) return e + LK_WORDS;
-    return nullptr;
 }
 
 }  // namespace svjg

@@ -35,21 +35,20 @@ constexpr uint32_t MAXL = 64;                       // line starts per stripe = 
 #endif
 constexpr uint32_t CAP_O = SVJG_CAP_O;              // orientation marks ('<' '>') per stripe
 constexpr uint32_t KMAX = 64;                    // path nodes per alignment handled by the main kernel: one wave pass (longer paths: exact path)
-constexpr uint32_t NODE_NAME_MAX = 48;                // bytes of a node name the node passes parse (a chromosome name of up to 24 bytes, ':', two decimals of up to nine digits)
 constexpr uint32_t LRW = MAXL;                   // lines per round
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
 // LDS of one worker (bytes); the hardware hands LDS out in units of 1280 bytes
 constexpr uint32_t L_TEXT = 0;                                             // staged text + slack for the word reads behind a name / column
-constexpr uint32_t L_NDBM = L_TEXT + TEXT + 64;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab (line phase: decimal columns; node passes: where a node name's ':' and '-' / '.' are)
-constexpr uint32_t L_TBM = L_NDBM + TEXT / 8 + 16;                         // u32[TEXT/32 + 4] one bit per byte: a tab (the line phase walks a line's columns on it)
-constexpr uint32_t L_RL = L_TBM;                                           // uint4[LRW] per line, written at the END of the line phase (the tab bitmap is dead by then; a stripe has one round):
+constexpr uint32_t L_NDBM = L_TEXT + TEXT + 64;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab (line phase only)
+constexpr uint32_t L_RL = L_NDBM;                                          // uint4[LRW] per line, written at the END of the line phase (the bitmap is dead by then):
                                                                            //   need_l, need_r, first mark (rel.) | k << 16 | status << 24, tab behind the path
+constexpr uint32_t L_TBM = L_NDBM + TEXT / 8 + 16;                         // u32[TEXT/32 + 4] one bit per byte: a tab (the line phase walks a line's columns on it)
 constexpr uint32_t L_OPL = L_TBM + TEXT / 8 + 16;                          // u32[CAP_O + 8]   orientation mark #o: position | line (ordinal in the stripe) << 16
 constexpr uint32_t L_LINE = L_OPL + (CAP_O + 8) * 4;                       // u16[2][MAXL + 8] line #l: start, marks in front of it ; [n].start = 0xFFFF
 constexpr uint32_t LDS_MAIN = L_LINE + (MAXL + 8) * 4;
 constexpr uint32_t LDS_GRANULE = 1280;
-static_assert(LRW * 16 <= TEXT / 8 + 16 && MAXL <= LRW, "the per-line records fit the bitmap they replace; one round of lines per stripe");
+static_assert(LRW * 16 <= TEXT / 8 + 16, "the per-line records fit the bitmap they replace");
 static_assert(LDS_MAIN <= 9 * LDS_GRANULE, "fourteen workers per CU");
 static_assert(L_NDBM % 16 == 0 && L_TBM % 16 == 0 && L_OPL % 16 == 0 && L_LINE % 16 == 0 && L_RL % 16 == 0, "LDS alignment");
 
@@ -134,12 +133,47 @@ __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
 
 enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round
 
-// the low min(max(bits, 0), 32) bits set: high half of 0x00000000FFFFFFFF << that
+// Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the 64-bit pre-hash of the node-name table
+// (svjg_line.h: name_prehash), in two parts: words 0..5 (enough for names of up to 24 bytes; d[6] = d[7] = 0) and, for
+// longer names, words 6 and 7 and what they add to the hash.
+// words in front of word L / 4 are name bytes only, that word keeps its first L % 4 bytes, the ones behind it are zero
+// the low min(max(bits, 0), 32) bits set (bits = name bits left from this word on): high half of 0x00000000FFFFFFFF << that
 __device__ inline uint32_t name_word_mask(int32_t bits) {
     const uint32_t n = (uint32_t)(bits < 0 ? 0 : bits > 32 ? 32 : bits);       // (one v_med3_i32)
     return (uint32_t)((0xFFFFFFFFull << n) >> 32);
 }
 typedef uint32_t u32_any __attribute__((aligned(1)));                   // LDS words at any byte address (gfx950 reads them as they are: tools/ubench/lds_unaligned.hip)
+__device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
+    const u32_any *w = (const u32_any *)(text + a0);
+    uint64_t h = (uint64_t)L * 0x7FEB352Du;
+    const uint32_t C[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du};
+    d[6] = 0u; d[7] = 0u;
+    const int32_t bits = (int32_t)(8u * L);
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) {
+        d[i] = w[i] & name_word_mask(bits - 32 * (int32_t)i);
+        h += (uint64_t)d[i] * C[i];
+    }
+    return h;
+}
+__device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
+    const u32_any *w = (const u32_any *)(text + a0);
+    const int32_t bits = (int32_t)(8u * L);
+    const uint32_t x6 = w[6], x7 = w[7];
+    d[6] = x6 & name_word_mask(bits - 192);
+    d[7] = x7 & name_word_mask(bits - 224);
+    return (uint64_t)d[6] * 0xFD7046C5u + (uint64_t)d[7] * 0xB55A4F09u;
+}
+
+// record of the node-name table (svjg_host_tables.h): r0 = name bytes 0..15, r1 = bytes 16..23 | meta | length in bp,
+// r2.xy = bytes 24..31 (only names longer than 24 bytes look at them)
+__device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[8], uint32_t L) {
+    // one OR of differences instead of a chain of compares (three-input bit operations: (a ^ b) | c is one instruction)
+    uint32_t diff = ((r1.z & 31u) ^ (L - 1u)) | (r0.x ^ d[0]) | (r0.y ^ d[1]) | (r0.z ^ d[2]) | (r0.w ^ d[3]) | (r1.x ^ d[4]) | (r1.y ^ d[5]);
+    const uint32_t tail = (r2.x ^ d[6]) | (r2.y ^ d[7]);
+    diff |= L > 24u ? tail : 0u;
+    return diff == 0u;
+}
 
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, the fences only pin the compiler
 __device__ inline void wave_sync() {
@@ -254,34 +288,15 @@ __device__ inline bool field_is_zero(const uint8_t *text, uint32_t a, uint32_t n
     return x == 0 && (n < 9 || ((uint32_t)text[a + 8] & 0xFu) == 0);
 }
 
-// bits [a, a + n) of the "not a digit" bitmap hold nothing but tabs, n <= 64 (three words of each bitmap are read: they are padded)
-__device__ inline bool digits_and_tabs(const uint32_t *ndbm, const uint32_t *tbm, uint32_t a, uint32_t n) {
-    const uint32_t *w = ndbm + (a >> 5), *t = tbm + (a >> 5);
+// no bit set in bits [a, a + n) of a bitmap, n <= 64 (three words are read: the bitmap is padded)
+__device__ inline bool bits_clear(const uint32_t *bm, uint32_t a, uint32_t n) {
+    const uint32_t *w = bm + (a >> 5);
     const uint32_t sh = a & 31u;
-    const uint32_t x0 = w[0] & ~t[0], x1 = w[1] & ~t[1], x2 = w[2] & ~t[2];
-    unsigned long long x = ((unsigned long long)x0 | ((unsigned long long)x1 << 32)) >> sh;
-    if (sh) x |= (unsigned long long)x2 << (64u - sh);
+    const unsigned long long lo = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+    unsigned long long x = lo >> sh;
+    if (sh) x |= (unsigned long long)w[2] << (64u - sh);
     const unsigned long long m = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
     return (x & m) == 0;
-}
-
-// A node name's decimal field behind its ':' / '-' / '.' at text[p]: the separator byte -> sepch, the 1 <= n <= 9 digits behind it ->
-// value (known to be digits: the "not a digit" bitmap), lead0: a leading zero (int() takes it, the spelling of a graph node never has one).
-// Three unaligned LDS words; straight-line SWAR as field_val.
-__device__ inline uint32_t field_behind(const uint8_t *text, uint32_t p, uint32_t n, uint32_t &sepch, bool &lead0) {
-    const u32_any *w = (const u32_any *)(text + p);
-    const uint32_t W0 = w[0], W1 = w[1], W2 = w[2];
-    sepch = W0 & 0xFFu;
-    const uint32_t d0 = __builtin_amdgcn_alignbyte(W1, W0, 1), d1 = __builtin_amdgcn_alignbyte(W2, W1, 1);
-    lead0 = (d0 & 0xFFu) == (uint32_t)'0' && n > 1u;
-    const uint32_t lo0 = d0 & 0x0F0F0F0Fu, hi0 = d1 & 0x0F0F0F0Fu;
-    const uint32_t n8 = n < 8 ? n : 8;
-    const unsigned long long x = (((unsigned long long)hi0 << 32) | lo0) << ((8 * (8 - n8)) & 63u);
-    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    const uint32_t pl = (((lo << 3) + (lo << 1)) + (lo >> 8)) & 0x00FF00FFu, ph = (((hi << 3) + (hi << 1)) + (hi >> 8)) & 0x00FF00FFu;
-    uint32_t r = __umul24(__umul24(pl & 0xFFu, 100u) + (pl >> 16), 10000u) + __umul24(ph & 0xFFu, 100u) + (ph >> 16);
-    if (n == 9) r = r * 10u + ((W2 >> 8) & 0xFu);
-    return r;
 }
 
 // Columns of a line on the tab bitmap (one bit per byte of the staged text).  tab_window: the 32 bits from position p on;
@@ -332,12 +347,6 @@ constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST =
 #define DIAG(bit) ((a.diag & (bit)) != 0)
 #else
 #define DIAG(bit) false
-#endif
-// measurement only (-DSVJG_NP_STOP=k builds, tools/np_stops.sh): the node pass ends after its k-th part; what it has computed so far goes to a sink nobody reads
-#ifdef SVJG_NP_STOP
-#define NP_STOP(k, v) if (SVJG_NP_STOP == (k)) { if (a.diag == 0xFFFFu) a.dbg[lane & 7u] = (unsigned long long)(v); continue; }
-#else
-#define NP_STOP(k, v)
 #endif
 #ifndef SVJG_MINW
 #define SVJG_MINW 4          /* four waves per SIMD: at most 128 VGPRs (fourteen workers per CU by LDS) */
@@ -617,13 +626,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t t1 = take_tab(wa, t0 + 1), t2 = take_tab(wa, t0 + 1), t3 = take_tab(wa, t0 + 1);
                     const uint32_t t4a = take_tab(wa, t0 + 1);
                     const uint32_t t4 = t4a < TEXT ? (t4a < e ? t4a : TEXT) : tab_from(tbm, t0 + 33 < TEXT ? t0 + 33 : TEXT, e);   // (nothing in the window: look further)
-                    // The path column ends at the first tab behind the line's LAST orientation mark (a node name has at most NODE_NAME_MAX bytes).  Should a tab sit in front of that mark (marks in later columns), the piece of text
+                    // The path column ends at the first tab behind the line's LAST orientation mark (a node name has at most 32 bytes).  Should a tab sit in front of that mark (marks in later columns), the piece of text
                     // between two marks that holds it is no node name, and the node pass sends the line to the exact path.
                     k = kall;
                     const bool kfit = k >= 1 && k <= KMAX;
                     const uint32_t m_first = OPL[o0] & 0xFFFFu, m_last = OPL[kfit ? o0 + k - 1 : o0] & 0xFFFFu;
                     uint32_t t5 = tab_near(tbm, m_last + 1);
-                    if (t5 == TEXT) t5 = tab_near(tbm, m_last + 33 < TEXT ? m_last + 33 : TEXT);   // (the node passes take names of up to NODE_NAME_MAX bytes)
+                    if (t5 == TEXT && (tab_window(tbm, m_last + 33 < TEXT ? m_last + 33 : TEXT) & 1u)) t5 = m_last + 33;   // (a 32-byte name)
                     uint32_t wb = tab_window(tbm, t5 + 1);              // columns 7..9
                     const uint32_t t6 = take_tab(wb, t5 + 1), t7 = take_tab(wb, t5 + 1), t8 = take_tab(wb, t5 + 1);
                     uint32_t wc = tab_window(tbm, t8 + 1);              // columns 10..12
@@ -638,7 +647,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // once instead of one dependent round trip per nested test).
                     const uint32_t u0 = ok ? t0 : 0u, u3 = ok ? t3 : 1u, u4 = ok ? t4 : 0u, u5 = ok ? t5 : 0u, u6 = ok ? t6 : 2u, u7 = ok ? t7 : 4u;
                     const uint32_t u8 = ok ? t8 : 6u, u9 = ok ? t9 : 8u, u10 = ok ? t10 : 10u, u11 = ok ? t11 : 12u;
-                    const bool digits = digits_and_tabs(ndbm, tbm, u0 + 1, u3 - u0 - 1) & digits_and_tabs(ndbm, tbm, u5 + 1, u11 - u5 - 1);
+                    const bool digits = bits_clear(ndbm, u0 + 1, u3 - u0 - 1) & bits_clear(ndbm, u5 + 1, u11 - u5 - 1);
                     const bool alen0 = field_is_zero(text, u9 + 1, u10 - u9 - 1);   // Alen == 0: ZeroDivisionError (no id:f: tag in this stripe): exact path decides
                     // path column (t4, t5): the first orientation mark of the line right after t4, the last one in front of t5
                     // check_bkpt_overlap (filter-alignments.py:258-273) for a link of this line reads
@@ -685,207 +694,107 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t na0 = opv + 1u;
                 const uint32_t len = ((j + 1 < lk) ? (op2.y & 0xFFFFu) : rl.w) - na0;
                 const uint32_t oribit = text[opv] == '<' ? 1u : 0u;
+                const bool probe = live && len - 1u <= 31u;              // names of 1..32 bytes; longer ones: exact path
+                uint32_t d[8];
                 tick_mem(8);                                             // (list and per-line record read)
-                NP_STOP(1, len + oribit + need_l + need_r + lnb + lk + j)
-                // -- the name in numbers: "chrom:start-end" (reference node; its length is arithmetic on the name, filter-alignments.py:343-349)
-                //    or "chrom:pos.n" (alt node).  On the "not a digit" bitmap the name's last set bit is the '-' / '.', the one in front
-                //    of it the ':' (both checked on the text); what lies between and behind are digits.  The chromosome is looked up by
-                //    its bytes in a table of a few entries (one 16-byte load that hits the L1).  Anything else — other characters,
-                //    leading zeros, more than nine digits, an unknown or odd chromosome, a name longer than NODE_NAME_MAX — is no spelling a
-                //    graph node can have as far as this kernel knows: the line takes the exact path. --
-                const bool fit = live && len - 5u <= NODE_NAME_MAX - 5u;
-                const uint32_t lenq = fit ? len : 5u;                    // (harmless positions for lanes that do not count)
-                const uint32_t wsz = lenq < 32u ? lenq : 32u, ws = na0 + lenq - wsz;   // the name's last 32 bytes hold both separators
-                uint32_t ndw;
-                { const uint32_t *nw = ndbm + (ws >> 5); ndw = __builtin_amdgcn_alignbit(nw[1], nw[0], ws & 31u) & name_word_mask((int32_t)wsz); }
-                const uint32_t q2 = 31u - (uint32_t)__builtin_clz(ndw | 1u);
-                const uint32_t nd1 = ndw & ~(1u << q2);
-                const uint32_t q1 = 31u - (uint32_t)__builtin_clz(nd1 | 1u);
-                uint32_t p1 = ws + q1, p2 = ws + q2;                    // ':' and '-' / '.'
-                uint32_t n1 = p2 - p1 - 1u, n2 = na0 + lenq - p2 - 1u, lc = p1 - na0;
-                bool good = fit & (nd1 != 0u) & (n1 - 1u <= 8u) & (n2 - 1u <= 8u) & (lc - 1u <= 23u);   // (two non-digits at least, fields of 1..9 digits)
-                p1 = good ? p1 : na0; p2 = good ? p2 : na0 + 2u; n1 = good ? n1 : 1u; n2 = good ? n2 : 1u; lc = good ? lc : 1u;
-                uint32_t ch1, ch2; bool z1, z2;
-                const uint32_t n_start = field_behind(text, p1, n1, ch1, z1), n_second = field_behind(text, p2, n2, ch2, z2);
-                const uint32_t kind = ch2 == (uint32_t)'.' ? 1u : 0u;
-                good = good & (ch1 == (uint32_t)':') & ((ch2 == (uint32_t)'-') | (kind != 0u)) & !z1 & !z2;
-                NP_STOP(2, n_start + n_second + (good ? 1u : 0u) + lc + need_l + need_r + lnb + lk + j)
-                uint32_t cmeta = CT_EMPTY, hclass = 0;
-                {
-                    const u32_any *cw = (const u32_any *)(text + na0);
-                    const uint32_t c0w = cw[0] & name_word_mask((int32_t)(8u * lc)), c1w = cw[1] & name_word_mask((int32_t)(8u * lc) - 32);
-                    uint32_t cs = chrom_short_slot(c0w, c1w, g.cs_mask, g.cs_mult);
-                    bool pend = good & (lc <= 8u);
-                    {                                                    // (every lane loads: a lane without a name asks for slot 0)
-                        const uint4 e = *(const uint4 *)(g.ctab_short + (size_t)(pend ? cs : 0u) * 4);
-                        const bool eq = pend & (e.x == c0w) & (e.y == c1w) & ((e.z >> 24) == lc) & (e.z != CT_EMPTY);
-                        cmeta = eq ? e.z : cmeta; hclass = eq ? e.w : hclass;
-                        pend = pend & !eq & (e.z != CT_EMPTY) & ((g.cs_mult & 1u) != 0u);   // (no collisions among the graph's names: one probe decides)
-                    }
-                    while (ballot64(pend)) {                            // linear probing at load <= 1/4 (graphs with so many short names that no multiplier separates them)
-                        cs = (cs + 1u) & g.cs_mask;
-                        const uint4 e = *(const uint4 *)(g.ctab_short + (size_t)(pend ? cs : 0u) * 4);
-                        const bool eq = pend & (e.x == c0w) & (e.y == c1w) & ((e.z >> 24) == lc) & (e.z != CT_EMPTY);
-                        cmeta = eq ? e.z : cmeta; hclass = eq ? e.w : hclass;
-                        pend = pend & !eq & (e.z != CT_EMPTY);
-                    }
-                    if (ballot64(good & (lc > 8u))) {                   // (wave-uniform: a chromosome name of 9..24 bytes)
-                        uint32_t w6[6];
-#pragma unroll
-                        for (uint32_t i = 0; i < 6; ++i) w6[i] = cw[i] & name_word_mask((int32_t)(8u * lc) - 32 * (int32_t)i);
-                        uint32_t cl = chrom_long_slot(w6, g.cl_mask);
-                        bool pl = good & (lc > 8u);
-                        do {
-                            const uint4 *ep = (const uint4 *)(g.ctab_long + (size_t)(pl ? cl : 0u) * 8);
-                            const uint4 e0 = ep[0], e1 = ep[1];
-                            const bool eq = pl & (e1.z != CT_EMPTY) & (((e0.x ^ w6[0]) | (e0.y ^ w6[1]) | (e0.z ^ w6[2]) | (e0.w ^ w6[3]) | (e1.x ^ w6[4]) | (e1.y ^ w6[5])) == 0u) & ((e1.z >> 24) == lc);
-                            cmeta = eq ? e1.z : cmeta; hclass = eq ? e1.w : hclass;
-                            pl = pl & !eq & (e1.z != CT_EMPTY);
-                            cl = (cl + 1u) & g.cl_mask;
-                        } while (ballot64(pl));
-                    }
-                }
-                tick_mem(9);                                             // (name bytes, numbers, chromosome)
-                NP_STOP(3, n_start + n_second + (good ? 1u : 0u) + cmeta + hclass + need_l + need_r + lnb + lk + j)
-                uint32_t lbp = kind ? 0u : n_second - n_start + 1u;      // alt nodes: the length comes with the link entry
-                good = good & (cmeta != CT_EMPTY) & (((cmeta >> 16) & CT_ODD) == 0u) & ((kind != 0u) | ((n_second >= n_start) & (lbp < (1u << 25))));   // (64 nodes of < 2^25 bp: the 32-bit path sums cannot overflow)
-                // -- the step this node -> next node in its lookup form (left strand '+': a step that leaves its left node backwards
-                //    is asked for as its reversed form, filter-alignments.py:221-225), and the ONE bucket of 64 bytes it can be in.
-                //    Every lane loads (a lane without a step: bucket 0), so nothing waits for the loads before their answers are needed --
-                const uint32_t pk = (cmeta & TAG_CHROM) | (kind << 14) | (oribit << 15) | ((good ? 1u : 0u) << 16);   // the node's tag | "this lane could read its name"
-                const uint32_t nx_pk = lane_above(pk), nx_start = lane_above(n_start), nx_second = lane_above(n_second);
-                bool flipped;
-                const LinkKey key = link_key(n_start, n_second, pk & 0xFFFFu, nx_start, nx_second, nx_pk & 0xFFFFu, flipped);
-                const uint64_t hk = link_hash(key);
-                const bool probe = live & (j + 1 < lk) & ((pk & nx_pk & 0x10000u) != 0u);
+                uint64_t h = name_words_head(text, na0, len, d);         // the first six words of the name
+                if (ballot64(probe && len > 24u)) h += name_words_tail(text, na0, len, d);   // (wave-uniform: node names of the usual length fit six words)
+                // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
+                //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
+                uint32_t dsp = 0;
+                if (probe) dsp = g.name_disp[name_bucket(h, g.name_buckets)];
+                tick_mem(9);                                             // (name bytes, hash, displacement)
+                // (lanes without a name load nothing: their record registers hold whatever was there and are looked at under `probe` only —
+                //  a later `go` implies a matched node)
                 uint4 r0, r1, r2, r3;
-                {
-                    const uint4 *e = (const uint4 *)(g.ltab + (size_t)(probe ? link_bucket1(hk, g.l_buckets) : 0u) * LB_WORDS);
+                asm volatile("" : "=v"(r0.x), "=v"(r0.y), "=v"(r0.z), "=v"(r0.w), "=v"(r1.x), "=v"(r1.y), "=v"(r1.z), "=v"(r1.w));
+                asm volatile("" : "=v"(r2.x), "=v"(r2.y), "=v"(r2.z), "=v"(r2.w), "=v"(r3.x), "=v"(r3.y), "=v"(r3.z), "=v"(r3.w));
+                if (probe) {
+                    const uint4 *e = (const uint4 *)(g.name_tab + (size_t)name_slot(h, dsp, g.name_slots) * 16);
                     r0 = e[0]; r1 = e[1]; r2 = e[2]; r3 = e[3];
                 }
                 __builtin_amdgcn_s_setprio(P_REST);
-                // a name this kernel cannot read: the line takes the exact path.  The lanes that see it say so in the line's record, and
-                // every lane of the pass reads its line's record again (all nodes of a line sit in this pass).  Ordinary text never gets here.
-                auto drop_lines = [&](bool bad) {
+                uint32_t id = NONE32, lbp = 0;
+                bool row_inline = false;
+                // id << 7 | flags << 5 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
+                if (probe && name_match(r0, r1, r2, d, len) && r1.z != 0xFFFFFFFFu && !(r1.z & 0x60u)) { id = r1.z >> 7; lbp = r1.w & 0x7FFFFFFFu; row_inline = (r1.w >> 31) != 0; }
+                // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
+                // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
+                // (all nodes of a line sit in this pass).  Ordinary text never gets here.
+                {
+                    const bool bad = live && (id == NONE32 || lbp >= (1u << 25));
                     if (ballot64(bad)) {
                         if (bad) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
                         wave_sync();
                         if ((((const uint32_t *)&RL[ln])[2] >> 24) != ST_OK) live = false;
                     }
-                };
-                drop_lines(live & !good);
-                NP_STOP(4, r0.x + r1.y + r2.z + r3.w + n_start + n_second + (live ? 1u : 0u) + hclass + need_l + need_r + lnb + lk + j + key.w3 + key.w4)
-                // -- does a line come back to a node?  (the reference works on the FIRST occurrence of a name: list.index / str.split,
-                //    filter-alignments.py:206, :269-271)  A walk whose starts rise all the way, or fall all the way, on one chromosome
-                //    cannot; only when some line of the pass does neither, every lane looks at the lanes below it for its own
-                //    start | kind (+ the suffix class of its chromosome): one DPP wave shift per distance, as far as the longest line
-                //    of the pass reaches.  Two DIFFERENT names of one line that agree in these are what a name that is a substring of
-                //    another looks like (the ':' of both coincide, so the starts do, and one chromosome name ends with the
-                //    other): such a line takes the exact path. --
-                uint32_t f = lane;
-                {
-                    // (an insertion's node "c:p.n" and the reference node behind it "c:p-e" share the number: the alt node sorts first)
-                    const uint32_t mk = (n_start << 1) | (kind ^ 1u), nx_mk = (nx_start << 1) | (((nx_pk >> 14) & 1u) ^ 1u);
-                    const uint32_t dir = ((((nx_pk ^ pk) & TAG_CHROM) != 0u) | (nx_mk == mk)) ? 0u : nx_mk > mk ? 1u : 2u;
-                    const uint32_t dprev = lane_below(dir);
-                    if (ballot64(live & (j + 1 < lk) & ((dir == 0u) | ((j >= 1u) & (dir != dprev))))) {
-                        // (salted with the line: lanes of other lines do not compare equal — and if ever they do, the check below sends
-                        //  the line to the exact path)
-                        const uint32_t k32 = live ? ((n_start | (kind << 30)) + hclass * 0x9E3779B1u) ^ (ln * 0x85EBCA77u) : NONE32 - lane;
-                        uint32_t y = k32;
-                        for (uint32_t dd = 1; ballot64(j >= dd); dd += 4) {
-                            y = lane_below_or(y, NONE32); f = y == k32 ? lane - dd : f;
-                            y = lane_below_or(y, NONE32); f = y == k32 ? lane - dd - 1u : f;
-                            y = lane_below_or(y, NONE32); f = y == k32 ? lane - dd - 2u : f;
-                            y = lane_below_or(y, NONE32); f = y == k32 ? lane - dd - 3u : f;
-                        }
-                        const bool back = live & (f != lane);
-                        if (ballot64(back)) {
-                            const uint32_t o_pk = (uint32_t)__shfl((int)pk, (int)f), o_start = (uint32_t)__shfl((int)n_start, (int)f), o_second = (uint32_t)__shfl((int)n_second, (int)f);
-                            const uint32_t o_ln = (uint32_t)__shfl((int)ln, (int)f);
-                            drop_lines(back & ((((o_pk ^ pk) & (TAG_CHROM | TAG_KIND)) != 0u) | (o_second != n_second) | (o_start != n_start) | (o_ln != ln) | (f > lane)));
-                        }
-                    }
                 }
-                if (!live) { j = 0; lk = 0; lnb = 0; lbp = 0; f = lane; }
-                const bool revisits = ballot64(live & (f != lane)) != 0;  // wave-uniform: some line of the pass comes back to a node
+                if (!live) { j = 0; lk = 0; lnb = 0; id = NONE32; lbp = 0; }
                 tick(4);
-                NP_STOP(5, r0.x + r1.y + r2.z + r3.w + n_start + n_second + (live ? 1u : 0u) + f + need_l + need_r + lnb + lk + j + key.w3 + key.w4 + lbp)
-                // -- the probe's answer: which of the bucket's two entries, if any; a full bucket may have sent the key to its second bucket --
-                uint32_t e5 = 0, h0 = 0, h1 = 0;
-                bool hit = false;
-                auto take = [&](const LinkKey &k, bool want) -> bool {
-                    const bool m0 = want & (((r0.x ^ k.w0) | (r0.y ^ k.w1) | (r0.z ^ k.w2) | (r0.w ^ k.w3) | (r1.x ^ k.w4)) == 0u);
-                    const bool m1 = want & (((r2.x ^ k.w0) | (r2.y ^ k.w1) | (r2.z ^ k.w2) | (r2.w ^ k.w3) | (r3.x ^ k.w4)) == 0u);
-                    e5 = m0 ? r1.y : m1 ? r3.y : e5; h0 = m0 ? r1.z : m1 ? r3.z : h0; h1 = m0 ? r1.w : m1 ? r3.w : h1;
-                    hit = hit | m0 | m1;
-                    return want & !(m0 | m1) & (r1.x != 0xFFFFFFFFu) & ((r1.y & LKF_OVER) != 0u);
-                };
-                auto second_bucket = [&](const LinkKey &k, uint64_t hh, bool more) {
-                    if (ballot64(more)) {
-                        const uint32_t b1 = link_bucket1(hh, g.l_buckets);
-                        const uint4 *e = (const uint4 *)(g.ltab + (size_t)(more ? link_bucket2(hh, g.l_buckets, b1) : 0u) * LB_WORDS);
-                        r0 = e[0]; r1 = e[1]; r2 = e[2]; r3 = e[3];
-                        take(k, more);
-                    }
-                };
-                second_bucket(key, hk, take(key, probe));
-                NP_STOP(6, e5 + h0 + h1 + (hit ? 1u : 0u) + (live ? 1u : 0u) + f + need_l + need_r + lnb + lk + j + lbp)
-                // -- the link between the FIRST occurrences of both names: same names, so the same key unless a strand differs --
-                uint32_t fl = lane, fr = lane + 1u;
-                if (revisits) {
-                    fl = f; fr = lane_above(f);
-                    const uint32_t orl = (uint32_t)__shfl((int)oribit, (int)fl), orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
-                    const bool other = probe & live & ((orl != oribit) | (orr != ((nx_pk >> 15) & 1u)));
-                    if (ballot64(other)) {
-                        bool fl2;
-                        const LinkKey k2 = link_key(n_start, n_second, (pk & 0x7FFFu) | (orl << 15), nx_start, nx_second, (nx_pk & 0x7FFFu) | (orr << 15), fl2);
-                        const uint64_t h2 = link_hash(k2);
-                        const uint4 *e = (const uint4 *)(g.ltab + (size_t)(other ? link_bucket1(h2, g.l_buckets) : 0u) * LB_WORDS);
-                        r0 = e[0]; r1 = e[1]; r2 = e[2]; r3 = e[3];
-                        if (other) { hit = false; flipped = fl2; }
-                        second_bucket(k2, h2, take(k2, other));
-                    }
-                }
-                hit = hit & live;
-                // -- alt nodes: the length comes with a link of the node, its own step's or the step's in front of it; a link flagged for
-                //    the exact path (unknown length, two alt nodes) or an alt node without either: exact path --
-                {
-                    // (which node of the entry is the alt one: the kind bits of its tags; flipped: the walk's left node is the entry's right one)
-                    const uint32_t alen = hit ? e5 >> LK_ALT_SHIFT : LK_ALT_NONE;
-                    const uint32_t nx_kind = (nx_pk >> 14) & 1u;
-                    const uint32_t from_prev = lane_below_or(nx_kind ? alen : LK_ALT_NONE, LK_ALT_NONE);
-                    if (ballot64(live & ((kind != 0u) | (hit & ((e5 & LKF_EXACT) != 0u))))) {
-                        uint32_t mine = (alen != LK_ALT_NONE) ? alen : (j >= 1u ? from_prev : LK_ALT_NONE);
-                        if (revisits) {                                  // (a node the line comes back to: the links between first occurrences may not exist; its length is the first occurrence's)
-                            const uint32_t first = (uint32_t)__shfl((int)mine, (int)(f & 63u));
-                            mine = (mine == LK_ALT_NONE && f != lane) ? first : mine;
-                        }
-                        lbp = (live & (kind != 0u)) ? (mine != LK_ALT_NONE ? mine : 0u) : lbp;
-                        drop_lines(live & (((kind != 0u) & (mine == LK_ALT_NONE)) | (hit & ((e5 & LKF_EXACT) != 0u))));
-                        if (!live) { j = 0; lk = 0; lnb = 0; lbp = 0; hit = false; }
-                    }
-                }
                 // -- running path length of the line (inclusive) = wave prefix sum minus what precedes the line's first node --
-                NP_STOP(7, e5 + h0 + h1 + (hit ? 1u : 0u) + (live ? 1u : 0u) + f + need_l + need_r + lnb + lk + j + lbp)
                 const uint32_t gsum = wave_incl_scan(lbp);               // every lbp < 2^25: no overflow over 64 lanes
                 const uint32_t gfirst = (uint32_t)__shfl((int)(gsum - lbp), (int)lnb);
                 const uint32_t glast = (uint32_t)__shfl((int)gsum, (int)(lane + (lk ? lk - 1 - j : 0u)));
                 const uint32_t pre = gsum - gfirst, tot = glast - gfirst;
+                // -- first occurrence of every name in its line (the reference's list.index / str.split quirks): every lane looks at
+                //    the lanes below it, one DPP wave shift per distance (no LDS round trips), as far as the longest line of the pass
+                //    reaches.  key = id | line << 26: lanes of other lines never compare equal --
+                uint32_t f = lane;
+                {
+                    const uint32_t key = live ? (id | (ln << 26)) : NONE32;
+                    uint32_t y = key;
+                    for (uint32_t dd = 1; ballot64(j >= dd); dd += 4) {
+                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd;
+                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 1u;
+                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 2u;
+                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 3u;
+                    }
+                }
+                const bool revisits = ballot64(live && f != lane) != 0;  // wave-uniform: some line of the pass comes back to a node
                 tick(5);
-                uint32_t pre_l = pre, pre_rx = pre;
+                // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
+                //    (str.split / list.index, filter-alignments.py:206, :269-271); equal names have equal ids and hashes --
+                const uint32_t nxv = lane_above((id << 1) | oribit);
+                const uint32_t idl = id, idr = nxv >> 1;
+                uint32_t fl = lane, fr = lane + 1u, pre_l = pre, pre_rx = pre, orl = oribit, orr = nxv & 1u;
                 if (revisits) {
+                    fl = f; fr = lane_above(f);
                     pre_l = (uint32_t)__shfl((int)pre, (int)fl);
                     pre_rx = (uint32_t)__shfl((int)pre, (int)((fr - 1u) & 63u));
+                    orl = (uint32_t)__shfl((int)oribit, (int)fl); orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
                 }
-                // overlap test of the step (check_bkpt_overlap, filter-alignments.py:258-273; a lane without a step fails it)
-                const bool go = live & (j + 1 < lk) & (pre_l >= need_l) & (tot - (fr > lnb ? pre_rx : 0u) >= need_r);
-                const bool found = go & hit;
-                NP_STOP(8, h0 + h1 + (found ? 1u : 0u))
-                uint32_t nh = found ? (h1 == LINK_NO_HIT ? 1u : 2u) : 0u;
+                // overlap test of the step (a lane without a step fails it); then the link is looked for among the (up to four)
+                // that sit in the left node's record — straight selects, no branches —; the link table is asked only if it is not
+                // there and the node has more links, or for a revisited node (the link between the first occurrences)
+                const bool go = live && j + 1 < lk && pre_l >= need_l && tot - (fr > lnb ? pre_rx : 0u) >= need_r;
+                const bool moved = revisits && (fl != lane || fr != lane + 1u);
+                const uint32_t want = (idr << 2) | orl | (orr << 1);
+                const bool m0 = len <= 24u && r2.x == want, m1 = r2.z == want, m2 = r3.x == want, m3 = r3.z == want;
+                const bool inl = m0 || m1 || m2 || m3;
+                const uint32_t v = m0 ? r2.y : m1 ? r2.w : m2 ? r3.y : r3.w;
+                const bool found = go && !moved && inl;
+                const bool ask = go && (moved || (!inl && !row_inline));
+                uint32_t nh = found ? 1u : 0u, h0 = v, h1 = 0;
                 const uint32_t *hp = nullptr;                             // more than two hits: the list
-                if (ballot64(found & ((h0 & LINK_MANY) != 0u) & (h1 != LINK_NO_HIT))) {   // (wave-uniform: a link with several hits)
-                    if (found && (h0 & LINK_MANY) && h1 != LINK_NO_HIT) { hp = g.hits + (h0 & ~LINK_MANY); nh = h1; }
+                if (ballot64(found && (v & 0x80000000u))) {              // (wave-uniform: a link with several hits)
+                    if (found && (v & 0x80000000u)) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1]; }
+                }
+                if (ballot64(ask)) {
+                    const uint64_t hl = h;                               // (the first occurrence spells the same name)
+                    const uint64_t hr = ((uint64_t)lane_above((uint32_t)(h >> 32)) << 32) | lane_above((uint32_t)h);
+                    if (ask) {
+                        const uint32_t klo = (idr << 1) | orr, khi = (idl << 1) | orl;
+                        uint32_t sa, sb2;
+                        link_slots(link_prehash(hl, orl, hr, orr), g.link_seed, g.link_mask, sa, sb2);
+                        uint4 ek = *(const uint4 *)(g.link_tab + (size_t)sa * 4);
+                        const uint4 ek2 = *(const uint4 *)(g.link_tab + (size_t)sb2 * 4);
+                        if (!(ek.x == klo && ek.y == khi)) ek = ek2;                          // the other candidate slot
+                        if (ek.x == klo && ek.y == khi) {
+                            // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
+                            if ((ek.z & 0x80000000u) && ek.w != 0xFFFFFFFFu && ek.z != 0xFFFFFFFFu) { hp = g.hits + (ek.z & 0x7FFFFFFFu); nh = ek.w; }
+                            else { h0 = ek.z; h1 = ek.w; nh = ek.w == 0xFFFFFFFFu ? 1u : 2u; }
+                        }
+                    }
                 }
                 // hit records: one aggregated atomic per wave reserves the slots
                 unsigned long long rbase = 0;

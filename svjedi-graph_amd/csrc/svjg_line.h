@@ -36,84 +36,52 @@ struct GraphView {
     uint32_t n_chrom;
     uint32_t hash_mask;
     uint32_t d_over;
-    // main kernel (svjg_host_tables.h): the chromosome names as hash tables of raw bytes, and the link table
-    const uint32_t *ctab_short;  // names of 1..8 bytes: 4 words per entry (bytes 0..3, bytes 4..7, index | flags << 16 | length << 24, suffix class)
-    const uint32_t *ctab_long;   // names of 9..24 bytes: 8 words per entry (bytes 0..23, index | flags << 16 | length << 24, suffix class)
-    uint32_t cs_mask, cl_mask;   // entries - 1 (powers of two; linear probing, an entry of all ones ends a probe sequence)
-    uint32_t cs_mult;            // multiplier of the short names' slot hash; bit 0 clear: the builder found one without collisions, ONE probe decides
-    const uint32_t *ltab;        // canonical link -> hits: buckets of LB_WORDS words (two entries of LK_WORDS)
-    uint32_t l_buckets;
+    const uint32_t *name_ihits;  // hit lists of the records' inline links with more than one hit
+    const uint32_t *name_tab;    // canonical node name -> node record (svjg_host_tables.h), 16 words (one 64-byte line) per slot
+    const uint16_t *name_disp;   // perfect hash of the node names: displacement of every bucket
+    uint32_t name_slots, name_buckets;
+    uint32_t name_complete;      // every node name is in name_tab: a miss there means "no such node" (else: search the sorted table)
+    const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 4 words per entry
+    uint32_t link_mask, link_seed;
 };
 
 
-// ---- link table of the main kernel (built by svjg_host_tables.h) -----------------------------------------------------
-// The reference never looks a node up: a reference node's length is arithmetic on its name (filter-alignments.py:343-349)
-// and the only dictionary it probes is keyed by the LINK (:141-153).  So is this table: the kernel parses every path node
-// into (chromosome index, start, end | multiplicity, kind) and probes ONE 64-byte bucket per path step.
-//   * a link is looked up in the form whose LEFT strand is '+': a step whose left node is walked backwards is asked for as its
-//     reversed form (filter-alignments.py:221-225; both forms give the same hits).  (+,+) / (-,-) pairs share one entry that
-//     way, (+,-) links have two (each is the other's reversed form), and the reversed form of a (-,+) link is a (-,+) link
-//     again: those are stored under both spellings and found through the reversed one.
-//   * an entry (LK_WORDS = 8 words): [0] left start  [1] left end (alt node: multiplicity)  [2] right start  [3] right end
-//     [4] the two nodes' tags, left | right << 16; a tag = chromosome index (14 bits) | kind << 14 | strand << 15 (all ones: empty)
-//     [5] LKF_OVER | LKF_EXACT | length in bp of the link's alt node << 6 (LK_ALT_NONE: no alt node, or the link is flagged
-//         LKF_EXACT: unknown length / two alt nodes)
-//     [6], [7] hits as in the CSR rows: one (hit, LINK_NO_HIT), two (hit, hit), more (LINK_MANY | index into hits[], count)
-//   * a bucket holds two entries; a key sits in its first bucket unless that one was full: then LKF_OVER is set in the
-//     first bucket's entry 0 and the key sits in its second bucket (the kernel's rare second probe)
-constexpr uint32_t LK_WORDS = 8, LB_WORDS = 16;
-constexpr uint32_t LKF_OVER = 16u, LKF_EXACT = 32u;
-constexpr uint32_t TAG_KIND = 1u << 14, TAG_STRAND = 1u << 15, TAG_CHROM = 0x3FFFu;   // node tag; more chromosomes than TAG_CHROM: exact path only
-constexpr uint32_t LK_ALT_SHIFT = 6, LK_ALT_NONE = 0x3FFFFFFu;
-constexpr uint32_t LINK_NO_HIT = 0xFFFFFFFFu, LINK_MANY = 0x80000000u;
-constexpr uint32_t CT_ODD = 1u;                                  // chromosome-table flag: the name holds a ':' (the main kernel's substring argument does not cover it)
-constexpr uint32_t CT_EMPTY = 0xFFFFFFFFu;
-
+// ---- perfect hash of the node names (hash and displace; built by svjg_host_tables.h) -------------------------------
+// pre-hash = 64-bit multilinear sum of the name's eight zero-padded words and its length; bucket from the pre-hash,
+// slot from the pre-hash and the bucket's displacement: every name of the graph has a slot of its own, so a lookup
+// touches one 2-byte displacement (a small, cache-resident array) and exactly ONE 64-byte record.
 SVJG_HD uint32_t fmix32(uint32_t z) { z ^= z >> 16; z *= 0x7FEB352Du; z ^= z >> 15; z *= 0x846CA68Bu; z ^= z >> 16; return z; }
 SVJG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-
-// node = (start a, end / multiplicity b, tag t = chromosome | kind (alt node "chrom:pos.n") | strand ('-'))
-struct LinkKey { uint32_t w0, w1, w2, w3, w4; };
-// the lookup form of the link L -> R (left strand '+'): a walk that leaves L backwards asks for the reversed link — the nodes trade
-// places and both strands turn.  flipped: the walk's left node is the entry's right node
-SVJG_HD LinkKey link_key(uint32_t al, uint32_t bl, uint32_t tl, uint32_t ar, uint32_t br, uint32_t tr, bool &flipped) {
-    flipped = (tl & TAG_STRAND) != 0u;
-    LinkKey k;
-    k.w0 = flipped ? ar : al; k.w1 = flipped ? br : bl; k.w2 = flipped ? al : ar; k.w3 = flipped ? bl : br;
-    const uint32_t fwd = tl | (tr << 16), rev = (tr | (tl << 16)) ^ (TAG_STRAND | (TAG_STRAND << 16));
-    k.w4 = flipped ? rev : fwd;
-    return k;
+SVJG_HD uint64_t name_prehash(const uint32_t d[8], uint32_t len) {
+    const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+    uint64_t h = (uint64_t)len * 0x7FEB352Du;
+    for (int i = 0; i < 8; ++i) h += (uint64_t)d[i] * C[i];
+    return h;
 }
-SVJG_HD uint64_t link_hash(const LinkKey &k) {
-    return (uint64_t)k.w0 * 0x9E3779B1u + (uint64_t)k.w1 * 0x85EBCA77u + (uint64_t)k.w2 * 0xC2B2AE3Du + (uint64_t)k.w3 * 0x27D4EB2Fu +
-           (uint64_t)k.w4 * 0x165667B1u;
-}
-SVJG_HD uint32_t link_bucket1(uint64_t h, uint32_t n_buckets) {
+// The pre-hash is a multiply-and-add with 32-bit factors: its words are only lightly mixed (names that differ in a digit or
+// two have nearby high words), so bucket and slot each put it through one multiply / xor-shift round of their own (measured:
+// without it hash-and-displace finds no placement for a DEL-only single-chromosome graph; two full finalisers — what this
+// replaced — cost about three times the instructions of the whole lookup's compare).
+SVJG_HD uint32_t name_bucket(uint64_t h, uint32_t n_buckets) {
     uint32_t z = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u;
     z ^= z >> 15;
     return mulhi32(z * 0x846CA68Bu, n_buckets);
 }
-SVJG_HD uint32_t link_bucket2(uint64_t h, uint32_t n_buckets, uint32_t b1) {
-    uint32_t y = ((uint32_t)(h >> 32) * 0x85EBCA77u) ^ (uint32_t)h;
-    y ^= y >> 13;
-    const uint32_t b2 = mulhi32(y * 0xC2B2AE3Du, n_buckets);
-    return b2 != b1 ? b2 : (b1 + 1u < n_buckets ? b1 + 1u : 0u);
+SVJG_HD uint32_t name_slot(uint64_t h, uint32_t disp, uint32_t n_slots) {
+    const uint32_t x = ((uint32_t)h * 0x85EBCA77u) ^ (uint32_t)(h >> 32);
+    uint32_t y = x * ((disp * 0x632BE5ABu + 0x7FEB352Du) | 1u);
+    y ^= y >> 15;
+    return mulhi32(y * 0x2C1B3C6Du, n_slots);
 }
-SVJG_HD bool link_match(const uint32_t *e, const LinkKey &k) {
-    return (((e[0] ^ k.w0) | (e[1] ^ k.w1) | (e[2] ^ k.w2) | (e[3] ^ k.w3) | (e[4] ^ k.w4)) == 0u);
+// Link table (two-choice): the slots of a link follow from the 64-bit name pre-hashes of its two nodes and the strands
+// (1 = '-'), so a lookup needs no node ids; with 64 bits no three links share their pair of slots.
+SVJG_HD uint64_t link_prehash(uint64_t hl, uint32_t sl, uint64_t hr, uint32_t sr) {
+    return hl * 0x9E3779B97F4A7C15ull + (hr + sl * 0x68E31DA4B5297A4Dull + sr * 0xD6E8FEB86659FD93ull) * 0xC2B2AE3D27D4EB4Full;
 }
-// chromosome tables: slot of a name from its zero-padded words
-SVJG_HD uint32_t chrom_short_slot(uint32_t lo, uint32_t hi, uint32_t mask, uint32_t mult) {
-    uint32_t x = (lo * (mult | 1u)) ^ (hi * 0x85EBCA77u);
-    x ^= x >> 15;
-    return ((x * 0x2C1B3C6Du) >> 12) & mask;
-}
-SVJG_HD uint32_t chrom_long_slot(const uint32_t w[6], uint32_t mask) {
-    const uint64_t h = (uint64_t)w[0] * 0x9E3779B1u + (uint64_t)w[1] * 0x85EBCA77u + (uint64_t)w[2] * 0xC2B2AE3Du + (uint64_t)w[3] * 0x27D4EB2Fu +
-                       (uint64_t)w[4] * 0x165667B1u + (uint64_t)w[5] * 0xD3A2646Du;
-    uint32_t x = ((uint32_t)h ^ (uint32_t)(h >> 32)) * 0x9E3779B1u;
-    x ^= x >> 15;
-    return ((x * 0x2C1B3C6Du) >> 10) & mask;
+SVJG_HD void link_slots(uint64_t v, uint32_t seed, uint32_t mask, uint32_t &s1, uint32_t &s2) {
+    s1 = fmix32((uint32_t)v ^ seed) & mask;
+    s2 = fmix32((uint32_t)(v >> 32) + seed * 0x85EBCA6Bu) & mask;
+    if (s2 == s1) s2 = s1 ^ 1u;
 }
 
 SVJG_HD bool py_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
@@ -260,6 +228,23 @@ SVJG_HD bool next_node(P t, uint64_t pe, bool oriented, uint64_t &pos, NameRef &
     return false;
 }
 
+// Node-name table of the main kernel (svjg_host_tables.h), probed with the raw bytes of a name of 1..32 bytes:
+// node id, or NONE32 when the name's slot does not hold this spelling.
+template <class P>
+SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
+    const uint32_t len = (uint32_t)(nm.e - nm.s);
+    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t b = 0; b < len; ++b) d[b >> 2] |= (uint32_t)(uint8_t)t[nm.s + b] << (8 * (b & 3));
+    const uint64_t h = name_prehash(d, len);
+    const uint32_t slot = name_slot(h, g.name_disp[name_bucket(h, g.name_buckets)], g.name_slots);
+    const uint32_t *e = g.name_tab + (uint64_t)slot * 16;
+    const uint32_t meta = e[6];
+    if (meta == 0xFFFFFFFFu || (meta & 31u) != len - 1u) return NONE32;
+    if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && (len <= 24u || (e[8] == d[6] && e[9] == d[7])))
+        return meta >> 7;
+    return NONE32;
+}
+
 // exact name -> node id (only canonical spellings can be in the table)
 template <class P>
 SVJG_HD uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_form) {
@@ -270,6 +255,10 @@ SVJG_HD uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_
         for (uint64_t q = (colon == nm.e ? nm.s : colon + 1); q < nm.e; ++q) if (t[q] == '.') *is_alt_form = true;
     }
     if (colon == nm.e) return NONE32;
+    if (g.name_tab && nm.e - nm.s <= 32) {                             // the canonical spelling is the only one that resolves
+        uint32_t id = name_tab_find(g, t, nm);
+        if (id != NONE32 || g.name_complete) return id;
+    }
     uint32_t h = FNV_INIT;
     for (uint64_t q = nm.s; q < colon; ++q) h = (h ^ (uint32_t)t[q]) * FNV_PRIME;
     uint32_t cidx = chrom_lookup(g, t, nm.s, (uint32_t)(colon - nm.s), h);

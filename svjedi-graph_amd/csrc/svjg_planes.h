@@ -89,7 +89,7 @@ SVJG_HD void span_planes(uint32_t w[16]) {
 }
 
 struct HalfClasses {                                   // one bit per byte of 32 bytes
-    uint32_t nl, cr, tab, ori, nd, dee, colon, high;   // '\n' | '\r' | '\t' | '<' '>' | not a digit | 'd' | ':' | >= 0x80
+    uint32_t nl, cr, tab, ori, nd, dee, colon, high;   // '\n' | '\r' | '\t' | '<' '>' | neither digit nor tab | 'd' | ':' | >= 0x80
 };
 
 // p = the eight planes of 32 bytes (p[k & 3][k >> 2] as span_planes leaves them: pass w + i5 * 8)
@@ -108,7 +108,7 @@ SVJG_HD HalfClasses half_classes(const uint32_t *p) {
     const uint32_t g0 = SVJG_B3(h3, P4, P3, A & B & C) & ~P0;           // 0x38, 0x3A, 0x3C, 0x3E
     r.ori = g0 & P2;                                                    // 0x3C, 0x3E
     r.colon = SVJG_B3(g0, P2, P1, A & ~B & C);                          // 0x3A
-    r.nd = ~dig;
+    r.nd = SVJG_B3(dig, r.tab, r.tab, ~(A | B));
     const uint32_t e6 = SVJG_B3(P7, P6, P5, ~A & B & C);                // 0x60 .. 0x7F
     const uint32_t e60 = SVJG_B3(e6, P4, P3, A & ~B & ~C);              // 0x60 .. 0x67
     r.dee = SVJG_B3(e60, P2, P1, A & B & ~C) & ~P0;                     // 0x64

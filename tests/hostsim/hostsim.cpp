@@ -17,19 +17,25 @@ struct CountEmit {
     void operator()(uint32_t slot, uint32_t allele) { counts[slot * 2 + allele]++; }
 };
 
-static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &hash) {
-    GraphView v{};
+static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &hash, const KernelTables *kt = nullptr) {
+    GraphView v;
     v.nodes = g->nodes; v.n_nodes = (uint32_t)g->n_nodes; v.edges = g->edges; v.hits = g->hits;
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
-    return v;                                                              // (the exact path does not touch the main kernel's tables)
+    v.name_tab = nullptr; v.name_ihits = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
+    if (kt) {                                                             // the exact path resolves names through the node-name table
+        v.name_tab = kt->names.data(); v.name_ihits = kt->ihits.data(); v.name_disp = kt->disp.data(); v.name_slots = kt->name_slots; v.name_buckets = kt->name_buckets;
+        v.name_complete = (kt->names_left_out == 0 && kt->names_skipped == 0) ? 1u : 0u;
+    }
+    return v;
 }
 
 extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n,
                                 uint32_t *counts, uint64_t *n_lines, int *exc, uint64_t *err_off)
 {
     std::vector<uint32_t> hash = build_chrom_hash(*g);
-    GraphView v = make_view(g, hash);
+    KernelTables kt = build_kernel_tables(*g);
+    GraphView v = make_view(g, hash, (g->flags & 2u) ? nullptr : &kt);      // flags bit 1 (harness only): sorted-table search instead
     const uint8_t *t = (const uint8_t *)gaf;
     *n_lines = 0; *exc = 0; *err_off = 0;
     uint64_t pos = 0;
@@ -75,81 +81,82 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
     return 0;
 }
 
-// the main kernel's tables must agree with the sorted node table / CSR rows: every directed link of the graph is found — through
-// the canonical form and the kernel's bucket probe(s) — with the same hits, every entry is some link's, and every chromosome name
-// resolves to its index
+// the main kernel's hash tables must agree with the sorted node table / CSR rows: every node name resolves to its
+// id, every CSR entry is found under its key with the same hits
 extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
     KernelTables kt = build_kernel_tables(*g);
-    uint64_t bad = kt.links_left_out, n_found = 0;
-    for (uint64_t n = 0; n < g->n_nodes; ++n) {
-        uint32_t cl, al, bl, kl;
-        node_fields(g->nodes[n], cl, al, bl, kl);
+    uint64_t bad = kt.names_left_out + kt.links_left_out, found = 0;
+    for (uint64_t j = 0; j < kt.name_slots; ++j) {
+        const uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
+        if (name_ent_empty(e)) { if (e[8] != REC_NO_LINK || e[10] != REC_NO_LINK || e[12] != REC_NO_LINK || e[14] != REC_NO_LINK) ++bad; continue; }
+        ++found;
+        uint32_t d[8];
+        name_ent_words(e, d);
+        const uint64_t h = name_prehash(d, name_ent_len(e));
+        if (j != name_slot(h, kt.disp[name_bucket(h, kt.name_buckets)], kt.name_slots)) ++bad;   // the kernel's one probe lands here
+        const uint32_t id = name_ent_id(e);
+        if (!kt.node_has[id] || kt.node_slot[id] != j || kt.node_pre[id] != h) ++bad;
+        const svjg_node &nd = g->nodes[id];
+        uint32_t kind = (uint32_t)(nd.key >> 15) & 1u, pos = (uint32_t)(nd.key >> 16);
+        if ((e[7] & ~REC_ROW_INLINE) != (kind ? nd.aux : nd.aux - pos + 1) && !(e[6] & 0x40u)) ++bad;
+        for (uint32_t b = name_ent_len(e); b < 32; ++b) if ((d[b >> 2] >> (8 * (b & 3))) & 0xFFu) ++bad;     // zero padded
+        // inline links = rows of this node, with the hits of the CSR row; REC_ROW_INLINE only if no row is missing
+        const uint32_t ra = nd.row & 0x7FFFFFFFu, rb = g->nodes[id + 1].row & 0x7FFFFFFFu;
+        uint32_t live = 0, inl = 0;
+        for (uint32_t i = ra; i < rb; ++i) live += (g->edges[i].meta >> 2) != 0;
+        for (uint32_t w = rec_first_link(e); w < 16; w += 2) {
+            const uint32_t *l = e + w;
+            if (l[0] == REC_NO_LINK) continue;
+            ++inl;
+            bool ok = false;
+            for (uint32_t i = ra; i < rb; ++i) {
+                const svjg_edge &ed = g->edges[i];
+                if (((ed.right << 2) | (ed.meta & 3u)) != l[0]) continue;
+                const uint32_t nh = ed.meta >> 2;
+                if (nh == 1) ok = l[1] == ed.h0;
+                else if (l[1] & REC_MANY) {
+                    const uint32_t *hp = &kt.ihits[l[1] & ~REC_MANY];
+                    ok = hp[0] == nh;
+                    for (uint32_t q = 0; q < nh && ok; ++q) ok = hp[1 + q] == (nh <= 2 ? (q ? ed.h1 : ed.h0) : g->hits[ed.h0 + q]);
+                }
+            }
+            if (!ok) ++bad;
+            for (uint32_t w2 = rec_first_link(e); w2 < w; w2 += 2) if (e[w2] == l[0]) ++bad;     // no key twice
+        }
+        if ((e[7] & REC_ROW_INLINE) && inl != live) ++bad;
+    }
+    if (found > g->n_nodes) ++bad;
+    uint64_t n_links = 0;
+    for (uint64_t n = 0; n < g->n_nodes; ++n)
         for (uint32_t i = g->nodes[n].row & 0x7FFFFFFFu; i < (g->nodes[n + 1].row & 0x7FFFFFFFu); ++i) {
             const svjg_edge &ed = g->edges[i];
+            uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
+            uint32_t s1, s2;
+            if (!kt.node_has[n] || !kt.node_has[ed.right]) continue;          // such lines take the exact path
+            link_slots(link_prehash(kt.node_pre[n], ed.meta & 1u, kt.node_pre[ed.right], (ed.meta >> 1) & 1u), kt.link_seed, kt.link_mask, s1, s2);
+            const uint32_t *e = &kt.links[(uint64_t)s1 * LINK_ENT_WORDS];
+            if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) e = &kt.links[(uint64_t)s2 * LINK_ENT_WORDS];
+            if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) {
+                if (!(kt.names[(size_t)kt.node_slot[n] * NAME_ENT_WORDS + 6] & (1u << 5))) ++bad;        // unplaced link: its left node must be flagged for the exact path
+                continue;
+            }
             const uint32_t nh = ed.meta >> 2;
-            uint32_t cr, ar, br, kr;
-            node_fields(g->nodes[ed.right], cr, ar, br, kr);
-            bool flipped;
-            const LinkKey k = link_key(al, bl, cl | (kl ? TAG_KIND : 0u) | ((ed.meta & 1u) ? TAG_STRAND : 0u), ar, br, cr | (kr ? TAG_KIND : 0u) | ((ed.meta & 2u) ? TAG_STRAND : 0u), flipped);
-            const uint32_t *e = link_find(kt, k);
-            if (!nh) { if (e) ++bad; continue; }
-            if (!e) { ++bad; continue; }
-            ++n_found;
-            // same multiset of hits as the row (the reversed form's row lists them in the other order)
-            std::vector<uint32_t> want, got;
-            for (uint32_t q = 0; q < nh; ++q) want.push_back(nh <= 2 ? (q ? ed.h1 : ed.h0) : g->hits[ed.h0 + q]);
-            if ((e[6] & LINK_MANY) && e[7] != LINK_NO_HIT) for (uint32_t q = 0; q < e[7]; ++q) got.push_back(g->hits[(e[6] & ~LINK_MANY) + q]);
-            else { got.push_back(e[6]); if (e[7] != LINK_NO_HIT) got.push_back(e[7]); }
-            std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
-            if (want != got) ++bad;
-            // the alt node's length, or the exact-path flag
-            const uint32_t k0 = flipped ? kr : kl, k1 = flipped ? kl : kr;
-            if ((((e[4] >> 14) & 1u) | (((e[4] >> 30) & 1u) << 1)) != (k0 | (k1 << 1))) ++bad;
-            const uint32_t alt = e[5] >> LK_ALT_SHIFT;
-            if (kl && kr) { if (!(e[5] & LKF_EXACT)) ++bad; }
-            else if (kl || kr) {
-                const uint32_t len = kl ? g->nodes[n].aux : g->nodes[ed.right].aux;
-                if (len == SVJG_LEN_UNKNOWN || len >= (1u << 25)) { if (!(e[5] & LKF_EXACT)) ++bad; }
-                else if (alt != len || (e[5] & LKF_EXACT)) ++bad;
-            } else if (alt != LK_ALT_NONE || (e[5] & LKF_EXACT)) ++bad;
+            if (nh == 1 ? (e[2] != ed.h0 || e[3] != LINK_NO_HIT) : nh == 2 ? (e[2] != ed.h0 || e[3] != ed.h1) : (e[2] != (LINK_MANY | ed.h0) || e[3] != nh)) ++bad;
+            ++n_links;
         }
-    }
     uint64_t occupied = 0;
-    for (uint64_t j = 0; j < (uint64_t)kt.l_buckets * 2; ++j) occupied += kt.links[j * LK_WORDS + 4] != 0xFFFFFFFFu;
-    if (occupied != kt.n_keys || n_found < kt.n_keys || n_found > 2 * kt.n_keys) ++bad;   // (every entry answers one or two directed rows)
-    for (uint32_t c = 0; c < g->n_chrom; ++c) {
-        const uint32_t o = g->chrom_off[c], n = g->chrom_off[c + 1] - o;
-        if (n == 0 || n > 24) continue;
-        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-        for (uint32_t b = 0; b < n; ++b) w[b >> 2] |= (uint32_t)(uint8_t)g->chrom_names[o + b] << (8 * (b & 3));
-        uint32_t meta = CT_EMPTY;
-        if (n <= 8) {
-            for (uint32_t j = chrom_short_slot(w[0], w[1], kt.cs_mask, kt.cs_mult), probes = 0;; j = (j + 1) & kt.cs_mask, ++probes) {
-                if (probes && !(kt.cs_mult & 1u)) { ++bad; break; }         // (one probe must decide)
-                const uint32_t *e = &kt.cshort[(size_t)j * 4];
-                if (e[2] == CT_EMPTY) break;
-                if (e[0] == w[0] && e[1] == w[1] && (e[2] >> 24) == n) { meta = e[2]; break; }
-            }
-        } else {
-            for (uint32_t j = chrom_long_slot(w, kt.cl_mask);; j = (j + 1) & kt.cl_mask) {
-                const uint32_t *e = &kt.clong[(size_t)j * 8];
-                if (e[6] == CT_EMPTY) break;
-                bool eq = (e[6] >> 24) == n;
-                for (int q = 0; q < 6; ++q) eq = eq && e[q] == w[q];
-                if (eq) { meta = e[6]; break; }
-            }
-        }
-        if (meta == CT_EMPTY || (meta & 0xFFFFu) != c) ++bad;
-    }
+    for (uint64_t j = 0; j <= kt.link_mask; ++j) occupied += !(kt.links[j * LINK_ENT_WORDS] == 0xFFFFFFFFu && kt.links[j * LINK_ENT_WORDS + 1] == 0xFFFFFFFFu);
+    if (occupied != n_links) ++bad;
     return bad;
 }
 
-// table statistics (harness only): canonical links, links in their second bucket, links left out, buckets, links flagged for the
-// exact path, chromosome names too long for the tables, entries of the two chromosome tables
+// table statistics (harness only): names left out / skipped, links left out, slots, buckets
 extern "C" void hostsim_table_stats(const svjg_graph *g, uint64_t *out) {
     KernelTables kt = build_kernel_tables(*g);
-    out[0] = kt.n_keys; out[1] = kt.n_second; out[2] = kt.links_left_out; out[3] = kt.l_buckets; out[4] = kt.n_exact;
-    out[5] = kt.chroms_skipped; out[6] = kt.cs_mask + 1ull; out[7] = kt.cl_mask + 1ull;
+    out[0] = kt.names_left_out; out[1] = kt.names_skipped; out[2] = kt.links_left_out + (kt.links_unplaced << 32); out[3] = kt.name_slots; out[4] = kt.name_buckets;
+    out[5] = kt.link_mask + 1ull; out[6] = kt.ihits.size();
+    uint64_t mx = 0; for (uint16_t d : kt.disp) if (d > mx) mx = d;
+    out[7] = mx;
 }
 
 // byte classes of n 64-byte spans by bit planes (svjg_planes.h, phase B1 of the main kernel): out = 8 masks of 64 bits per span

@@ -32,10 +32,12 @@ def _lib():
 
 
 def classify(graph, gaf, tables=True, wave=False):
-    """Every line through svjg::slow_line (the exact path the kernels defer to).  (`tables` is kept for callers of the round-2
-    harness: node names are always resolved through the sorted node table now.)"""
+    """Every line through svjg::slow_line (the exact path the kernels defer to).  tables=False: node names are resolved
+    through the sorted node table only (what the device does for names the node-name hash table cannot hold)."""
     lib, capi = _lib()
     cg = capi.cgraph_of(graph)
+    if not tables:
+        cg.flags |= 2
     if wave:
         cg.flags |= 8 if wave == 2 else 4   # every line by 64 cooperating lanes: 2 = the two-phase routine of k_classify_slow_wave, 1 = its fallback for very long paths
     buf = np.frombuffer(gaf, dtype=np.uint8) if not isinstance(gaf, np.ndarray) else gaf
@@ -56,8 +58,7 @@ def check_tables(graph):
 
 
 def table_stats(graph):
-    """(canonical links, links in their second bucket, links left out, buckets, links flagged for the exact path,
-    chromosome names too long for the tables, entries of the short / long chromosome table)"""
+    """(names left out, names skipped, links left out, name slots, name buckets, link slots, inline hit words, max displacement)"""
     lib, capi = _lib()
     cg = capi.cgraph_of(graph)
     out = (ctypes.c_uint64 * 8)()
