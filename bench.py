@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the hot path (classify + all-reduce + genotype) on synthetic GAF, N GPUs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4shard] [--aln N_ALN]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4shard] [--aln N_ALN]     (N > 1: one process, one thread per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...          (one process per GPU)
 
 A step = one pass of the path over one batch: zero the count vector, classify every alignment of this rank's
-GAF shard (text already resident in HBM), all-reduce the per-SV counts (N > 1), genotype every VCF row.
+GAF shard (text already resident in HBM), all-reduce the per-SV counts (N > 1), genotype every VCF row — one library call
+(svjg_run_resident) with one host wait per pass.
 value = alignments classified per second over all ranks.  One JSON line on rank 0.
 
 Workload at N = 1: BASELINE.json configs[2] (10 M alignments x 100 k mixed SVs, the largest single-GPU
@@ -37,6 +38,69 @@ WORKLOADS = {
 }
 
 
+def timed_steps(ctxs, steps, warmup, min_support=3, err=0.00005, outer_barrier=None):
+    """`warmup` untimed and `steps` timed passes on every context of this process — one thread per context when there are
+    several: their all-reduce keeps them in step — between two barriers.  A pass = Context.run_resident(): zero counts, classify
+    the resident shard, all-reduce (if the context has a communicator), genotype the resident rows; one host wait per pass.
+    -> (seconds for the timed passes, per context [(main, exact, genotype) kernel ms per pass], the last pass's outputs of context 0)"""
+    import threading
+    n = len(ctxs)
+    ms = [[] for _ in range(n)]
+    outs = [None] * n
+    if n == 1:
+        c = ctxs[0]
+        for _ in range(warmup):
+            c.run_resident(min_support, err)
+        c.sync()
+        if outer_barrier:
+            outer_barrier()
+        t = time.perf_counter()
+        for _ in range(steps):
+            outs[0] = c.run_resident(min_support, err)
+            ms[0].append(c.kernel_ms())
+        c.sync()
+        if outer_barrier:
+            outer_barrier()
+        return time.perf_counter() - t, ms, outs[0]
+    bar = threading.Barrier(n + 1)
+    errors = []
+
+    def worker(i):
+        try:
+            c = ctxs[i]
+            for _ in range(warmup):
+                c.run_resident(min_support, err)
+            c.sync()
+            bar.wait()                                           # start line
+            for _ in range(steps):
+                outs[i] = c.run_resident(min_support, err)
+                ms[i].append(c.kernel_ms())
+            c.sync()
+            bar.wait()                                           # finish line
+        except BaseException as e:                               # noqa: BLE001 (reported by the caller)
+            errors.append(e)
+            bar.abort()
+    th = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(n)]
+    for x in th:
+        x.start()
+    try:
+        bar.wait()
+        if outer_barrier:
+            outer_barrier()
+        t = time.perf_counter()
+        bar.wait()
+        if outer_barrier:
+            outer_barrier()
+        dt = time.perf_counter() - t
+    except threading.BrokenBarrierError:
+        dt = None
+    for x in th:
+        x.join()
+    if errors:
+        raise errors[0]
+    return dt, ms, outs[0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,13 +113,17 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed end-to-end block (files -> JSON -> VCF through the drop-in scripts)")
     args = ap.parse_args()
 
+    # Two ways to N GPUs: under a launcher (torch.distributed.run: WORLD_SIZE ranks, one GPU each, RCCL communicator from a
+    # unique id that travels over the launcher's process group), or — no launcher — this one process with one context and one
+    # thread per GPU (ncclCommInitAll), which is also what the drop-in filter-alignments.py does with the GPUs it sees.
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    n_local = 1
+    if world > 1:
         args.gpus = world
+    elif args.gpus > 1:
+        n_local = args.gpus
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -66,92 +134,94 @@ def main():
     from svjg import capi, genotype, shard
     from svjg.graph import Graph
 
+    if n_local > 1:
+        have = capi.device_count()
+        if have < n_local:
+            sys.exit(f"bench.py --gpus {n_local}: needs {n_local} devices, found {have}")
+
     n_aln, n_sv, n_chrom, mix, seed, desc = WORKLOADS[args.workload]
     if args.aln:
         n_aln = args.aln
     if args.svs:
         n_sv = args.svs
         desc += f" [--svs {n_sv}]"
+    n_total_ranks = world * n_local
 
     # ---- inputs (untimed) --------------------------------------------------------------------------
     t0 = time.time()
     tmp = tempfile.mkdtemp(prefix="svjg_bench_")
     pre = os.path.join(tmp, "w")
     inf = synth.generate(pre, 0, n_sv, n_chrom, mix, seed, write_gaf=False)
-    gaf = synth.gaf_bytes(inf["tables"], seed, rank * n_aln, n_aln, threads=min(16, os.cpu_count() or 8))
+    gaf = synth.gaf_bytes(inf["tables"], seed, rank * n_local * n_aln, n_aln, threads=min(16, os.cpu_count() or 8))   # this process's first shard
     graph = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
     rows = genotype.VcfRows(pre + ".vcf", graph.slot_of)
     t_setup = time.time() - t0
-    cpu = cpu_rates(pre, gaf) if (not args.no_cpu_baseline and world == 1) else None   # (forks workers: before the GPU is touched)
+    cpu = cpu_rates(pre, gaf) if (not args.no_cpu_baseline and n_total_ranks == 1) else None   # (forks workers: before the GPU is touched)
 
-    ctx = capi.Context(local_rank)
-    ctx.load_graph(graph)
-    t1 = time.time()
-    ctx.upload(gaf)
-    t_h2d = time.time() - t1
+    ctxs = [capi.Context(local_rank + i) for i in range(n_local)]
+    t_h2d = 0.0
+    gaf_bytes_0 = int(gaf.size)
+    for i, ctx in enumerate(ctxs):
+        ctx.load_graph(graph)
+        ctx.set_rows(rows.sv_type, rows.slot, rows.ok)
+        text = gaf if i == 0 else synth.gaf_bytes(inf["tables"], seed, (rank * n_local + i) * n_aln, n_aln, threads=min(16, os.cpu_count() or 8))
+        t1 = time.time()
+        ctx.upload(text)
+        t_h2d = max(t_h2d, time.time() - t1)
+        del text
+    rccl = None
     if world > 1:
         import dist_boot
-    group = shard.RcclGroup(ctx, world, rank, dist_boot.torch_exchange) if world > 1 else None
+        shard.RcclGroup(ctxs[0], world, rank, dist_boot.torch_exchange)
+        rccl = {"ranks": world, "init": "ncclCommInitRank, one process per GPU"}
+    elif n_local > 1:
+        capi.comm_init_all(ctxs)
+        rccl = {"ranks": n_local, "init": "ncclCommInitAll, one process, one thread per GPU"}
 
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-
-    def step():
-        ctx.reset_counts()
-        ctx.classify_resident(base_offset=0, want_hits=False)
-        if group is not None:
-            group.allreduce_counts()
-        return ctx.genotype(rows.sv_type, rows.slot, rows.ok, 3, 0.00005, reuse_outputs=True)
-
-    for _ in range(args.warmup):
-        step()
-    main_ms, slow_ms, geno_ms = [], [], []
-    barrier()
-    t = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        a, b, c = ctx.kernel_ms()
-        main_ms.append(a); slow_ms.append(b); geno_ms.append(c)
-    barrier()
-    dt = time.perf_counter() - t
+    dt, kms, out = timed_steps(ctxs, args.steps, args.warmup, outer_barrier=(dist.barrier if dist is not None else None))
     if dist is not None:
         import torch
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
+    main_ms = [m[0] for per in kms for m in per]
+    slow_ms = [m[1] for per in kms for m in per]
+    geno_ms = [m[2] for per in kms for m in per]
 
+    ctx = ctxs[0]
     st = ctx.stats()
     counts = ctx.counts()
     gt, pl, raw, done = (np.array(x) for x in out)            # (views of the library's pinned result block: copied before anything else runs)
 
     if rank == 0:
-        total_aln = n_aln * world
+        total_aln = n_aln * n_total_ranks
         ms_per_step = dt / args.steps * 1e3
         k_main = float(np.mean(main_ms))
-        achieved = gaf.size / (k_main * 1e-3) / 1e9
+        achieved = gaf_bytes_0 / (k_main * 1e-3) / 1e9
         res = {
             "metric": "GAF alignments classified/sec (classify + count all-reduce + genotype, text resident in HBM)",
             "value": total_aln * args.steps / dt,
             "unit": "alignments/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_total_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int64 (classify), f64 (likelihood)", "data": "synthetic",
-            "config": {"workload": desc, "alignments_per_gpu": n_aln, "svs": n_sv, "gaf_bytes_per_gpu": int(gaf.size),
-                       "bytes_per_alignment": round(gaf.size / n_aln, 1), "count_slots": graph.n_slots,
+            "config": {"workload": desc, "alignments_per_gpu": n_aln, "svs": n_sv, "gaf_bytes_per_gpu": gaf_bytes_0,
+                       "bytes_per_alignment": round(gaf_bytes_0 / n_aln, 1), "count_slots": graph.n_slots,
                        "graph_nodes": graph.n_nodes, "vcf_rows": int(len(rows.sv_type))},
-            "svs_genotyped_per_s": float(len(rows.sv_type) * world / (np.mean(geno_ms) * 1e-3)) if np.mean(geno_ms) > 0 else None,
-            "genotyped_rows": int(done.sum()),
+            "svs_genotyped_per_s": float(len(rows.sv_type) * n_total_ranks / (np.mean(geno_ms) * 1e-3)) if np.mean(geno_ms) > 0 else None,
+            "genotyped_rows": int((done & 1).sum()),
             "kernel_ms": {"classify_main": k_main, "classify_exact_path": float(np.mean(slow_ms)), "genotype": float(np.mean(geno_ms))},
-            "deferred_lines_per_step": st["n_deferred"] // max(1, args.steps + args.warmup),
+            "step_overhead_ms": ms_per_step - (k_main + float(np.mean(slow_ms)) + float(np.mean(geno_ms))),
+            "deferred_lines_per_step": st["n_deferred"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_classify_main", "algorithmic_bytes_per_launch": int(gaf.size)},
+                         "kernel": "k_classify_main", "algorithmic_bytes_per_launch": gaf_bytes_0},
             "setup_s": {"generate_and_tables": round(t_setup, 1), "h2d_upload": round(t_h2d, 3),
                         "pcie_inclusive_alignments_per_s": n_aln / (t_h2d + ms_per_step * 1e-3)},
         }
+        if rccl:
+            res["rccl"] = rccl
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (profiles/<round>/traffic.json,
         # the newest round that has one)
         try:
@@ -159,7 +229,7 @@ def main():
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "traffic.json")))
             tr_path = cands[-1]
             tr = json.load(open(tr_path)).get(args.workload)
-            if tr and tr["text_bytes"] == int(gaf.size) and world == 1:
+            if tr and tr["text_bytes"] == gaf_bytes_0 and n_total_ranks == 1:
                 rel = os.path.relpath(tr_path, ROOT)
                 res["roofline"]["traffic"] = tr["traffic_bytes"]
                 res["roofline"]["traffic_source"] = f"{rel} (rocprofv3 FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
@@ -172,15 +242,16 @@ def main():
                                                      "issue_ms": round(issue_ms, 3), "frac_of_launch": round(issue_ms / k_main, 3)}
         except (OSError, ValueError, KeyError, IndexError):
             pass
-        if not args.no_cpu_baseline and world == 1:            # reported on rank 0 at N = 1 only
+        if not args.no_cpu_baseline and n_total_ranks == 1:    # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pre, graph, counts, cpu)
-        if not args.no_e2e and world == 1 and args.workload in ("c2", "c3") and not args.aln and not args.svs:
-            ctx.close()                                          # (the scripts open the GPU themselves)
-            ctx = None
+        if not args.no_e2e and n_total_ranks == 1 and args.workload in ("c2", "c3") and not args.aln and not args.svs:
+            for c in ctxs:
+                c.close()                                        # (the scripts open the GPU themselves)
+            ctxs = []
             res["e2e"] = end_to_end(args.workload, pre, gaf)
         print(json.dumps(res))
-    if ctx is not None:
-        ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -173,6 +173,19 @@ int svjg_genotype_view(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *sl
                        uint64_t n_rows, uint32_t min_support, double err,
                        const uint8_t **gt, const int64_t **pl, const uint32_t **raw, const uint8_t **genotyped);
 
+/* ---- the whole pass in one call (what a fused svjedi-graph run and bench.py do per batch) -----------------------------------
+ * svjg_set_rows copies the three per-row input arrays of svjg_genotype to the device once (they stay until the next
+ * svjg_set_rows / svjg_destroy).  svjg_run_resident then does, for the resident text of svjg_gaf_upload and those rows:
+ * svjg_reset_counts, svjg_classify_resident(base_offset, no hit records), svjg_allreduce_counts if the context has a
+ * communicator, svjg_genotype — enqueued back to back with ONE host wait at the end (filter-alignments.py:123-166 and
+ * predict-genotype.py:216-227, :281-325 with the counts handed over in HBM instead of through the JSON file).
+ * Results land in the context's pinned host block, valid until the next svjg_run_resident / svjg_set_rows / svjg_destroy:
+ * gt[r], raw[r*2..] as svjg_genotype; pl[r*3..] = the PLs as 32-bit integers; flags[r] bit 0 = genotyped, bit 1 = a PL of the
+ * row does not fit 32 bits (ask svjg_genotype for the 64-bit values: it needs > 4e7 informative alignments for one SV). */
+int svjg_set_rows(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows);
+int svjg_run_resident(svjg_ctx *ctx, uint64_t base_offset, uint32_t min_support, double err,
+                      const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags);
+
 /* ---- host-side writer of <prefix>_informative_aln.json (libsvjg_host.so, no GPU involved) -----------------
  * Byte-identical to json.dumps(dict_of_informative_aln, sort_keys=True, indent=4) (filter-alignments.py:174-175)
  * from the hit records: sv_ids[slot] is the key of each count slot, `gaf` the same bytes that were classified. */

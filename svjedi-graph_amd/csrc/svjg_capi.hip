@@ -57,6 +57,8 @@ struct svjg_ctx {
     unsigned int *d_maxn = nullptr;
     void *d_rows = nullptr;  uint64_t rows_cap = 0;
     void *h_rows = nullptr;  uint64_t h_rows_cap = 0;   // pinned twin of d_rows
+    // resident VCF rows of svjg_set_rows / svjg_run_resident: device block (results, row inputs) and the pinned host block the results land in
+    void *d_run = nullptr;  uint64_t d_run_cap = 0;  void *h_run = nullptr;  uint64_t h_run_cap = 0;  uint64_t run_rows = 0;
     // timing of the last calls
     float ms_main = 0, ms_slow = 0, ms_geno = 0;
     // rccl
@@ -131,8 +133,9 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     if (c->comm) ncclCommDestroy(c->comm);
     free_graph(c);
     hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
-    hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows);
+    hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows); hipFree(c->d_run);
     if (c->h_rows) hipHostFree(c->h_rows);
+    if (c->h_run) hipHostFree(c->h_run);
     if (c->h_stp) hipHostFree(c->h_stp);
     for (auto &b : c->h_stage) if (b) hipHostFree(b);
     for (auto &ev : c->stage_ev) if (ev) hipEventDestroy(ev);
@@ -328,13 +331,53 @@ static int ensure(svjg_ctx *c, void **p, uint64_t *cap, uint64_t want, size_t el
     return 0;
 }
 
+// arguments and geometry of one k_classify_main launch over the lines of the resident text that lie in [begin, end)
+static uint64_t deferred_want(const svjg_ctx *c, uint64_t n) { return (c->gflags & SVJG_GRAPH_ALL_SLOW) ? n / 24 + 64 : (n / 4096 + 65536); }
+
+static void main_launch_setup(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t base_offset, int want_hits, ClassifyArgs &a, uint32_t &grid, size_t &lds) {
+    const uint64_t n = end - begin;
+    const bool all_slow = (c->gflags & SVJG_GRAPH_ALL_SLOW) != 0;
+    a.gaf = c->d_gaf; a.begin = begin; a.n_bytes = end; a.base_offset = base_offset; a.g = c->gv;
+    a.all_slow = all_slow; a.want_hits = want_hits != 0;
+#ifdef SVJG_ABLATE
+    { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob (measurement builds only)
+#endif
+    a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
+    a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
+    lds = LDS_MAIN;
+    if (c->occ_main < 1) {                                // persistent grid: every CU filled to what LDS / registers admit (asked once)
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_classify_main, (int)WG, lds) != hipSuccess || occ < 1) occ = 1;
+        // LDS is handed out in units of LDS_GRANULE bytes (measured: a 15 568-byte workgroup is admitted 9 times per CU where the
+        // API says 10); a worker too many would run in a second round behind the others
+        const int by_lds = (int)((160u * 1024u) / ((lds + LDS_GRANULE - 1) / LDS_GRANULE * LDS_GRANULE));
+        if (by_lds >= 1 && occ > by_lds) occ = by_lds;
+        c->occ_main = occ;
+#ifdef SVJG_ABLATE
+        { const char *oc = getenv("SVJG_OCC"); fprintf(stderr, "[svjg diag] occupancy API: %d workgroups of %u threads per CU (LDS %zu)\n", occ, WG, lds); if (oc && atoi(oc) > 0) c->occ_main = atoi(oc); }
+#endif
+    }
+    // one worker (wave) per resident slot; every worker owns the lines starting in its region of the text.  Small inputs:
+    // regions of at least one stripe, fewer workers.
+    // A worker's first chunk is most of an even share, fixed; what is left goes in small chunks to whoever is free next
+    // (svjg_kernels.h: the workers of a CU do not run equally fast).  Inputs too small for that: even shares of at least a stripe.
+    const uint64_t full = (uint64_t)c->n_cu * (uint64_t)c->occ_main;
+    const uint64_t share = (n + full - 1) / full;
+    uint64_t region = (share + 15) & ~15ull;
+    a.small = 0;
+    if (share >= 8 * SMALL_CHUNK) { region = ((uint64_t)(share * FIRST_CHUNK_SHARE) + 15) & ~15ull; a.small = SMALL_CHUNK; }
+    if (region < TEXT) region = TEXT;
+    a.region = region;
+    const uint64_t want_grid = (n + region - 1) / region;
+    grid = (uint32_t)(want_grid < full ? want_grid : full);
+}
+
 // the lines of the resident text that lie in [begin, end): begin is a line start, end the byte behind a terminator (or the text's end)
 static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t base_offset, int want_hits) {
     HIPCHK(c, hipSetDevice(c->device));
     if (end <= begin) return 0;
     const uint64_t n = end - begin;
-    const bool all_slow = (c->gflags & SVJG_GRAPH_ALL_SLOW) != 0;
-    uint64_t def_want = all_slow ? n / 24 + 64 : (n / 4096 + 65536);
+    uint64_t def_want = deferred_want(c, n);
     uint64_t rec_want = want_hits ? c->hs().n_recs + n / 64 + 65536 : 0;
     int rc;
     for (int attempt = 0; attempt < 3; ++attempt) {
@@ -345,39 +388,9 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         DevStatus before = c->hs();
         if ((rc = reset_status(c, false))) return rc;
         ClassifyArgs a{};
-        a.gaf = c->d_gaf; a.begin = begin; a.n_bytes = end; a.base_offset = base_offset; a.g = c->gv;
-        a.all_slow = all_slow; a.want_hits = want_hits != 0;
-#ifdef SVJG_ABLATE
-        { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob (measurement builds only)
-#endif
-        a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
-        a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
-        size_t lds = LDS_MAIN;
-        if (c->occ_main < 1) {                                // persistent grid: every CU filled to what LDS / registers admit (asked once)
-            int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_classify_main, (int)WG, lds) != hipSuccess || occ < 1) occ = 1;
-            // LDS is handed out in units of LDS_GRANULE bytes (measured: a 15 568-byte workgroup is admitted 9 times per CU where the
-            // API says 10); a worker too many would run in a second round behind the others
-            const int by_lds = (int)((160u * 1024u) / ((lds + LDS_GRANULE - 1) / LDS_GRANULE * LDS_GRANULE));
-            if (by_lds >= 1 && occ > by_lds) occ = by_lds;
-            c->occ_main = occ;
-#ifdef SVJG_ABLATE
-            { const char *oc = getenv("SVJG_OCC"); fprintf(stderr, "[svjg diag] occupancy API: %d workgroups of %u threads per CU (LDS %zu)\n", occ, WG, lds); if (oc && atoi(oc) > 0) c->occ_main = atoi(oc); }
-#endif
-        }
-        // one worker (wave) per resident slot; every worker owns the lines starting in its region of the text.  Small inputs:
-        // regions of at least one stripe, fewer workers.
-        // A worker's first chunk is most of an even share, fixed; what is left goes in small chunks to whoever is free next
-        // (svjg_kernels.h: the workers of a CU do not run equally fast).  Inputs too small for that: even shares of at least a stripe.
-        const uint64_t full = (uint64_t)c->n_cu * (uint64_t)c->occ_main;
-        const uint64_t share = (n + full - 1) / full;
-        uint64_t region = (share + 15) & ~15ull;
-        a.small = 0;
-        if (share >= 8 * SMALL_CHUNK) { region = ((uint64_t)(share * FIRST_CHUNK_SHARE) + 15) & ~15ull; a.small = SMALL_CHUNK; }
-        if (region < TEXT) region = TEXT;
-        a.region = region;
-        const uint64_t want_grid = (n + region - 1) / region;
-        const uint32_t grid = (uint32_t)(want_grid < full ? want_grid : full);
+        uint32_t grid = 0;
+        size_t lds = 0;
+        main_launch_setup(c, begin, end, base_offset, want_hits, a, grid, lds);
 #ifdef SVJG_TIMING
         if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
 #endif
@@ -402,10 +415,10 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
             const uint64_t max_blocks = (uint64_t)c->n_cu * 4;              // 32 KB of LDS each: four per CU
             if (n_def <= 16 * max_blocks) {
                 // few lines: one wave per line (latency of a line O(k) instead of O(k^2) name resolutions)
-                hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)(n_def < max_blocks ? n_def : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def);
+                hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)(n_def < max_blocks ? n_def : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def, 0ull, 0ull);
             } else {
                 const uint64_t want_blocks = (n_def + SLOW_TPB - 1) / SLOW_TPB;
-                hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)(want_blocks < max_blocks ? want_blocks : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def);
+                hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)(want_blocks < max_blocks ? want_blocks : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def, 0ull, 0ull);
             }
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
@@ -684,6 +697,20 @@ extern "C" int svjg_allreduce_counts_all(svjg_ctx *const *ctxs, int n) {
 
 // ---- genotypes -----------------------------------------------------------------------------------------
 
+// table of log10(i!) in double-double for the binomial term, at least `upto` entries (kernels on the context's stream; no host wait)
+static int build_logfact(svjg_ctx *c, uint32_t upto) {
+    const uint32_t want = (upto + LF_BLOCK - 1) / LF_BLOCK * LF_BLOCK;
+    hipFree(c->d_logfact); hipFree(c->d_bsum); c->d_logfact = nullptr; c->d_bsum = nullptr; c->logfact_n = 0;
+    HIPCHK(c, hipMalloc((void **)&c->d_logfact, (uint64_t)want * sizeof(dd)));
+    HIPCHK(c, hipMalloc((void **)&c->d_bsum, (uint64_t)(want / LF_BLOCK) * sizeof(dd)));
+    hipLaunchKernelGGL(k_logfact_local, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
+    hipLaunchKernelGGL(k_logfact_bsum, dim3(1), dim3(64), 0, c->stream, c->d_bsum, want / LF_BLOCK);
+    hipLaunchKernelGGL(k_logfact_add, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
+    HIPCHK(c, hipGetLastError());
+    c->logfact_n = want;
+    return 0;
+}
+
 // results of all rows -> the pinned host block of the context: [ pl 24 | raw 8 | gt 1 | done 1 ] x n_rows
 static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
                          uint32_t min_support, double err) {
@@ -719,17 +746,7 @@ static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *sl
     // only then (first call, or a deeper sample than ever before) the table is rebuilt and the pass repeated.
     uint32_t grow_to = 65536;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (c->logfact_n == 0) {
-            uint32_t want = (grow_to + LF_BLOCK - 1) / LF_BLOCK * LF_BLOCK;
-            hipFree(c->d_logfact); hipFree(c->d_bsum); c->d_logfact = nullptr; c->d_bsum = nullptr;
-            HIPCHK(c, hipMalloc((void **)&c->d_logfact, (uint64_t)want * sizeof(dd)));
-            HIPCHK(c, hipMalloc((void **)&c->d_bsum, (uint64_t)(want / LF_BLOCK) * sizeof(dd)));
-            hipLaunchKernelGGL(k_logfact_local, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
-            hipLaunchKernelGGL(k_logfact_bsum, dim3(1), dim3(64), 0, c->stream, c->d_bsum, want / LF_BLOCK);
-            hipLaunchKernelGGL(k_logfact_add, dim3(want / LF_BLOCK), dim3(LF_BLOCK), 0, c->stream, c->d_logfact, c->d_bsum, want);
-            HIPCHK(c, hipGetLastError());
-            c->logfact_n = want;
-        }
+        if (c->logfact_n == 0 && (rc = build_logfact(c, grow_to))) return rc;
         a.logfact = c->d_logfact; a.logfact_n = c->logfact_n;
         HIPCHK(c, hipMemsetAsync(d_maxn, 0, 8, c->stream));
         hipLaunchKernelGGL(k_genotype, dim3(grid), dim3(TPB), 0, c->stream, a);
@@ -775,6 +792,155 @@ extern "C" int svjg_genotype_view(svjg_ctx *c, const uint8_t *sv_type, const uin
     const uint8_t *hb = (const uint8_t *)c->h_rows;
     *pl = (const int64_t *)hb; *raw = (const uint32_t *)(hb + n_rows * 24);
     *gt = hb + n_rows * 32; *genotyped = hb + n_rows * 33;
+    return 0;
+}
+
+// ---- the whole pass in one call, one host wait ---------------------------------------------------------------------
+// svjg_set_rows leaves the VCF rows' three input arrays on the device; svjg_run_resident then enqueues — back to back on the
+// context's stream, no host round trip in between — zero counts, classify the resident text (the exact-path kernels take the
+// number of deferred lines from the device), the count all-reduce when the context has a communicator, genotype every row, and
+// copies the results (PLs as 32-bit integers) into the context's pinned block; then it waits ONCE.  What the host used to decide
+// between the kernels it checks afterwards, and repeats the pass the slow way if a buffer overflowed or the log10(i!) table was
+// too short (first call after a deeper sample than ever before).
+struct RunLayout { uint64_t pl32, raw, gt, flags, maxn, status, out_bytes, pl64, slot, type, ok, total; };
+static RunLayout run_layout(uint64_t n) {
+    RunLayout L; uint64_t o = 0;
+    L.pl32 = o; o += n * 12; L.raw = o; o += n * 8; L.gt = o; o += n; L.flags = o; o += n; o = (o + 7) & ~7ull; L.maxn = o; o += 8; L.status = o; o += (sizeof(DevStatus) + 7) & ~7ull; L.out_bytes = o;
+    L.pl64 = o; o += n * 24; L.slot = o; o += n * 4; L.type = o; o += n; L.ok = o; o += n; L.total = o + 64;
+    return L;
+}
+
+extern "C" int svjg_set_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows) {
+    if (!c || (n_rows && (!sv_type || !slot || !ok))) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const RunLayout L = run_layout(n_rows);
+    int rc = ensure(c, &c->d_run, &c->d_run_cap, L.total, 1, false);
+    if (rc) return rc;
+    if (L.out_bytes + 16 > c->h_run_cap) {
+        if (c->h_run) hipHostFree(c->h_run);
+        c->h_run = nullptr; c->h_run_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_run, L.out_bytes + 16, hipHostMallocDefault));
+        c->h_run_cap = L.out_bytes + 16;
+    }
+    uint8_t *base = (uint8_t *)c->d_run;
+    if (n_rows) {
+        HIPCHK(c, hipMemcpyAsync(base + L.slot, slot, n_rows * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(base + L.type, sv_type, n_rows, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(base + L.ok, ok, n_rows, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));               // (the caller's arrays may go away)
+    c->run_rows = n_rows;
+    return 0;
+}
+
+static GenoArgs run_geno_args(svjg_ctx *c, const RunLayout &L, uint32_t min_support, double err) {
+    uint8_t *base = (uint8_t *)c->d_run;
+    GenoArgs a{};
+    a.counts = c->d_counts; a.sv_type = base + L.type; a.slot = (const uint32_t *)(base + L.slot); a.ok = base + L.ok; a.n_rows = c->run_rows;
+    a.min_support = min_support;
+    a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
+    a.gt = base + L.gt; a.pl = (int64_t *)(base + L.pl64); a.raw = (uint32_t *)(base + L.raw); a.genotyped = base + L.flags;
+    a.pl32 = (int32_t *)(base + L.pl32); a.max_n = (unsigned int *)(base + L.maxn); a.n_slots = c->n_slots;
+    a.logfact = c->d_logfact; a.logfact_n = c->logfact_n;
+    return a;
+}
+
+extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min_support, double err,
+                                 const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags) {
+    if (!c || !gt || !pl || !raw || !flags) return SVJG_E_ARG;
+    *gt = nullptr; *pl = nullptr; *raw = nullptr; *flags = nullptr;
+    if (!c->have_graph || !c->have_gaf) { c->err = "svjg_run_resident needs a graph and an uploaded GAF"; return SVJG_E_ARG; }
+    if (!c->d_run) { c->err = "svjg_set_rows has not been called"; return SVJG_E_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = c->gaf_bytes, n_rows = c->run_rows;
+    const RunLayout L = run_layout(n_rows);
+    uint8_t *hb = (uint8_t *)c->h_run;
+    int rc;
+    if ((rc = ensure(c, (void **)&c->d_deferred, &c->deferred_cap, deferred_want(c, n), sizeof(uint64_t), false))) return rc;
+    if (c->logfact_n == 0 && (rc = build_logfact(c, 65536))) return rc;
+    // ---- everything enqueued ----
+    uint8_t *base = (uint8_t *)c->d_run;
+    DevStatus *d_st = (DevStatus *)(base + L.status);             // (the pass's status block sits behind the results: one copy brings both)
+    GenoArgs ga = run_geno_args(c, L, min_support, err);
+    {
+        const uint64_t words = (uint64_t)c->n_slots + 2;
+        uint32_t rg = (uint32_t)((words + TPB - 1) / TPB);
+        if (rg > 1024) rg = 1024;
+        hipLaunchKernelGGL(k_step_reset, dim3(rg), dim3(TPB), 0, c->stream, c->d_counts, words, d_st, ga.max_n);
+    }
+    c->ms_slow = 0;
+    const uint64_t max_blocks = (uint64_t)c->n_cu * 4, wave_limit = 16 * max_blocks;
+    if (n) {
+        ClassifyArgs a{};
+        uint32_t grid = 0;
+        size_t lds = 0;
+        main_launch_setup(c, 0, n, base_offset, 0, a, grid, lds);
+        a.st = d_st;
+        HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        // the exact path for up to wave_limit lines, their number read on the device (more: the pass is repeated step by step)
+        hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)c->n_cu), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, 0ull, wave_limit);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    }
+    if (c->comm) {
+        if ((rc = launch_guard(c))) return rc;
+        ncclResult_t r = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
+        if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return SVJG_E_RCCL; }
+        HIPCHK(c, hipMemcpyAsync(hb + L.out_bytes, c->d_counts + c->n_slots, 16, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (n_rows) {
+        HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+        hipLaunchKernelGGL(k_genotype, dim3((uint32_t)((n_rows + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, ga);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(hb, c->d_run, L.out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                           // the pass's one host wait
+    c->hs() = *(const DevStatus *)(hb + L.status);
+    // ---- what the host would have decided in between ----
+    if (n) {
+        HIPCHK(c, hipEventElapsedTime(&c->ms_main, c->ev[0], c->ev[1]));
+        if (c->hs().n_deferred) HIPCHK(c, hipEventElapsedTime(&c->ms_slow, c->ev[1], c->ev[3]));
+    }
+    bool again = false;
+    if (c->hs().overflow || c->hs().n_deferred > wave_limit) {
+        // the list of deferred lines was too short, or holds more lines than one wave per line is good for: the pass again, step by
+        // step (classify_range sizes the list, picks the exact-path kernel and retries)
+        if ((rc = svjg_reset_counts(c))) return rc;
+        rc = classify_range(c, 0, n, base_offset, 0);
+        if (rc) return rc;
+        if (c->comm && (rc = svjg_allreduce_counts(c))) return rc;
+        again = true;
+    } else {
+        c->total_deferred = c->hs().n_deferred;
+        if (c->hs().err != ~0ull) return SVJG_E_INPUT;
+        if (c->comm) {
+            const unsigned long long *gd = (const unsigned long long *)(hb + L.out_bytes);
+            if (gd[0] >= (1ull << 32) || gd[1] >= (1ull << 32)) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
+        }
+    }
+    if (n_rows) {
+        for (int attempt = 0;; ++attempt) {
+            if (!again) {
+                if (*(const unsigned int *)(hb + L.maxn + 4)) { c->err = "slot out of range"; return SVJG_E_ARG; }
+                const unsigned int max_n = *(const unsigned int *)(hb + L.maxn);
+                if (max_n == 0) break;                           // every row found its binomial term
+                if (attempt == 2) { c->err = "log10(i!) table could not be sized"; return SVJG_E_HIP; }
+                if ((rc = build_logfact(c, max_n + 1 + 1024))) return rc;
+            }
+            again = false;
+            ga = run_geno_args(c, L, min_support, err);
+            HIPCHK(c, hipMemsetAsync(ga.max_n, 0, 8, c->stream));
+            hipLaunchKernelGGL(k_genotype, dim3((uint32_t)((n_rows + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, ga);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(hb, c->d_run, L.out_bytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        HIPCHK(c, hipEventElapsedTime(&c->ms_geno, c->ev[4], c->ev[5]));
+    }
+    *pl = (const int32_t *)(hb + L.pl32); *raw = (const uint32_t *)(hb + L.raw); *gt = hb + L.gt; *flags = hb + L.flags;
     return 0;
 }
 

@@ -863,6 +863,17 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
 #endif
 }
 
+// svjg_run_resident: the three things a pass starts from — zero counts (and guard words), a fresh status block, "no row lacked its
+// binomial term" — in one launch instead of two memsets and a copy
+__global__ __launch_bounds__(TPB) void k_step_reset(unsigned long long *counts, uint64_t n_words, DevStatus *st, unsigned int *max_n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * TPB) counts[i] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        DevStatus z{}; z.err = ~0ull;
+        *st = z;
+        max_n[0] = 0u; max_n[1] = 0u;
+    }
+}
+
 struct SlowEmit {
     const ClassifyArgs *a;
     uint64_t line_start;
@@ -883,7 +894,19 @@ struct SlowEmit {
 // copies the line, 16 bytes per step) and the string logic then pays LDS latency per byte, not HBM latency.  A line
 // that does not fit (longer than SLOW_MAXLINE, or the 64 lines together exceed the buffer) is read in place.
 constexpr uint32_t SLOW_TPB = 64, SLOW_LDS = 32 * 1024, SLOW_MAXLINE = 16 * 1024;
-__global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint64_t n_def) {
+// n_def = SLOW_ASK_DEVICE: the launch was enqueued right behind the main kernel without a host round trip (svjg_run_resident); the
+// number of deferred lines is what the main kernel left in the status block, and the kernel works only if it lies in (lo, hi]
+// (two launches share the range: one wave per line up to a limit, one lane per line beyond it).  A list that overflowed is not
+// touched: the host sees the flag and repeats the pass with a larger one.
+constexpr uint64_t SLOW_ASK_DEVICE = ~0ull;
+__device__ inline uint64_t slow_n_def(const ClassifyArgs &a, uint64_t n_def, uint64_t lo, uint64_t hi) {
+    if (n_def != SLOW_ASK_DEVICE) return n_def;
+    if (a.st->overflow & 1u) return 0;
+    const uint64_t n = a.st->n_deferred;
+    return (n > lo && n <= hi) ? n : 0;
+}
+__global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint64_t n_def_arg, uint64_t lo, uint64_t hi) {
+    const uint64_t n_def = slow_n_def(a, n_def_arg, lo, hi);
     __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
     const uint32_t lane = threadIdx.x;
     for (uint64_t b0 = (uint64_t)blockIdx.x * SLOW_TPB; b0 < n_def; b0 += (uint64_t)gridDim.x * SLOW_TPB) {
@@ -930,7 +953,8 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
 // resolutions per lane where one lane per line needs O(k^2).  An error is the one the reference would meet first
 // (smallest position in its sequence of steps).
 constexpr uint32_t SLOW_NODES = 1024;                                  // path nodes the per-node scratch of one line holds
-__global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a, uint64_t n_def) {
+__global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a, uint64_t n_def_arg, uint64_t lo, uint64_t hi) {
+    const uint64_t n_def = slow_n_def(a, n_def_arg, lo, hi);
     __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
     __shared__ int64_t n_len[SLOW_NODES];
     __shared__ uint32_t n_id[SLOW_NODES];
@@ -1064,6 +1088,7 @@ struct GenoArgs {
     double l_ok, l_err, l_half;        // log10(1-e), log10(e), log10(1/2) computed by the host libm like CPython does
     const dd *logfact; uint32_t logfact_n;
     uint8_t *gt; int64_t *pl; uint32_t *raw; uint8_t *genotyped;
+    int32_t *pl32;                     // svjg_run_resident: the three PLs as 32-bit integers (nullptr: not wanted); a row whose PLs do not fit sets bit 1 of genotyped[]
     unsigned int *max_n;               // [0] largest n = ref + alt beyond the log10(i!) table, [1] set if a row names a slot >= n_slots
     uint32_t n_slots;
 };
@@ -1115,7 +1140,7 @@ __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
     bool go = geno_gate(a, r, ref, alt);
     a.raw[r * 2] = go ? ref : 0; a.raw[r * 2 + 1] = go ? alt : 0;
     a.genotyped[r] = go;
-    if (!go) { a.gt[r] = 3; a.pl[r * 3] = a.pl[r * 3 + 1] = a.pl[r * 3 + 2] = 0; return; }
+    if (!go) { a.gt[r] = 3; a.pl[r * 3] = a.pl[r * 3 + 1] = a.pl[r * 3 + 2] = 0; if (a.pl32) a.pl32[r * 3] = a.pl32[r * 3 + 1] = a.pl32[r * 3 + 2] = 0; return; }
     double c1, c2; uint32_t r1, r2;
     geno_counts(a.sv_type[r], ref, alt, c1, c2, r1, r2);
     // products in double, sums exact (the reference adds Decimal images of the doubles, :295-297)
@@ -1133,13 +1158,17 @@ __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
     else atomicMax(a.max_n, n);                          // the log10(i!) table is too short: the host grows it and runs the pass again
     comb = dd{comb.hi, 0.0};                             // the reference rounds log10(comb) to a double first (:313)
     dd ls[3] = {l0, l1, l2};
+    bool wide = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         dd s = dd_add(ls[i], comb);
         dd p = dd_add(dd_add(dd_add(s, s), dd_add(s, s)), s);             // 5 s
         p = dd_add(p, p);                                                 // 10 s
-        a.pl[r * 3 + i] = trunc_dd(dd_neg(p));
+        const int64_t v = trunc_dd(dd_neg(p));
+        a.pl[r * 3 + i] = v;
+        if (a.pl32) { a.pl32[r * 3 + i] = (int32_t)v; if (v != (int64_t)(int32_t)v) wide = true; }
     }
+    if (wide) a.genotyped[r] = 3;
 }
 
 }  // namespace svjg

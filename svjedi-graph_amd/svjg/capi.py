@@ -73,6 +73,8 @@ _SIGS = {
                                      ctypes.c_void_p]),
     "svjg_genotype_view": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                           ctypes.c_uint32, ctypes.c_double] + [ctypes.POINTER(ctypes.c_void_p)] * 4),
+    "svjg_set_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "svjg_run_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_double] + [ctypes.POINTER(ctypes.c_void_p)] * 4),
     "svjg_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                            ctypes.POINTER(ctypes.c_float)]),
     "svjg_sync": (ctypes.c_int, [ctypes.c_void_p]),
@@ -401,6 +403,31 @@ class Context:
                                          float(err), gt.ctypes.data, pl.ctypes.data, raw.ctypes.data, done.ctypes.data))
         return gt, pl, raw, done
 
+    def set_rows(self, sv_type, slot, ok):
+        """the VCF rows' input arrays of genotype(), left on the device for run_resident()"""
+        sv_type = np.ascontiguousarray(sv_type, dtype=np.uint8)
+        slot = np.ascontiguousarray(slot, dtype=np.uint32)
+        ok = np.ascontiguousarray(ok, dtype=np.uint8)
+        self._n_rows = len(sv_type)
+        self._chk(self.lib.svjg_set_rows(self.h, sv_type.ctypes.data, slot.ctypes.data, ok.ctypes.data, self._n_rows))
+
+    def run_resident(self, min_support, err, base_offset=0):
+        """One whole pass with one host wait (svjg_run_resident): zero the counts, classify the uploaded text, all-reduce the
+        counts if this context has a communicator, genotype the rows of set_rows().  -> (gt, pl[n, 3] int32, raw[n, 2], flags):
+        read-only views of the library's pinned result block, overwritten by the next call; flags bit 0 = genotyped, bit 1 =
+        the row's PLs need 64 bits (genotype() has them)."""
+        n = self._n_rows
+        p = [ctypes.c_void_p() for _ in range(4)]
+        self._chk(self.lib.svjg_run_resident(self.h, base_offset, min_support, float(err), *[ctypes.byref(x) for x in p]))
+        if not n:
+            return np.zeros(0, np.uint8), np.zeros((0, 3), np.int32), np.zeros((0, 2), np.uint32), np.zeros(0, np.uint8)
+
+        def view(ptr, count, dt):
+            a = np.frombuffer((ctypes.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr.value), dtype=dt)
+            a.flags.writeable = False
+            return a
+        return view(p[0], n, np.uint8), view(p[1], n * 3, np.int32).reshape(n, 3), view(p[2], n * 2, np.uint32).reshape(n, 2), view(p[3], n, np.uint8)
+
     def kernel_ms(self):
         a, b, c = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
         self._chk(self.lib.svjg_last_kernel_ms(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
@@ -408,6 +435,10 @@ class Context:
 
     def sync(self):
         self._chk(self.lib.svjg_sync(self.h))
+
+
+def device_count():
+    return int(load_library().svjg_device_count())
 
 
 def _handles(ctxs):

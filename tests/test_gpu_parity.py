@@ -740,3 +740,65 @@ def test_id_tag_across_span_and_half_boundaries(ctx, tmp_path):
         ctx.classify(np.frombuffer(good, dtype=np.uint8))
         assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want), p
         assert ctx.stats()["n_deferred"] >= 1
+
+
+def _step_by_step(c, gaf, rows, ms=3, err=0.00005):
+    c.reset_counts()
+    c.upload(gaf)
+    c.classify_resident()
+    gt, pl, raw, done = c.genotype(rows.sv_type, rows.slot, rows.ok, ms, err)
+    return c.counts(), c.stats(), gt, pl, raw, done
+
+
+def test_run_resident_is_the_three_calls(tmp_path):
+    """svjg_run_resident (zero, classify, genotype with ONE host wait; what bench.py times) gives what reset_counts +
+    classify_resident + genotype give: counts, statistics, GT, PL, raw counts — on ordinary lines, with lines on the exact path
+    (revisited names are in the synthetic stream; CRLF and an id:f: tag are added), behind a one-rank RCCL communicator, and
+    again after more lines than the list of deferred lines holds (the call then repeats the pass step by step)."""
+    from svjg import capi, genotype, shard
+    pre, gaf, g, orc = _synth_case(tmp_path, 40000, 1500, 3, "mixed", 33)
+    rows = genotype.VcfRows(pre + ".vcf", g.slot_of)
+    tagged = bytes(gaf).replace(b"\tdv:f:", b"\tid:f:0.9\tdv:f:", 40).replace(b"\n", b"\r\n", 3)
+    many = np.frombuffer(bytes(gaf).replace(b"\tdv:f:", b"\tid:f:0.5\tdv:f:") * 4, dtype=np.uint8)   # 160 k lines, every one with the tag
+    c = capi.Context(0)
+    try:
+        c.load_graph(g)
+        c.set_rows(rows.sv_type, rows.slot, rows.ok)
+        for text, min_def in ((gaf, 0), (np.frombuffer(tagged, dtype=np.uint8), 40), (many, 150000)):
+            want = _step_by_step(c, text, rows)
+            for _ in range(2):                                  # (twice: the status of the call before must not leak into the next)
+                gt, pl, raw, flags = (np.array(x) for x in c.run_resident(3, 0.00005))
+                assert np.array_equal(c.counts(), want[0]) and want[0].sum() > 0
+                st = c.stats()
+                assert st["n_lines"] == want[1]["n_lines"] and st["n_deferred"] == want[1]["n_deferred"] >= min_def
+                assert np.array_equal(gt, want[2]) and np.array_equal(pl, want[3]) and pl.dtype == np.int32 and np.array_equal(raw, want[4])
+                assert np.array_equal(flags & 1, want[5]) and not (flags & 2).any()
+        shard.RcclGroup(c, 1, 0, lambda uid: uid)              # a communicator of one rank: the all-reduce leg runs, the counts stay
+        want = _step_by_step(c, gaf, rows)
+        gt, pl, raw, flags = (np.array(x) for x in c.run_resident(3, 0.00005))
+        assert np.array_equal(c.counts(), want[0]) and np.array_equal(pl, want[3]) and np.array_equal(gt, want[2])
+        # a malformed line: the reference's exception, as from classify()
+        bad = bytes(gaf)[:5000].rsplit(b"\n", 1)[0] + b"\nread\tx\t1\t2\t+\t>a>b\t1\t0\t1\t1\t1\t60\n"
+        c.upload(bad)
+        with pytest.raises(ValueError):
+            c.run_resident(3, 0.00005)
+    finally:
+        c.close()
+
+
+def test_bench_single_process_two_gpus():
+    """bench.py --gpus 2 without a launcher: one process, one context and one thread per GPU, RCCL all-reduce inside the timed
+    pass.  On a one-GPU box it must refuse (non-zero exit, no JSON line)."""
+    import subprocess
+    import sys
+    from svjg import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    have = capi.device_count()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c2", "--aln", "200000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=600)
+    if have < 2:
+        assert r.returncode != 0 and "needs 2 devices, found" in r.stderr and not r.stdout.strip()
+        return
+    assert r.returncode == 0, r.stderr[-500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["ranks"] == 2 and line["value"] > 0 and line["deferred_lines_per_step"] == 0
