@@ -62,6 +62,33 @@ def test_synth_sha(golden, tmp_path):
     assert hashlib.sha256(open(out, "rb").read()).hexdigest() == g6["sha256_json"]
 
 
+def test_repeated_and_many_records(tmp_path):
+    """a record that stands for several list elements (n_ref / n_alt > 1), lists of thousands of lines over several runs of
+    keys, the last line without a terminator: the file is what json.dumps makes of the same dictionary"""
+    lines = [f"read{i}\t{i}\tq\"\\\x01\u00e9\tcol\n".encode("utf-8") for i in range(3000)]
+    lines[-1] = lines[-1][:-1]
+    raw = b"".join(lines)
+    starts = np.cumsum([0] + [len(x) for x in lines[:-1]])
+    rng = np.random.default_rng(3)
+    n_slots = 40
+    recs = np.zeros(60000, dtype=capi.HITREC_DT)
+    recs["line_start"] = starts[rng.integers(0, len(lines), len(recs))]
+    recs["slot"] = rng.integers(0, n_slots - 3, len(recs))
+    recs["n_ref"] = rng.integers(0, 3, len(recs))
+    recs["n_alt"] = np.where(recs["n_ref"] == 0, rng.integers(1, 4, len(recs)), 0)
+    ids = [f"chr{i % 7}:DEL-{i}-{i + 60}" for i in range(n_slots)]
+    text = raw.decode("utf-8").splitlines(True)
+    at = {int(s): t for s, t in zip(starts, text)}
+    want = {}
+    order = np.lexsort((np.arange(len(recs)), recs["line_start"]))          # file order inside a key
+    for r in recs[order]:
+        e = want.setdefault(ids[int(r["slot"])], [[], []])
+        e[0] += [at[int(r["line_start"])]] * int(r["n_ref"]); e[1] += [at[int(r["line_start"])]] * int(r["n_alt"])
+    out = str(tmp_path / "o.json")
+    capi.write_informative_json(out, np.frombuffer(raw, dtype=np.uint8), recs, ids, n_threads=5)
+    assert open(out).read() == json.dumps(want, sort_keys=True, indent=4)
+
+
 def test_invalid_utf8(tmp_path):
     recs = np.zeros(1, dtype=capi.HITREC_DT)
     recs["n_ref"] = 1
