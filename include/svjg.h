@@ -41,6 +41,12 @@ extern "C" {
 #define SVJG_EXC_INDEX_ERROR     2   /* empty path column, unoriented multi-node path, node name without '-' */
 #define SVJG_EXC_KEY_ERROR       3   /* alt node missing from the GFA (filter-alignments.py:346) */
 #define SVJG_EXC_ZERO_DIVISION   4   /* Alen == 0 without an id:f: tag (filter-alignments.py:196) */
+/* Not an exception: int() / float() / str.rstrip() of the reference also take non-ASCII digits and blanks (Unicode categories Nd,
+ * Zs, ...), which the kernels do not read.  A line whose decimal column or id:f: value fails the ASCII rules AND holds a byte
+ * >= 0x80 is neither counted nor an error: its offset goes to a list (svjg_get_host_lines) and the host decides with Python's
+ * own int() / float() (svjedi-graph_amd/svjg/filter.py: resolve_host_lines), resubmitting an ASCII spelling of the line if the
+ * reference accepts it. */
+#define SVJG_EXC_ASK_HOST        5
 
 typedef struct svjg_ctx svjg_ctx;
 
@@ -146,6 +152,9 @@ int svjg_set_counts(svjg_ctx *ctx, const uint32_t *in, uint32_t n_slots);   /* p
 int svjg_alloc_counts(svjg_ctx *ctx, uint32_t n_slots);
 /* hit records accumulated since the last svjg_reset_counts, unordered; copy at most `cap` */
 int svjg_get_hits(svjg_ctx *ctx, svjg_hitrec *out, uint64_t cap, uint64_t *n);
+/* byte offsets (base_offset included) of the lines set aside for the host since the last svjg_reset_counts (SVJG_EXC_ASK_HOST),
+ * unordered; copy at most `cap`, *n = how many there are */
+int svjg_get_host_lines(svjg_ctx *ctx, uint64_t *out, uint64_t cap, uint64_t *n);
 
 /* ---- multi-GPU: one process per GPU, one all-reduce of the count vector over RCCL/xGMI ------------- */
 int svjg_comm_unique_id(char *out128);                                      /* rank 0, then broadcast by the launcher */
@@ -167,6 +176,13 @@ int svjg_allreduce_counts_all(svjg_ctx *const *ctxs, int n);
 int svjg_genotype(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok,
                   uint64_t n_rows, uint32_t min_support, double err,
                   uint8_t *gt, int64_t *pl, uint32_t *raw, uint8_t *genotyped);
+/* PL boundary guard.  The reference adds Decimal(math.log10(math.comb(rc1 + rc2, rc1))) to the three likelihoods
+ * (predict-genotype.py:313): libm's log10 of an exact big integer, a double that need not be the correctly rounded logarithm the
+ * kernel works with (double-double table of log10(i!)).  The two agree on every known answer, but a difference in the last
+ * places, times ten, right next to an integer would turn a PL by one: out[r] = 1 for the rows of the last svjg_genotype /
+ * svjg_genotype_view call in which one of the three -10 * (lik + comb) lies within 1e-6 of an integer.  The caller recomputes
+ * those rows (a few per million) with the reference's own arithmetic: svjedi-graph_amd/svjg/genotype.py: exact_pl. */
+int svjg_genotype_boundary(svjg_ctx *ctx, uint8_t *out, uint64_t n_rows);
 /* The same without the copy into caller buffers: the four pointers look into the context's pinned host block (where the
  * device wrote the results) and stay valid until the next svjg_genotype / svjg_genotype_view / svjg_destroy on `ctx`. */
 int svjg_genotype_view(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok,
@@ -181,10 +197,11 @@ int svjg_genotype_view(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *sl
  * predict-genotype.py:216-227, :281-325 with the counts handed over in HBM instead of through the JSON file).
  * Results land in the context's pinned host block, valid until the next svjg_run_resident / svjg_set_rows / svjg_destroy:
  * gt[r], raw[r*2..] as svjg_genotype; pl[r*3..] = the PLs as 32-bit integers; flags[r] bit 0 = genotyped, bit 1 = a PL of the
- * row does not fit 32 bits (ask svjg_genotype for the 64-bit values: it needs > 4e7 informative alignments for one SV). */
+ * row does not fit 32 bits (ask svjg_genotype for the 64-bit values: it needs > 4e7 informative alignments for one SV);
+ * boundary[r] as svjg_genotype_boundary. */
 int svjg_set_rows(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows);
 int svjg_run_resident(svjg_ctx *ctx, uint64_t base_offset, uint32_t min_support, double err,
-                      const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags);
+                      const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags, const uint8_t **boundary);
 
 /* ---- host-side writer of <prefix>_informative_aln.json (libsvjg_host.so, no GPU involved) -----------------
  * Byte-identical to json.dumps(dict_of_informative_aln, sort_keys=True, indent=4) (filter-alignments.py:174-175)

@@ -47,6 +47,7 @@ struct svjg_ctx {
     // outputs
     uint64_t *d_deferred = nullptr;  uint64_t deferred_cap = 0;
     svjg_hitrec *d_recs = nullptr;   uint64_t rec_cap = 0;
+    uint64_t *d_host = nullptr;      uint64_t host_cap = 0;     // offsets of the lines set aside for the host (SVJG_EXC_ASK_HOST)
     DevStatus *d_st = nullptr;
     unsigned long long *d_dbg = nullptr;
     DevStatus *h_stp = nullptr;          // host twin of d_st in pinned memory: the status copies are asynchronous in both directions
@@ -57,6 +58,7 @@ struct svjg_ctx {
     unsigned int *d_maxn = nullptr;
     void *d_rows = nullptr;  uint64_t rows_cap = 0;
     void *h_rows = nullptr;  uint64_t h_rows_cap = 0;   // pinned twin of d_rows
+    uint64_t geno_rows = 0;                              // rows of the last svjg_genotype / svjg_genotype_view (svjg_genotype_boundary)
     // resident VCF rows of svjg_set_rows / svjg_run_resident: device block (results, row inputs) and the pinned host block the results land in
     void *d_run = nullptr;  uint64_t d_run_cap = 0;  void *h_run = nullptr;  uint64_t h_run_cap = 0;  uint64_t run_rows = 0;
     // timing of the last calls
@@ -132,7 +134,7 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     free_graph(c);
-    hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_st); hipFree(c->d_logfact);
+    hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_host); hipFree(c->d_st); hipFree(c->d_logfact);
     hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows); hipFree(c->d_run);
     if (c->h_rows) hipHostFree(c->h_rows);
     if (c->h_run) hipHostFree(c->h_run);
@@ -343,7 +345,7 @@ static void main_launch_setup(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_
     { const char *dg = getenv("SVJG_DIAG"); a.diag = dg ? (uint32_t)atoi(dg) : 0u; }   // ablation knob (measurement builds only)
 #endif
     a.counts = c->d_counts; a.deferred = c->d_deferred; a.deferred_cap = c->deferred_cap;
-    a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.st = c->d_st; a.dbg = c->d_dbg;
+    a.recs = c->d_recs; a.rec_cap = c->rec_cap; a.host_lines = c->d_host; a.host_cap = c->host_cap; a.st = c->d_st; a.dbg = c->d_dbg;
     lds = LDS_MAIN;
     if (c->occ_main < 1) {                                // persistent grid: every CU filled to what LDS / registers admit (asked once)
         int occ = 0;
@@ -379,9 +381,11 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
     const uint64_t n = end - begin;
     uint64_t def_want = deferred_want(c, n);
     uint64_t rec_want = want_hits ? c->hs().n_recs + n / 64 + 65536 : 0;
+    uint64_t host_want = c->hs().n_host + 4096;
     int rc;
     for (int attempt = 0; attempt < 3; ++attempt) {
         if ((rc = ensure(c, (void **)&c->d_deferred, &c->deferred_cap, def_want, sizeof(uint64_t), false))) return rc;
+        if ((rc = ensure(c, (void **)&c->d_host, &c->host_cap, host_want, sizeof(uint64_t), true))) return rc;
         if (want_hits && (rc = ensure(c, (void **)&c->d_recs, &c->rec_cap, rec_want, sizeof(svjg_hitrec), true))) return rc;
         // snapshot so that an overflowed attempt can be rolled back
         HIPCHK(c, hipMemcpyAsync(c->d_snap, c->d_counts, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -435,6 +439,7 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         if (attempt == 2) { c->err = "output buffers overflowed repeatedly"; return SVJG_E_NOMEM; }
         if (c->hs().overflow & 1u) def_want = n / 24 + 64;
         if (c->hs().overflow & 2u) rec_want = before.n_recs + (c->hs().n_recs - before.n_recs) * 2 + n / 24 + 64;
+        if (c->hs().overflow & 4u) host_want = before.n_host + n / 24 + 64;
         HIPCHK(c, hipMemcpyAsync(c->d_counts, c->d_snap, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
         uint64_t keep_err = before.err;
         c->hs() = before; c->hs().err = keep_err;
@@ -587,6 +592,17 @@ extern "C" int svjg_set_counts(svjg_ctx *c, const uint32_t *in, uint32_t n_slots
     return 0;
 }
 
+extern "C" int svjg_get_host_lines(svjg_ctx *c, uint64_t *out, uint64_t cap, uint64_t *n) {
+    if (!c || !n) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    *n = c->hs().n_host;
+    const uint64_t have = c->hs().n_host < cap ? c->hs().n_host : cap;
+    if (have && !out) return SVJG_E_ARG;
+    if (have) HIPCHK(c, hipMemcpyAsync(out, c->d_host, have * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 extern "C" int svjg_get_hits(svjg_ctx *c, svjg_hitrec *out, uint64_t cap, uint64_t *n) {
     if (!c || !n) return SVJG_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -711,13 +727,13 @@ static int build_logfact(svjg_ctx *c, uint32_t upto) {
     return 0;
 }
 
-// results of all rows -> the pinned host block of the context: [ pl 24 | raw 8 | gt 1 | done 1 ] x n_rows
+// results of all rows -> the pinned host block of the context: [ pl 24 | raw 8 | gt 1 | done 1 | boundary 1 ] x n_rows
 static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
                          uint32_t min_support, double err) {
     HIPCHK(c, hipSetDevice(c->device));
-    // one device block and its pinned host twin: [ pl 24 | raw 8 | gt 1 | done 1 ] n rows of output, max_n, then
+    // one device block and its pinned host twin: [ pl 24 | raw 8 | gt 1 | done 1 | boundary 1 ] n rows of output, max_n, then
     // [ slot 4 | type 1 | ok 1 ] n rows of input -> ONE copy in and ONE copy out per call whatever the number of arrays
-    const uint64_t out_bytes = n_rows * 34, maxn_off = (out_bytes + 7) & ~7ull, in_off = maxn_off + 8, in_bytes = n_rows * 6;
+    const uint64_t out_bytes = n_rows * 35, maxn_off = (out_bytes + 7) & ~7ull, in_off = maxn_off + 8, in_bytes = n_rows * 6;
     const uint64_t total = in_off + in_bytes + 64;
     int rc = ensure(c, &c->d_rows, &c->rows_cap, total, 1, false);
     if (rc) return rc;
@@ -739,7 +755,8 @@ static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *sl
     GenoArgs a{};
     a.counts = c->d_counts; a.sv_type = d_type; a.slot = d_slot; a.ok = d_ok; a.n_rows = n_rows; a.min_support = min_support;
     a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
-    a.gt = d_gt; a.pl = d_pl; a.raw = d_raw; a.genotyped = d_done; a.max_n = d_maxn; a.n_slots = c->n_slots;
+    a.gt = d_gt; a.pl = d_pl; a.raw = d_raw; a.genotyped = d_done; a.boundary = base + n_rows * 34; a.max_n = d_maxn; a.n_slots = c->n_slots;
+    c->geno_rows = n_rows;
     const uint32_t grid = (uint32_t)((n_rows + TPB - 1) / TPB);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     // One pass with the log10(i!) table at hand; the kernel reports the largest n = ref + alt it met beyond the table, and
@@ -802,10 +819,10 @@ extern "C" int svjg_genotype_view(svjg_ctx *c, const uint8_t *sv_type, const uin
 // copies the results (PLs as 32-bit integers) into the context's pinned block; then it waits ONCE.  What the host used to decide
 // between the kernels it checks afterwards, and repeats the pass the slow way if a buffer overflowed or the log10(i!) table was
 // too short (first call after a deeper sample than ever before).
-struct RunLayout { uint64_t pl32, raw, gt, flags, maxn, status, out_bytes, pl64, slot, type, ok, total; };
+struct RunLayout { uint64_t pl32, raw, gt, flags, boundary, maxn, status, out_bytes, pl64, slot, type, ok, total; };
 static RunLayout run_layout(uint64_t n) {
     RunLayout L; uint64_t o = 0;
-    L.pl32 = o; o += n * 12; L.raw = o; o += n * 8; L.gt = o; o += n; L.flags = o; o += n; o = (o + 7) & ~7ull; L.maxn = o; o += 8; L.status = o; o += (sizeof(DevStatus) + 7) & ~7ull; L.out_bytes = o;
+    L.pl32 = o; o += n * 12; L.raw = o; o += n * 8; L.gt = o; o += n; L.flags = o; o += n; L.boundary = o; o += n; o = (o + 7) & ~7ull; L.maxn = o; o += 8; L.status = o; o += (sizeof(DevStatus) + 7) & ~7ull; L.out_bytes = o;
     L.pl64 = o; o += n * 24; L.slot = o; o += n * 4; L.type = o; o += n; L.ok = o; o += n; L.total = o + 64;
     return L;
 }
@@ -840,15 +857,15 @@ static GenoArgs run_geno_args(svjg_ctx *c, const RunLayout &L, uint32_t min_supp
     a.min_support = min_support;
     a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
     a.gt = base + L.gt; a.pl = (int64_t *)(base + L.pl64); a.raw = (uint32_t *)(base + L.raw); a.genotyped = base + L.flags;
-    a.pl32 = (int32_t *)(base + L.pl32); a.max_n = (unsigned int *)(base + L.maxn); a.n_slots = c->n_slots;
+    a.pl32 = (int32_t *)(base + L.pl32); a.boundary = base + L.boundary; a.max_n = (unsigned int *)(base + L.maxn); a.n_slots = c->n_slots;
     a.logfact = c->d_logfact; a.logfact_n = c->logfact_n;
     return a;
 }
 
 extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min_support, double err,
-                                 const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags) {
-    if (!c || !gt || !pl || !raw || !flags) return SVJG_E_ARG;
-    *gt = nullptr; *pl = nullptr; *raw = nullptr; *flags = nullptr;
+                                 const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags, const uint8_t **boundary) {
+    if (!c || !gt || !pl || !raw || !flags || !boundary) return SVJG_E_ARG;
+    *gt = nullptr; *pl = nullptr; *raw = nullptr; *flags = nullptr; *boundary = nullptr;
     if (!c->have_graph || !c->have_gaf) { c->err = "svjg_run_resident needs a graph and an uploaded GAF"; return SVJG_E_ARG; }
     if (!c->d_run) { c->err = "svjg_set_rows has not been called"; return SVJG_E_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
@@ -857,6 +874,7 @@ extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min
     uint8_t *hb = (uint8_t *)c->h_run;
     int rc;
     if ((rc = ensure(c, (void **)&c->d_deferred, &c->deferred_cap, deferred_want(c, n), sizeof(uint64_t), false))) return rc;
+    if ((rc = ensure(c, (void **)&c->d_host, &c->host_cap, 4096, sizeof(uint64_t), false))) return rc;
     if (c->logfact_n == 0 && (rc = build_logfact(c, 65536))) return rc;
     // ---- everything enqueued ----
     uint8_t *base = (uint8_t *)c->d_run;
@@ -916,6 +934,7 @@ extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min
     } else {
         c->total_deferred = c->hs().n_deferred;
         if (c->hs().err != ~0ull) return SVJG_E_INPUT;
+        if (c->hs().n_host) { c->err = "the text holds lines only the host can decide (non-ASCII digits in a decimal column: svjg_get_host_lines); classify it with svjg_classify"; return SVJG_E_ARG; }
         if (c->comm) {
             const unsigned long long *gd = (const unsigned long long *)(hb + L.out_bytes);
             if (gd[0] >= (1ull << 32) || gd[1] >= (1ull << 32)) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
@@ -940,7 +959,15 @@ extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min
         }
         HIPCHK(c, hipEventElapsedTime(&c->ms_geno, c->ev[4], c->ev[5]));
     }
-    *pl = (const int32_t *)(hb + L.pl32); *raw = (const uint32_t *)(hb + L.raw); *gt = hb + L.gt; *flags = hb + L.flags;
+    *pl = (const int32_t *)(hb + L.pl32); *raw = (const uint32_t *)(hb + L.raw); *gt = hb + L.gt; *flags = hb + L.flags; *boundary = hb + L.boundary;
+    return 0;
+}
+
+// which rows of the last svjg_genotype / svjg_genotype_view call lie so close to a PL's integer boundary that the caller should
+// recompute them with the reference's own arithmetic (predict-genotype.py:313: log10 of an exact big integer)
+extern "C" int svjg_genotype_boundary(svjg_ctx *c, uint8_t *out, uint64_t n_rows) {
+    if (!c || (n_rows && !out) || n_rows != c->geno_rows || !c->h_rows) return SVJG_E_ARG;
+    memcpy(out, (const uint8_t *)c->h_rows + n_rows * 34, n_rows);
     return 0;
 }
 

@@ -59,8 +59,9 @@ struct DevStatus {
     unsigned long long n_recs;           // hit records appended
     unsigned long long err;              // min over (file offset << 3 | exception class); ~0 = none
     unsigned int non_ascii;
-    unsigned int overflow;               // bit 0: deferred list, bit 1: hit-record buffer
+    unsigned int overflow;               // bit 0: deferred list, bit 1: hit-record buffer, bit 2: list of lines for the host
     unsigned long long next_chunk;       // k_classify_main: small chunks handed out so far (zero at launch)
+    unsigned long long n_host;           // lines set aside for the host (SVJG_EXC_ASK_HOST)
 };
 
 struct ClassifyArgs {
@@ -77,6 +78,7 @@ struct ClassifyArgs {
     unsigned long long *counts;          // [n_slots] ref | alt << 32
     uint64_t *deferred;  uint64_t deferred_cap;
     svjg_hitrec *recs;   uint64_t rec_cap;
+    uint64_t *host_lines; uint64_t host_cap;
     DevStatus *st;
     unsigned long long *dbg;             // measurement only (SVJG_DIAG & 16): per-phase cycle sums of lane 0 of every worker
 };
@@ -874,6 +876,15 @@ __global__ __launch_bounds__(TPB) void k_step_reset(unsigned long long *counts, 
     }
 }
 
+// what the exact routine returned for the line at file offset `off`: the exception the reference would die with (the first of
+// the file wins), or "the host decides" (svjg.h: SVJG_EXC_ASK_HOST): neither counted nor fatal, its offset is kept
+__device__ inline void report_line(const ClassifyArgs &a, unsigned long long off, int rc) {
+    if (rc == SVJG_EXC_ASK_HOST) {
+        const unsigned long long i = atomicAdd(&a.st->n_host, 1ull);
+        if (i < a.host_cap) a.host_lines[i] = off; else atomicOr(&a.st->overflow, 4u);
+    } else atomicMin(&a.st->err, (off << 3) | (unsigned long long)rc);
+}
+
 struct SlowEmit {
     const ClassifyArgs *a;
     uint64_t line_start;
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
                 typedef const __attribute__((address_space(3))) uint8_t *lds_text;
                 rc = slow_line(a.g, (lds_text)(stage + off), s - a0, s - a0 + (e - s), em);
             } else rc = slow_line(a.g, a.gaf, s, e, em);
-            if (rc) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (unsigned long long)rc);
+            if (rc) report_line(a, a.base_offset + s, rc);
         }
         __syncthreads();
     }
@@ -1006,7 +1017,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
                 } else { const int r3 = slow_line(a.g, t, s - a0, s - a0 + (e - s), em, lane, 64u, &order); rc = wave_min(r3, order); }   // a path of more nodes than the scratch holds
             }
         } else { const int r4 = slow_line(a.g, a.gaf, s, e, em, lane, 64u, &order); rc = wave_min(r4, order); }
-        if (lane == 0 && rc) atomicMin(&a.st->err, ((a.base_offset + s) << 3) | (unsigned long long)rc);
+        if (lane == 0 && rc) report_line(a, a.base_offset + s, rc);
         __syncthreads();
     }
 }
@@ -1088,6 +1099,7 @@ struct GenoArgs {
     double l_ok, l_err, l_half;        // log10(1-e), log10(e), log10(1/2) computed by the host libm like CPython does
     const dd *logfact; uint32_t logfact_n;
     uint8_t *gt; int64_t *pl; uint32_t *raw; uint8_t *genotyped;
+    uint8_t *boundary;                 // 1: one of the row's three -10 * (lik + comb) lies within PL_GUARD of an integer (the host recomputes the row like the reference)
     int32_t *pl32;                     // svjg_run_resident: the three PLs as 32-bit integers (nullptr: not wanted); a row whose PLs do not fit sets bit 1 of genotyped[]
     unsigned int *max_n;               // [0] largest n = ref + alt beyond the log10(i!) table, [1] set if a row names a slot >= n_slots
     uint32_t n_slots;
@@ -1124,6 +1136,8 @@ __global__ __launch_bounds__(TPB) void k_geno_maxn(GenoArgs a) {
     if ((threadIdx.x & 63) == 0 && n) atomicMax(a.max_n, n);
 }
 
+constexpr double PL_GUARD = 1e-6;
+
 __device__ inline int64_t trunc_dd(dd v) {               // int(Decimal): toward zero
     double t = trunc(v.hi);
     if (t == v.hi) {                                     // hi is integral: the tail decides
@@ -1140,6 +1154,7 @@ __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
     bool go = geno_gate(a, r, ref, alt);
     a.raw[r * 2] = go ? ref : 0; a.raw[r * 2 + 1] = go ? alt : 0;
     a.genotyped[r] = go;
+    a.boundary[r] = 0;
     if (!go) { a.gt[r] = 3; a.pl[r * 3] = a.pl[r * 3 + 1] = a.pl[r * 3 + 2] = 0; if (a.pl32) a.pl32[r * 3] = a.pl32[r * 3 + 1] = a.pl32[r * 3 + 2] = 0; return; }
     double c1, c2; uint32_t r1, r2;
     geno_counts(a.sv_type[r], ref, alt, c1, c2, r1, r2);
@@ -1158,7 +1173,7 @@ __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
     else atomicMax(a.max_n, n);                          // the log10(i!) table is too short: the host grows it and runs the pass again
     comb = dd{comb.hi, 0.0};                             // the reference rounds log10(comb) to a double first (:313)
     dd ls[3] = {l0, l1, l2};
-    bool wide = false;
+    bool wide = false, near = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         dd s = dd_add(ls[i], comb);
@@ -1166,9 +1181,14 @@ __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
         p = dd_add(p, p);                                                 // 10 s
         const int64_t v = trunc_dd(dd_neg(p));
         a.pl[r * 3 + i] = v;
+        // The reference adds Decimal(math.log10(math.comb(n, k))) (:313): libm's log10 of a big integer rounded to a double, which
+        // need not be the correctly rounded value this kernel uses.  The two can differ in the last places; times ten, next to an
+        // integer, that could turn a PL by one.  Rows that close are flagged and recomputed on the host (svjg/genotype.py).
+        { const double fr = fabs(p.hi - rint(p.hi)); if (fr < PL_GUARD && comb.hi != 0.0) near = true; }   // (comb = log10(1) = 0 on both sides: nothing to disagree about)
         if (a.pl32) { a.pl32[r * 3 + i] = (int32_t)v; if (v != (int64_t)(int32_t)v) wide = true; }
     }
     if (wide) a.genotyped[r] = 3;
+    if (near) a.boundary[r] = 1;
 }
 
 }  // namespace svjg

@@ -324,10 +324,18 @@ SVJG_HD int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &stran
 // the nine int() columns, the id:f: tag, the path column and its node count.  0 or the exception class.
 struct SlowLine { uint64_t ps, pe; bool oriented; uint32_t k; int64_t Tlen, Ts, Te; };
 
+// some byte >= 0x80 in t[a, b): what failed the ASCII rules may pass Python's (Unicode digits, Unicode blanks): the host decides
+template <class P>
+SVJG_HD bool has_high(P t, uint64_t a, uint64_t b) {
+    for (uint64_t q = a; q < b; ++q) if ((uint32_t)t[q] >= 0x80u) return true;
+    return false;
+}
+
 template <class P>
 SVJG_HD int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
     o.k = 0;
     while (e > s && py_space(t[e - 1])) --e;
+    // (str.rstrip() also takes Unicode blanks: a line that ends in a byte >= 0x80 is the host's if anything below fails on it)
     uint64_t fs[12], fe[12]; uint32_t nf = 0;
     { uint64_t st = s;
       for (uint64_t q = s; q <= e && nf < 12; ++q)
@@ -335,14 +343,15 @@ SVJG_HD int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
     if (nf < 12) return SVJG_EXC_VALUE_ERROR;
     int64_t v[12];
     const int cols[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
-    for (int j = 0; j < 9; ++j) if (!py_int(t, fs[cols[j]], fe[cols[j]], v[cols[j]])) return SVJG_EXC_VALUE_ERROR;
+    for (int j = 0; j < 9; ++j)
+        if (!py_int(t, fs[cols[j]], fe[cols[j]], v[cols[j]])) return has_high(t, fs[cols[j]], fe[cols[j]]) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR;
     { uint64_t last = e;                                           // "id:f:" in line  (:193-196)
       for (uint64_t q = s; q + 5 <= e; ++q)
           if (t[q] == 'i' && t[q + 1] == 'd' && t[q + 2] == ':' && t[q + 3] == 'f' && t[q + 4] == ':') last = q;
       if (last != e) {
           uint64_t a = last + 5, b = a;
           while (b < e && t[b] != '\t') ++b;
-          if (!py_float_ok(t, a, b)) return SVJG_EXC_VALUE_ERROR;
+          if (!py_float_ok(t, a, b)) return has_high(t, a, b) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR;
       } else if (v[10] == 0) return SVJG_EXC_ZERO_DIVISION; }
     o.ps = fs[5]; o.pe = fe[5];
     if (o.pe == o.ps) return SVJG_EXC_INDEX_ERROR;                 // p[0]

@@ -63,6 +63,7 @@ _SIGS = {
     "svjg_set_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
     "svjg_alloc_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32]),
     "svjg_get_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
+    "svjg_get_host_lines": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "svjg_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "svjg_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "svjg_allreduce_counts": (ctypes.c_int, [ctypes.c_void_p]),
@@ -74,7 +75,8 @@ _SIGS = {
     "svjg_genotype_view": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                           ctypes.c_uint32, ctypes.c_double] + [ctypes.POINTER(ctypes.c_void_p)] * 4),
     "svjg_set_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
-    "svjg_run_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_double] + [ctypes.POINTER(ctypes.c_void_p)] * 4),
+    "svjg_run_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_double] + [ctypes.POINTER(ctypes.c_void_p)] * 5),
+    "svjg_genotype_boundary": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "svjg_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                            ctypes.POINTER(ctypes.c_float)]),
     "svjg_sync": (ctypes.c_int, [ctypes.c_void_p]),
@@ -371,6 +373,15 @@ class Context:
         self._chk(self.lib.svjg_get_hits(self.h, out.ctypes.data, n, ctypes.byref(got)))
         return out[: got.value]
 
+    def host_lines(self):
+        """byte offsets of the lines the kernels set aside for the host (svjg.h: SVJG_EXC_ASK_HOST), in file order"""
+        n = ctypes.c_uint64(0)
+        self._chk(self.lib.svjg_get_host_lines(self.h, None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint64)
+        if n.value:
+            self._chk(self.lib.svjg_get_host_lines(self.h, out.ctypes.data, n.value, ctypes.byref(n)))
+        return np.sort(out)
+
     def comm_init(self, unique_id, n_ranks, rank):
         self._chk(self.lib.svjg_comm_init(self.h, unique_id, n_ranks, rank))
 
@@ -415,9 +426,10 @@ class Context:
         """One whole pass with one host wait (svjg_run_resident): zero the counts, classify the uploaded text, all-reduce the
         counts if this context has a communicator, genotype the rows of set_rows().  -> (gt, pl[n, 3] int32, raw[n, 2], flags):
         read-only views of the library's pinned result block, overwritten by the next call; flags bit 0 = genotyped, bit 1 =
-        the row's PLs need 64 bits (genotype() has them)."""
+        the row's PLs need 64 bits (genotype() has them).  self.last_boundary: the rows to recompute like the reference
+        (svjg_genotype_boundary)."""
         n = self._n_rows
-        p = [ctypes.c_void_p() for _ in range(4)]
+        p = [ctypes.c_void_p() for _ in range(5)]
         self._chk(self.lib.svjg_run_resident(self.h, base_offset, min_support, float(err), *[ctypes.byref(x) for x in p]))
         if not n:
             return np.zeros(0, np.uint8), np.zeros((0, 3), np.int32), np.zeros((0, 2), np.uint32), np.zeros(0, np.uint8)
@@ -426,7 +438,16 @@ class Context:
             a = np.frombuffer((ctypes.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr.value), dtype=dt)
             a.flags.writeable = False
             return a
+        self.last_boundary = view(p[4], n, np.uint8)
         return view(p[0], n, np.uint8), view(p[1], n * 3, np.int32).reshape(n, 3), view(p[2], n * 2, np.uint32).reshape(n, 2), view(p[3], n, np.uint8)
+
+    def boundary_flags(self, n_rows):
+        """rows of the last genotype() call whose PLs lie within 1e-6 of an integer boundary (to be recomputed by
+        svjg.genotype.exact_pl, the reference's own arithmetic)"""
+        out = np.zeros(n_rows, dtype=np.uint8)
+        if n_rows:
+            self._chk(self.lib.svjg_genotype_boundary(self.h, out.ctypes.data, n_rows))
+        return out
 
     def kernel_ms(self):
         a, b, c = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)

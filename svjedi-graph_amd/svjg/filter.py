@@ -92,6 +92,122 @@ def reference_error(data, exc):
     return exc
 
 
+# ---- lines the kernels leave to the host (svjg.h: SVJG_EXC_ASK_HOST) ---------------------------------------------------------
+# int() / float() / str.rstrip() of the reference (filter-alignments.py:125, :189-194) also take Unicode digits and blanks; the
+# kernels read ASCII.  A line whose decimal column (or id:f: value) fails the ASCII rules and holds a byte >= 0x80 is set aside by
+# the kernels: not counted, not an error.  Here such a line is put to Python's own int() / float(): it either raises what the
+# reference raises, or is rewritten — digit for digit, blank for blank — into an ASCII spelling that means the same to the
+# reference and goes through the GPU again (its hit records are mapped back onto the original line, whose text the JSON holds).
+HOST_BASE = 1 << 60            # base offset of the resubmitted lines: hit records / errors at or beyond it belong to them
+_INT_COLS = (1, 2, 3, 6, 7, 8, 9, 10, 11)
+
+
+def _ascii_number(s):
+    import unicodedata
+    out = []
+    for ch in s:
+        if ord(ch) < 128:
+            out.append(ch)
+        elif ch.isspace():
+            out.append(" ")
+        else:
+            out.append(str(unicodedata.decimal(ch)))           # (int() / float() accepted the text: what is left are decimal digits)
+    return "".join(out)
+
+
+def host_line(text):
+    """read_gaf_line (filter-alignments.py:184-198) on one line as the text-mode read delivers it, with Python's own int() /
+    float().  Raises what the reference raises there; else -> the ASCII spelling of the line for the kernels."""
+    line = text.rstrip()
+    cols = line.split("\t")
+    Qid, Qlen, Qs, Qe = cols[:4]                                # (ValueError: not enough values to unpack, like the reference)
+    Tid, Tlen, Ts, Te = cols[5:9]
+    Am, Alen, Aq = cols[9:12]
+    val = {i: int(cols[i]) for i in _INT_COLS}
+    if "id:f:" in line:
+        float(line.split("id:f:")[-1].split("\t")[0])
+    else:
+        val[9] / val[10]
+    for i in _INT_COLS:
+        cols[i] = _ascii_number(cols[i])
+    out = "\t".join(cols)
+    if "id:f:" in out:
+        head, _, tail = out.rpartition("id:f:")
+        v, sep, rest = tail.partition("\t")
+        if not v.isascii():
+            if head.count("\t") < 12 and head.count("\t") == 5:
+                # (the tag's value is a piece of the path column: rewriting it would rename a node)
+                raise NotImplementedError("an id:f: value with non-ASCII digits inside the path column")
+            out = head + "id:f:" + _ascii_number(v) + sep + rest
+    return out.encode("utf-8") + b"\n"
+
+
+def resolve_host_lines(ctxs, data, want_hits, error=None):
+    """After every shard is classified (`error`: the exception of the first bad line the kernels met, if any): decide the lines the
+    kernels set aside.  Raises the exception of the file's first bad line (a host line's own, or `error`); else resubmits the
+    accepted lines through ctxs[0] and returns (their offsets in the resubmitted text, the original offsets) for remap_hits(),
+    or None when there was nothing to do."""
+    offs = np.sort(np.concatenate([c.host_lines() for c in ctxs])) if ctxs else np.zeros(0, np.uint64)
+    limit = None if error is None else getattr(error, "svjg_offset", None)
+    first = error
+    accepted = []
+    n = int(data.size)
+    for off in offs.tolist():
+        if limit is not None and off >= limit:
+            break
+        e = off
+        while e < n and data[e] not in (10, 13):
+            blk = np.asarray(data[e:e + 65536])
+            hit = np.flatnonzero((blk == 10) | (blk == 13))
+            if hit.size:
+                e += int(hit[0])
+                break
+            e += blk.size
+        raw = bytes(data[off:e])
+        try:
+            text = raw.decode("utf-8") + ("\n" if e < n else "")
+        except UnicodeDecodeError:
+            break                                               # (the text-mode read dies first: check_utf8 / reference_error say where)
+        try:
+            accepted.append((off, host_line(text)))
+        except (ValueError, ZeroDivisionError, IndexError) as ex:
+            ex.svjg_offset = off
+            first, limit = ex, off
+            break
+    if accepted:
+        starts = np.cumsum([0] + [len(b) for _, b in accepted[:-1]]).astype(np.uint64)
+        orig = np.array([o for o, _ in accepted], dtype=np.uint64)
+        ctx = ctxs[0]
+        before = len(ctx.host_lines())
+        try:
+            ctx.classify(np.frombuffer(b"".join(b for _, b in accepted), dtype=np.uint8), base_offset=HOST_BASE, want_hits=want_hits)
+        except (ValueError, IndexError, KeyError, ZeroDivisionError) as ex:
+            o = getattr(ex, "svjg_offset", None)
+            if o is not None and o >= HOST_BASE:
+                ex.svjg_offset = int(orig[np.searchsorted(starts, np.uint64(o - HOST_BASE), side="right") - 1])
+                if limit is None or ex.svjg_offset < limit:
+                    first = ex
+        if len(ctx.host_lines()) != before:
+            raise RuntimeError("a rewritten line was set aside again")
+    if first is not None:
+        raise first
+    return (starts, orig) if accepted else None
+
+
+def remap_hits(recs, remap):
+    """hit records of resubmitted host lines -> the original lines' offsets"""
+    if remap is None or recs is None or len(recs) == 0:
+        return recs
+    starts, orig = remap
+    sel = recs["line_start"] >= HOST_BASE
+    if sel.any():
+        recs = recs.copy()
+        idx = np.searchsorted(starts, recs["line_start"][sel] - np.uint64(HOST_BASE), side="right") - 1
+        recs["line_start"][sel] = orig[idx]
+    return recs
+
+
+
 def _stamp(t, what):
     """stage timers on stderr when SVJG_VERBOSE is set (measurement only)"""
     if os.environ.get("SVJG_VERBOSE"):
@@ -139,16 +255,21 @@ def classify_file(ctx, graph, gaf_path, want_hits=True):
     ctx.load_graph(graph)
     n = int(data.size)
     cuts = shard.cut_points(data, max(1, -(-n // CHUNK_BYTES)))
+    err = None
     try:
         for a, b in zip(cuts[:-1], cuts[1:]):
             if b > a:
                 ctx.classify(data[a:b], base_offset=a, want_hits=want_hits)
     except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+        err = e
+    try:
+        remap = resolve_host_lines([ctx], data, want_hits, err)
+    except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
         raise reference_error(data, e)
     if ctx.stats()["non_ascii"]:
         check_utf8(data)
     capi.allreduce_counts_all([ctx])              # one GPU: only the overflow guard of the 32-bit count fields
-    return ctx.counts(), (ctx.hits() if want_hits else None), data
+    return ctx.counts(), (remap_hits(ctx.hits(), remap) if want_hits else None), data
 
 
 def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
@@ -179,8 +300,13 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
                 x.join()
         # the first failing shard (file order) holds the first bad line
         first_bad = [(ranges[d][0][0], errs[i]) for i, d in enumerate(distinct) if errs[i] is not None]
-        if first_bad:
-            raise reference_error(data, min(first_bad, key=lambda x: x[0])[1])
+        err = min(first_bad, key=lambda x: x[0])[1] if first_bad else None
+        if err is not None and not isinstance(err, (ValueError, IndexError, KeyError, ZeroDivisionError)):
+            raise err
+        try:
+            remap = resolve_host_lines(ctxs, data, want_hits, err)       # (lines with non-ASCII digits: Python's int() decides)
+        except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+            raise reference_error(data, e)
         _stamp(t, f"tables -> device, upload + classify on {len(distinct)} GPU(s)")
         if any(c.stats()["non_ascii"] for c in ctxs):
             check_utf8(data)
@@ -190,7 +316,7 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
         total = ctxs[0].counts()
         recs = None
         if want_hits:
-            recs = ctxs[0].hits() if len(ctxs) == 1 else np.concatenate([c.hits() for c in ctxs])
+            recs = remap_hits(ctxs[0].hits() if len(ctxs) == 1 else np.concatenate([c.hits() for c in ctxs]), remap)
         _stamp(t, "count all-reduce, counts + hit records -> host")
         return total, recs, data
     finally:
@@ -311,6 +437,7 @@ def classify_stream(graph, stream, want_hits=True, device=0, _t=None):
                 finally:
                     del view                       # (a bytearray with a live export cannot grow)
                 done = upto
+        err = None
         try:
             while True:
                 b = stream.read(STREAM_BLOCK)
@@ -326,13 +453,17 @@ def classify_stream(graph, stream, want_hits=True, device=0, _t=None):
             # non-UTF-8 byte before it still wins (reference_error), then report
             for b in iter(lambda: stream.read(STREAM_BLOCK), b""):
                 buf += b
-            raise reference_error(np.frombuffer(bytes(buf), dtype=np.uint8), e)
-        data = np.frombuffer(buf, dtype=np.uint8)
+            err = e
+        data = np.frombuffer(bytes(buf), dtype=np.uint8) if err is not None else np.frombuffer(buf, dtype=np.uint8)
+        try:
+            remap = resolve_host_lines([ctx], data, want_hits, err)
+        except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+            raise reference_error(data, e)
         _stamp(t, "stream -> device, classified while it arrived")
         if ctx.stats()["non_ascii"]:
             check_utf8(data)
         capi.allreduce_counts_all([ctx])          # one GPU: the overflow guard
-        return ctx.counts(), (ctx.hits() if want_hits else None), data
+        return ctx.counts(), (remap_hits(ctx.hits(), remap) if want_hits else None), data
     finally:
         ctx.close()
 

@@ -97,6 +97,37 @@ def _fmt_counts(svtype_code, ref, alt):
     return str(round(sum(c), 3)), "%s,%s" % (c[0], c[1])
 
 
+def exact_pl(svtype_code, ref, alt, err):
+    """The three PL integers of one row with the reference's own arithmetic (predict-genotype.py:284-323): double products, Decimal
+    sums at precision 28, log10 of the exact binomial coefficient, truncation.  For the rows the kernel flags as lying within 1e-6 of
+    an integer boundary (svjg_genotype_boundary): there libm's log10 of a big integer — not necessarily the correctly rounded
+    value the kernel uses — could decide the integer."""
+    import math
+    from decimal import Decimal
+    c1, c2 = ref, alt
+    if svtype_code == 0 and ref > 0:
+        c1 = round(ref / 2, 1)
+    elif svtype_code == 1 and alt > 0:
+        c2 = round(alt / 2, 1)
+    rc1, rc2 = int(round(c1, 0)), int(round(c2, 0))
+    l_ok, l_err, l_half = math.log10(1 - err), math.log10(err), math.log10(1 / 2)
+    comb = Decimal(math.log10(math.comb(rc1 + rc2, rc1)))
+    liks = (Decimal(c1 * l_ok) + Decimal(c2 * l_err), Decimal((c1 + c2) * l_half), Decimal(c2 * l_ok) + Decimal(c1 * l_err))
+    return [int(-10 * (x + comb)) for x in liks]
+
+
+def apply_boundary_guard(ctx, rows, pl, raw, done, err):
+    """-> pl with the flagged rows recomputed by exact_pl (a copy only if a row is flagged), number of flagged rows"""
+    flags = ctx.boundary_flags(len(rows.sv_type))
+    idx = np.flatnonzero(flags & (np.asarray(done) != 0))
+    if len(idx) == 0:
+        return pl, 0
+    pl = np.array(pl, dtype=np.int64)
+    for r in idx:
+        pl[r] = exact_pl(int(rows.sv_type[r]), int(raw[r, 0]), int(raw[r, 1]), err)
+    return pl, len(idx)
+
+
 def write_vcf(out_path, rows, gt, pl, raw, done):
     n_done = 0
     with open(out_path, "w") as out:
@@ -141,6 +172,7 @@ def genotype_with_counts(ctx, vcf_path, slot_of, out_path, min_support=3, err=0.
     gt, pl, raw, done = ctx.genotype(rows.sv_type, rows.slot, rows.ok, min_support, 0.5 if bad_err else err, reuse_outputs=True)   # views: written out right away
     if bad_err and np.asarray(done).any():
         raise ValueError("math domain error")                   # (predict-genotype.py:295-297: the reference dies at the first genotyped row)
+    pl, _ = apply_boundary_guard(ctx, rows, pl, raw, done, err)
     if isinstance(rows, VcfRows):
         return write_vcf(out_path, rows, gt, pl, raw, done)
     try:

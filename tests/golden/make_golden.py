@@ -429,6 +429,74 @@ def make_quirks():
 
 
 # ----------------------------------------------------------------------------------------------
+# G3b lines whose decimal columns are written with non-ASCII digits / blanks (int(), float() and str.rstrip() take them)
+# ----------------------------------------------------------------------------------------------
+
+def make_unicode():
+    """golden/unicode: the quirks graph; GAF lines with Arabic-Indic / fullwidth digits and Unicode blanks in the integer columns,
+    at the line's end and in an id:f: value, alone and between ordinary lines; what the reference wrote or died with."""
+    q = f"{HERE}/quirks"
+    out = f"{HERE}/unicode"
+    os.makedirs(out, exist_ok=True)
+    L = {}
+    for line in open(f"{q}/q.gfa"):
+        c = line.rstrip("\n").split("\t")
+        if c[0] == "S":
+            L[c[1]] = len(c[2]) if "." in c[1].split(":")[-1] else int(c[1].split(":")[-1].split("-")[1]) - int(c[1].split(":")[-1].split("-")[0]) + 1
+    tags = "tp:A:P\tcm:i:9\ts1:i:90\ts2:i:0\tdv:f:0.0200"
+
+    def g(name, nodes_, ori, **kw):
+        return gaf_line(name, nodes_, list(ori), L, extra=kw.pop("extra", tags), **kw)
+
+    def arabic(s):
+        return "".join(chr(0x660 + int(ch)) if ch.isdigit() else ch for ch in s)
+
+    def wide(s):
+        return "".join(chr(0xFF10 + int(ch)) if ch.isdigit() else ch for ch in s)
+
+    def cols(line, f, which):
+        c = line.rstrip("\n").split("\t")
+        for i in which:
+            c[i] = f(c[i])
+        return "\t".join(c) + "\n"
+    plain = g("r0", ["1:1-1000", "1:1001-1500", "1:1501-3000"], ">>>")
+    alt = g("r1", ["1:1-1000", "1:1501-3000"], ">>")
+    ins = g("r2", ["1:1-1000", "1:1001.1", "1:1001-1500"], ">>>")
+    cases = {}
+    cases["digits_in_every_column"] = [plain, cols(alt, arabic, (1, 2, 3, 6, 7, 8, 9, 10, 11)), cols(ins, wide, (6, 7, 8)), alt]
+    cases["blanks"] = [cols(plain, lambda x: "\u2003" + x + "\u00a0", (7, 8)), alt.rstrip("\n") + "\u2003\u3000\n", cols(ins, lambda x: " " + arabic(x), (1, 6))]
+    cases["mixed_and_signs"] = [cols(alt, lambda x: "+" + arabic(x)[:1] + x[1:], (6, 8)), cols(plain, lambda x: arabic(x[:1]) + "_" + x[1:] if len(x) > 1 else x, (6, 8))]
+    cases["id_tag_value"] = ["r3\t500\t0\t500\t+\t>1:1-1000>1:1001-1500\t1500\t0\t1500\t0\t0\t60\tid:f:" + arabic("0.5") + "\n",
+                             alt.rstrip("\n") + "\tid:f:" + wide("1") + "e" + arabic("2") + "\n"]
+    cases["overlap_boundary"] = [cols(g(f"l{d}", ["1:1-1000", "1:1001-1500"], ">>", ts=1000 - d), arabic, (7,)) for d in (99, 100)]
+    cases["err_not_a_digit"] = [plain, cols(alt, lambda x: x + "\u00e9", (7,)), alt]
+    cases["err_behind_unicode_lines"] = [cols(alt, arabic, (6, 7, 8)), plain.replace("\t60\t", "\tx\t"), cols(ins, wide, (6,))]
+    cases["err_unicode_zero_alen"] = ["r3\t500\t0\t500\t+\t>1:1-1000>1:1001-1500\t1500\t0\t1500\t0\t" + arabic("0") + "\t60\t" + tags + "\n"]
+    cases["err_unicode_before_ascii_error"] = [cols(alt, lambda x: x + "\u0663x", (7,)), plain.replace("\t60\t", "\t\t")]
+    cases["err_id_tag_value"] = [alt.rstrip("\n") + "\tid:f:" + arabic("0.5") + "\u00e9\n"]
+    manifest = {}
+    tdir = tempfile.mkdtemp()
+    shutil.copy(f"{q}/q_svs_edges.json", f"{tdir}/q_svs_edges.json")
+    for name, lines in cases.items():
+        gaf = f"{out}/{name}.gaf"
+        with open(gaf, "w", encoding="utf-8") as fh:
+            fh.write("".join(lines))
+        js = f"{tdir}/q_informative_aln.json"
+        if os.path.exists(js):
+            os.remove(js)
+        rc, err = run_ref_filter(gaf, f"{q}/q.gfa", f"{tdir}/q")
+        if rc == 0:
+            shutil.copy(js, f"{out}/{name}.ref.json")
+            manifest[name] = {"rc": 0, "n_lines": len(lines)}
+        else:
+            assert rc == 1
+            manifest[name] = {"rc": 1, "error": err.split(":")[0], "n_lines": len(lines)}
+    with open(f"{out}/manifest.json", "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+    print("unicode:", {k: (v["rc"], v.get("error", "")) for k, v in manifest.items()})
+
+
+# ----------------------------------------------------------------------------------------------
 # G4 likelihood known answers
 # ----------------------------------------------------------------------------------------------
 
@@ -457,6 +525,46 @@ def make_lik():
     txt = np.array([r[9] for r in rows])
     np.savez_compressed(f"{out}/lik_kat.npz", cases=arr, err=errs, dp_ad=txt)
     print(f"lik: {len(rows)} known answers")
+
+
+def make_lik_boundary():
+    """lik/lik_boundary.npz: known answers of likelihood() where a PL lies next to an integer boundary (found by a search in
+    double precision over counts up to 3 000, then run through the reference), and for deep samples (counts up to 10^6)."""
+    import math
+    out = f"{HERE}/lik"
+    types = ["DEL", "INS", "INV", "BND"]
+    e = 5e-5
+    l_ok, l_err, l_half = math.log10(1 - e), math.log10(e), math.log10(0.5)
+    lg = np.array([math.lgamma(i + 1) for i in range(6002)]) / math.log(10)
+    a = np.arange(0, 3001, dtype=np.float64)
+    A, B = np.meshgrid(a, a, indexing="ij")
+    cases = []
+    for t in range(4):
+        c1, c2 = A.copy(), B.copy()
+        if t == 0:
+            c1 = np.where(A > 0, A / 2, A)
+        if t == 1:
+            c2 = np.where(B > 0, B / 2, B)
+        r1, r2 = np.rint(c1).astype(np.int64), np.rint(c2).astype(np.int64)          # (halves round to even, like round(c, 0))
+        comb = lg[r1 + r2] - lg[r1] - lg[r2]
+        near = np.zeros(A.shape, dtype=bool)
+        for lik in (c1 * l_ok + c2 * l_err, (c1 + c2) * l_half, c2 * l_ok + c1 * l_err):
+            v = -10 * (lik + comb)
+            near |= (np.abs(v - np.rint(v)) < 4e-7) & (comb != 0)
+        ii, jj = np.nonzero(near)
+        cases += [(t, int(x), int(y)) for x, y in zip(ii, jj)]
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        cases.append((int(rng.integers(4)), int(rng.integers(0, 100001)), int(rng.integers(0, 100001))))
+    for _ in range(40):
+        cases.append((int(rng.integers(4)), int(rng.integers(0, 1000001)), int(rng.integers(0, 1000001))))
+    gtc = {"0/0": 0, "0/1": 1, "1/1": 2, "./.": 3}
+    rows = []
+    for t, x, y in cases:
+        gt, pl = ref_geno.likelihood([x, y], types[t], 3, e)
+        rows.append((t, x, y, 3, gtc[gt], int(pl[0]), int(pl[1]), int(pl[2])))
+    np.savez_compressed(f"{out}/lik_boundary.npz", cases=np.array(rows, dtype=np.int64), err=np.full(len(rows), e))
+    print(f"lik_boundary: {len(rows)} known answers ({len(rows) - 240} next to an integer boundary)")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -800,7 +908,7 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "lik", "vcf", "synth", "realshape", "utf8order"]
+    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order"]
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))

@@ -7,7 +7,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "_hostsim.so")
-EXC = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError}
+class HostLine(Exception):
+    """the exact routine's "the host decides" (svjg.h: SVJG_EXC_ASK_HOST): a decimal column with non-ASCII bytes"""
+
+
+EXC = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError, 5: HostLine}
 
 
 def build():

@@ -30,7 +30,9 @@ def _want(c):
 
 
 def documented_divergence(c):
-    """decimal columns written with non-ASCII Unicode digits (int() takes them) are a ValueError here."""
+    """decimal columns written with non-ASCII Unicode digits (int() takes them): the C oracle (test infrastructure) reads ASCII
+    only; the device routine sets such a line aside for the host (tests/hostsim: HostLine), whose part is
+    svjg/filter.py: resolve_host_lines (tests/test_oracle_golden.py::test_py_filter_unicode_digits, tests/test_gpu_parity.py)"""
     return b"\xd9\xa3" in c["raw"]
 
 
@@ -50,8 +52,20 @@ def test_c_oracle_and_exact_device_routine(fuzz):
     cases, edges, alt, g = fuzz
     orc = OC.COracle(edges, alt)
     for i, c in enumerate(cases):
-        if (c["rc"] and c["error"] == "UnicodeDecodeError") or documented_divergence(c):
+        if c["rc"] and c["error"] == "UnicodeDecodeError":
             continue                                            # raised by the text-mode read, in front of the per-line code
+        if documented_divergence(c):
+            # the device routine neither counts nor condemns the line: it asks the host (or meets another line's error first)
+            for tables, wave in ((True, 0), (True, 1), (True, 2)):
+                try:
+                    sim.classify(g, c["raw"], tables, wave)
+                    got = "ok"
+                except sim.HostLine:
+                    got = "host"
+                except Exception as e:
+                    got = type(e).__name__
+                assert got == "host" or (c["rc"] and got == c["error"]), ("slow_line", wave, i, c["raw"], got)
+            continue
         try:
             cnt, _, _ = orc.filter(c["raw"], want_hits=False)
             got = ("ok", {sv: [int(cnt[j, 0]), int(cnt[j, 1])] for j, sv in enumerate(orc.sv_ids) if cnt[j].sum()})

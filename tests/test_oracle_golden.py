@@ -35,6 +35,36 @@ def test_py_filter_quirks(golden, name):
         assert type(ei.value).__name__ == man["error"]
 
 
+UNICODE = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "unicode")) if f.endswith(".gaf"))
+
+
+@pytest.mark.parametrize("name", UNICODE)
+def test_py_filter_unicode_digits(golden, name):
+    """golden/unicode: decimal columns written with non-ASCII digits and blanks (int(), float(), str.rstrip() take them).  The
+    Python oracle does what the reference did; so does the product's host-side decision for such lines (svjg/filter.py: host_line):
+    it raises the reference's exception, or rewrites the line into an ASCII spelling that classifies the same."""
+    from svjg import filter as flt
+    q, u = f"{golden}/quirks", f"{golden}/unicode"
+    man = json.load(open(f"{u}/manifest.json"))[name]
+    edges = O.load_edges(f"{q}/q_svs_edges.json")
+    alt = O.load_alt_node_len(f"{q}/q.gfa")
+    lines = _read_lines(f"{u}/{name}.gaf")
+    if man["rc"] == 0:
+        D = O.classify(lines, edges, alt)
+        assert O.dump_informative(D) == open(f"{u}/{name}.ref.json").read()
+        ascii_lines = [flt.host_line(x).decode("ascii") for x in lines]
+        D2 = O.classify(ascii_lines, edges, alt)
+        assert {k: [len(v[0]), len(v[1])] for k, v in D2.items()} == {k: [len(v[0]), len(v[1])] for k, v in D.items()}
+    else:
+        with pytest.raises(Exception) as ei:
+            O.classify(lines, edges, alt)
+        assert type(ei.value).__name__ == man["error"]
+        with pytest.raises(Exception) as ei:
+            for x in lines:
+                flt.host_line(x)
+        assert type(ei.value).__name__ == man["error"]
+
+
 def test_py_testdir_end_to_end(golden):
     t = f"{golden}/testdir"
     edges = O.load_edges(f"{t}/test_svs_edges.json")

@@ -139,3 +139,17 @@ def test_irregular_files_are_left_to_python(tmp_path):
         assert isinstance(G.open_rows(p, ["1:DEL-100-400"]), G.VcfRows)
     finally:
         del os.environ["SVJG_PY_VCF"]
+
+
+def test_exact_pl_is_the_reference_arithmetic(golden):
+    """svjg.genotype.exact_pl (what recomputes the rows the kernel flags as lying next to a PL's integer boundary) on the
+    reference's known answers: the near-boundary and deep-sample cases of lik_boundary.npz and a slice of the main table."""
+    import numpy as np
+    from svjg import genotype
+    for name, step in (("lik_boundary.npz", 1), ("lik_kat.npz", 37)):
+        z = np.load(f"{golden}/lik/{name}")
+        cases, errs = z["cases"][::step], z["err"][::step]
+        for c, e in zip(cases.tolist(), errs.tolist()):
+            if c[1] + c[2] > 20000:
+                continue                                           # (seconds each in math.comb; the GPU test covers them)
+            assert genotype.exact_pl(c[0], c[1], c[2], e) == c[5:8], c
