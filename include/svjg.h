@@ -126,6 +126,9 @@ const char *svjg_last_error(const svjg_ctx *ctx);          /* ctx may be NULL: e
 
 /* ---- graph (filter-alignments.py:95-113) ---------------------------------------------------------- */
 int svjg_load_graph(svjg_ctx *ctx, const svjg_graph *g);
+/* The lookup tables the kernels use are derived from `g` on the host (seconds for a graph of 500 k SVs) and kept for the next
+ * svjg_load_graph of the same graph in this process (one context per GPU: they are built once); this drops the kept copy. */
+void svjg_release_host_tables(void);
 
 /* ---- alignments (filter-alignments.py:123-166) ----------------------------------------------------
  * svjg_gaf_upload copies a GAF byte buffer to HBM (the PCIe leg); svjg_classify_resident runs the kernels
@@ -143,6 +146,13 @@ int svjg_classify_file(svjg_ctx *ctx, const char *path, uint64_t offset, uint64_
 int svjg_reset_counts(svjg_ctx *ctx);
 int svjg_get_stats(svjg_ctx *ctx, svjg_stats *out);
 int svjg_input_error(svjg_ctx *ctx, int *exc_class, uint64_t *line_offset);
+/* Why lines took the exact string path since the last svjg_reset_counts (their sum is svjg_stats.n_deferred):
+ * out[0] columns that are not twelve plain ones (blanks, signs, too few, Alen = 0, ...), [1] a 64-byte span of the line holds the
+ * byte pair "d:" (an id:f: tag, filter-alignments.py:193-196, or a false alarm), [2] a path of more than 64 nodes, [3] a node name
+ * the kernel's name table does not hold (not in the graph, a substring of another name, longer than 48 bytes, alt node without a
+ * length), [4] whole stripes of 8 KB (more than 64 lines or 216 orientation marks, a line longer than 8 KB, SVJG_GRAPH_ALL_SLOW),
+ * [5..7] reserved (0). */
+int svjg_get_defer_causes(svjg_ctx *ctx, uint64_t *out8);
 
 /* counts: out[slot*2 + 0] = ref, out[slot*2 + 1] = alt  (= len() of the two lists of
  * dict_of_informative_aln[sv_id], filter-alignments.py:163-166) */

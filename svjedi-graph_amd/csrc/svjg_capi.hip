@@ -18,6 +18,46 @@ using namespace svjg;
 
 static thread_local std::string g_init_error;
 
+// The main kernel's tables (perfect hash of the node names, link table) are built on the host from the graph: 0.25 s at 100 k SVs,
+// 2.5 s at 500 k.  A process that gives several contexts the same graph (one per GPU: filter-alignments.py, bench.py --gpus N)
+// builds them once: the most recent build is kept, keyed by the graph's arrays (addresses, sizes and a checksum of their
+// contents); the contexts' loads may come from several threads at once (the first builds, the others wait for it).
+#include <memory>
+#include <mutex>
+namespace {
+struct TablesCache {
+    std::mutex mu;
+    uint64_t key[6] = {0, 0, 0, 0, 0, 0};
+    std::shared_ptr<const KernelTables> kt;
+} g_tables;
+
+uint64_t fold64(const void *p, size_t n, uint64_t h) {
+    const uint64_t *w = (const uint64_t *)p;
+    for (size_t i = 0; i < n / 8; ++i) { h = (h ^ w[i]) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    return h;
+}
+
+std::shared_ptr<const KernelTables> kernel_tables_for(const svjg_graph &g) {
+    uint64_t key[6] = {(uint64_t)(uintptr_t)g.nodes, g.n_nodes, (uint64_t)(uintptr_t)g.edges, g.n_edges, g.n_hits, 0};
+    key[5] = fold64(g.nodes, (size_t)(g.n_nodes + 1) * sizeof(svjg_node), 1);
+    key[5] = fold64(g.edges, (size_t)g.n_edges * sizeof(svjg_edge), key[5]);
+    key[5] = fold64(g.hits, (size_t)g.n_hits * sizeof(uint32_t), key[5]);
+    key[5] = fold64(g.chrom_off, (size_t)(g.n_chrom + 1) / 2 * 8, key[5] ^ g.n_chrom);
+    std::lock_guard<std::mutex> lk(g_tables.mu);              // (held while building: a second loader of the same graph waits, then reuses)
+    if (!g_tables.kt || memcmp(key, g_tables.key, sizeof key) != 0) {
+        g_tables.kt = std::make_shared<const KernelTables>(build_kernel_tables(g));
+        memcpy(g_tables.key, key, sizeof key);
+    }
+    return g_tables.kt;
+}
+}  // namespace
+
+extern "C" void svjg_release_host_tables(void) {
+    std::lock_guard<std::mutex> lk(g_tables.mu);
+    g_tables.kt.reset();
+    memset(g_tables.key, 0, sizeof g_tables.key);
+}
+
 // ingest geometry: a file range goes to HBM through pinned buffers filled by STAGE_THREADS host threads (page cache ->
 // pinned piece by pread -> asynchronous copy on the thread's stream; the next piece is read while the previous one is on
 // the bus)
@@ -193,7 +233,8 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     if ((rc = upload(c, &c->d_clo, g->chrom_node_lo, g->n_chrom + 1))) return rc;
     std::vector<uint32_t> hash = build_chrom_hash(*g);
     if ((rc = upload(c, &c->d_chash, hash.data(), hash.size()))) return rc;
-    KernelTables kt = build_kernel_tables(*g);
+    const std::shared_ptr<const KernelTables> ktp = kernel_tables_for(*g);   // (built once per graph and process)
+    const KernelTables &kt = *ktp;
     if ((rc = upload(c, &c->d_names, kt.names.data(), kt.names.size()))) return rc;
     if ((rc = upload(c, &c->d_links, kt.links.data(), kt.links.size()))) return rc;
     if ((rc = upload(c, &c->d_disp, kt.disp.data(), kt.disp.size()))) return rc;
@@ -562,6 +603,12 @@ extern "C" int svjg_classify_file(svjg_ctx *c, const char *path, uint64_t offset
 extern "C" int svjg_get_stats(svjg_ctx *c, svjg_stats *out) {
     if (!c || !out) return SVJG_E_ARG;
     out->n_lines = c->hs().n_lines; out->n_deferred = c->total_deferred; out->n_hitrecs = c->hs().n_recs; out->non_ascii = c->hs().non_ascii;
+    return 0;
+}
+
+extern "C" int svjg_get_defer_causes(svjg_ctx *c, uint64_t *out8) {
+    if (!c || !out8) return SVJG_E_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = c->hs().cause[i];
     return 0;
 }
 

@@ -45,15 +45,16 @@ namespace svjg {
 // The kernel is bound by how many 64-byte lines it pulls from beyond the L2 (random lines of a table of tens of MB come
 // at ~66 G lines/s on MI355X, tools/ubench/randread.hip), so the tables are built for ONE line per path node:
 // NODE RECORDS: perfect hash (hash and displace, svjg_line.h: name_prehash / name_bucket / name_slot) of the canonical
-// node names (<= 32 bytes).  The kernel hashes the raw bytes of a path segment, reads the bucket's 2-byte displacement
+// node names (<= 48 bytes).  The kernel hashes the raw bytes of a path segment, reads the bucket's 2-byte displacement
 // (a small array that stays cached), fetches the one record the name can be in and compares the spelling: no number
 // parsing on the device, and only names spelled exactly like the graph's can match (anything else: exact path).
 //   record = 16 words (one 64-byte line):
-//     [0..5] name bytes 0..23   [6] node id << 7 | flags << 5 | (byte length - 1)   (flags: bit 0 hazard-prone name,
+//     [0..5] name bytes 0..23   [6] node id << 8 | flags << 6 | (byte length - 1)   (flags: bit 0 hazard-prone name,
 //     bit 1 length unknown; all ones = empty slot)   [7] node length in bp | REC_ROW_INLINE if the node has no other links
 //     than the inline ones
-//     names of up to 24 bytes: [8..15] = four inline links;  longer names: [8..9] = name bytes 24..31, [10..15] = three
-//     inline links.  An inline link = two words: key = right id << 2 | left strand | right strand << 1 (all ones = none),
+//     names of up to 24 bytes: [8..15] = four inline links;  25..32 bytes: [8..9] = name bytes 24..31, [10..15] = three
+//     inline links;  33..48 bytes (contig names like chr1_KI270706v1_random): [8..13] = name bytes 24..47, [14..15] = one
+//     inline link.  An inline link = two words: key = right id << 2 | left strand | right strand << 1 (all ones = none),
 //     value = the hit (slot << 1 | allele) of a one-hit link, or REC_MANY | index into the inline hit list
 //     (ihits[index] = number of hits, then the hits).  Reference-allele links come first.  Nearly every path step is
 //     answered from the record that the node lookup fetched anyway and never touches the link table.
@@ -66,14 +67,19 @@ namespace svjg {
 //   key = left << 33 | left strand << 32 | right << 1 | right strand ; all ones = empty slot.
 constexpr uint32_t NAME_ENT_WORDS = 16, LINK_ENT_WORDS = 4;
 constexpr uint32_t LINK_NO_HIT = 0xFFFFFFFFu, LINK_MANY = 0x80000000u;
-constexpr uint32_t NAME_EMPTY = 0xFFFFFFFFu, NAME_MAX_ID = (1u << 25) - 2u;
+constexpr uint32_t NAME_EMPTY = 0xFFFFFFFFu, NAME_MAX_ID = (1u << 24) - 2u;
 constexpr uint32_t REC_ROW_INLINE = 0x80000000u, REC_NO_LINK = 0xFFFFFFFFu, REC_MANY = 0x80000000u;
 inline bool name_ent_empty(const uint32_t *e) { return e[6] == NAME_EMPTY; }
-inline uint32_t name_ent_len(const uint32_t *e) { return (e[6] & 31u) + 1u; }
-inline uint32_t name_ent_id(const uint32_t *e) { return e[6] >> 7; }
-inline void name_ent_words(const uint32_t *e, uint32_t d[8]) { for (int w = 0; w < 6; ++w) d[w] = e[w]; const bool lg = name_ent_len(e) > 24u; d[6] = lg ? e[8] : 0u; d[7] = lg ? e[9] : 0u; }
-inline bool nm_len_gt24(uint32_t meta) { return (meta & 31u) + 1u > 24u; }
-inline uint32_t rec_first_link(const uint32_t *e) { return name_ent_len(e) > 24u ? 10u : 8u; }   // word of the first inline link
+inline uint32_t name_ent_len(const uint32_t *e) { return (e[6] & NAME_LEN_MASK) + 1u; }
+inline uint32_t name_ent_id(const uint32_t *e) { return e[6] >> NAME_ID_SHIFT; }
+inline void name_ent_words(const uint32_t *e, uint32_t d[NAME_WORDS]) {
+    for (int w = 0; w < 6; ++w) d[w] = e[w];
+    const uint32_t n = name_ent_len(e);
+    d[6] = n > 24u ? e[8] : 0u; d[7] = n > 24u ? e[9] : 0u;
+    for (int w = 0; w < 4; ++w) d[8 + w] = n > 32u ? e[10 + w] : 0u;
+}
+inline uint32_t nm_first_link(uint32_t meta) { const uint32_t n = (meta & NAME_LEN_MASK) + 1u; return n > 32u ? 14u : n > 24u ? 10u : 8u; }   // word of the first inline link
+inline uint32_t rec_first_link(const uint32_t *e) { return nm_first_link(e[6]); }
 
 struct KernelTables {
     std::vector<uint32_t> names; uint32_t name_slots = 0, name_buckets = 0;
@@ -172,7 +178,8 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
     std::vector<uint8_t> node_has((size_t)g.n_nodes, 0);
     std::vector<uint32_t> node_slot((size_t)g.n_nodes, 0);
     {
-        std::vector<uint32_t> ent;                            // 10 words per key: d[0..7], meta, len_bp
+        std::vector<uint32_t> ent;                            // NAME_WORDS + 2 words per key: d[0..11], meta, len_bp
+        constexpr size_t EW = NAME_WORDS + 2;
         std::vector<uint64_t> hs;
         std::vector<uint32_t> key_node;
         for (uint64_t i = 0; i < g.n_nodes; ++i) {
@@ -180,14 +187,14 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             uint32_t c = (uint32_t)(nd.key >> 48), pos = (uint32_t)(nd.key >> 16), kind = (uint32_t)(nd.key >> 15) & 1u, cnt = (uint32_t)nd.key & 0x7FFFu;
             std::string nm(g.chrom_names + g.chrom_off[c], g.chrom_off[c + 1] - g.chrom_off[c]);
             nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
-            if (nm.size() > 32 || i > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path
-            uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (nm.size() > 4 * NAME_WORDS || i > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path
+            uint32_t d[NAME_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (size_t b = 0; b < nm.size(); ++b) d[b >> 2] |= (uint32_t)(uint8_t)nm[b] << (8 * (b & 3));
             uint32_t flags = ((nd.row & 0x80000000u) ? 1u : 0u) | ((kind && nd.aux == SVJG_LEN_UNKNOWN) ? 2u : 0u);
             uint32_t len_bp = kind ? nd.aux : nd.aux - pos + 1;
             if (len_bp & REC_ROW_INLINE) flags |= 2u;         // (no node is 2 Gbp long; keeps the flag bit free)
-            for (int w = 0; w < 8; ++w) ent.push_back(d[w]);
-            ent.push_back(((uint32_t)i << 7) | (flags << 5) | ((uint32_t)nm.size() - 1u));
+            for (uint32_t w = 0; w < NAME_WORDS; ++w) ent.push_back(d[w]);
+            ent.push_back(((uint32_t)i << NAME_ID_SHIFT) | (flags << NAME_LEN_BITS) | ((uint32_t)nm.size() - 1u));
             ent.push_back(len_bp & ~REC_ROW_INLINE);
             hs.push_back(name_prehash(d, (uint32_t)nm.size()));
             key_node.push_back((uint32_t)i);
@@ -202,10 +209,10 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             size_t w = 0;
             for (size_t i = 0; i < hs.size(); ++i) {
                 if (drop[i]) { ++kt.names_left_out; continue; }
-                if (w != i) { hs[w] = hs[i]; key_node[w] = key_node[i]; for (int q = 0; q < 10; ++q) ent[w * 10 + q] = ent[i * 10 + q]; }
+                if (w != i) { hs[w] = hs[i]; key_node[w] = key_node[i]; for (size_t q = 0; q < EW; ++q) ent[w * EW + q] = ent[i * EW + q]; }
                 ++w;
             }
-            hs.resize(w); key_node.resize(w); ent.resize(w * 10);
+            hs.resize(w); key_node.resize(w); ent.resize(w * EW);
         }
         lap("name words and pre-hashes");
         const uint64_t n = hs.size();
@@ -225,11 +232,13 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             e[6] = NAME_EMPTY; e[8] = e[10] = e[12] = e[14] = REC_NO_LINK;
         }
         for (uint64_t k = 0; k < hs.size(); ++k) {
-            const uint32_t *src = &ent[(size_t)k * 10];
+            const uint32_t *src = &ent[(size_t)k * EW];
             uint32_t *e = &kt.names[(size_t)slot_of[k] * NAME_ENT_WORDS];
             for (int w = 0; w < 6; ++w) e[w] = src[w];
-            e[6] = src[8]; e[7] = src[9];
-            if (nm_len_gt24(src[8])) { e[8] = src[6]; e[9] = src[7]; }
+            e[6] = src[NAME_WORDS]; e[7] = src[NAME_WORDS + 1];
+            const uint32_t w0 = nm_first_link(src[NAME_WORDS]);
+            if (w0 >= 10u) { e[8] = src[6]; e[9] = src[7]; }
+            if (w0 >= 14u) { e[10] = src[8]; e[11] = src[9]; e[12] = src[10]; e[13] = src[11]; }
             const uint32_t node = key_node[k];
             node_pre[node] = hs[k]; node_has[node] = 1; node_slot[node] = slot_of[k];
             // inline links: up to two rows of the node, those whose hits are all reference-allele first
@@ -246,7 +255,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
                 }
             uint32_t n_live = 0;
             for (uint32_t i = a; i < b; ++i) n_live += (g.edges[i].meta >> 2) != 0;
-            const uint32_t w0 = nm_len_gt24(src[8]) ? 10u : 8u, cap = (16u - w0) / 2u;
+            const uint32_t cap = (16u - w0) / 2u;
             for (uint32_t w = w0; w < 16; w += 2) e[w] = REC_NO_LINK, e[w + 1] = 0;
             for (size_t q = 0; q < rows.size() && q < cap; ++q) {
                 const svjg_edge &ed = g.edges[rows[q]];
@@ -297,7 +306,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             for (int w = 0; w < 4; ++w) kt.links[j * LINK_ENT_WORDS + w] = ent[(size_t)owner[j] * 4 + w];
         }
         kt.links_unplaced = n_unplaced;
-        for (uint32_t k : unplaced) kt.names[(size_t)node_slot[left_node[k]] * NAME_ENT_WORDS + 6] |= 1u << 5;
+        for (uint32_t k : unplaced) kt.names[(size_t)node_slot[left_node[k]] * NAME_ENT_WORDS + 6] |= NAME_FLAG_HAZARD;
     }
     lap("link table placement");
     kt.node_pre.swap(node_pre); kt.node_has.swap(node_has); kt.node_slot.swap(node_slot);

@@ -62,6 +62,7 @@ struct DevStatus {
     unsigned int overflow;               // bit 0: deferred list, bit 1: hit-record buffer, bit 2: list of lines for the host
     unsigned long long next_chunk;       // k_classify_main: small chunks handed out so far (zero at launch)
     unsigned long long n_host;           // lines set aside for the host (SVJG_EXC_ASK_HOST)
+    unsigned long long cause[8];         // deferred lines by cause (DC_*)
 };
 
 struct ClassifyArgs {
@@ -133,11 +134,17 @@ __device__ inline uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
     return x - v;
 }
 
-enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round
+enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per-line status inside a round; ST_DEFER + cause: why the line takes the exact path
+enum : uint32_t { DC_COLUMNS = 0,      // the line's columns are not twelve plain ones (blanks, signs, too few, Alen = 0, marks outside the path column, ...)
+                  DC_IDF = 1,          // a 64-byte span of the line holds the pair "d:" (an id:f: tag, or a false alarm)
+                  DC_LONG_PATH = 2,    // more than KMAX path nodes
+                  DC_NAME = 3,         // a node name the name table does not hold (unknown, hazard-prone, longer than 48 bytes, alt length unknown)
+                  DC_STRIPE = 4,       // the whole stripe: denser than the lists hold, a line longer than the staged text, or the caller asked for the exact path
+                  DC_N = 5 };
 
-// Path segment text[a0, a0+L), 1 <= L <= 32: its eight zero-padded words -> d, and the 64-bit pre-hash of the node-name table
-// (svjg_line.h: name_prehash), in two parts: words 0..5 (enough for names of up to 24 bytes; d[6] = d[7] = 0) and, for
-// longer names, words 6 and 7 and what they add to the hash.
+// Path segment text[a0, a0+L), 1 <= L <= 48: its twelve zero-padded words -> d, and the 64-bit pre-hash of the node-name table
+// (svjg_line.h: name_prehash), in three parts: words 0..5 (enough for names of up to 24 bytes; d[6..11] = 0), words 6 and 7
+// (names of 25..32 bytes) and words 8..11 (33..48 bytes: contig names like chr1_KI270706v1_random), each with what it adds to the hash.
 // words in front of word L / 4 are name bytes only, that word keeps its first L % 4 bytes, the ones behind it are zero
 // the low min(max(bits, 0), 32) bits set (bits = name bits left from this word on): high half of 0x00000000FFFFFFFF << that
 __device__ inline uint32_t name_word_mask(int32_t bits) {
@@ -145,11 +152,12 @@ __device__ inline uint32_t name_word_mask(int32_t bits) {
     return (uint32_t)((0xFFFFFFFFull << n) >> 32);
 }
 typedef uint32_t u32_any __attribute__((aligned(1)));                   // LDS words at any byte address (gfx950 reads them as they are: tools/ubench/lds_unaligned.hip)
-__device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
+__device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[NAME_WORDS]) {
     const u32_any *w = (const u32_any *)(text + a0);
     uint64_t h = (uint64_t)L * 0x7FEB352Du;
     const uint32_t C[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du};
-    d[6] = 0u; d[7] = 0u;
+#pragma unroll
+    for (uint32_t i = 6; i < NAME_WORDS; ++i) d[i] = 0u;
     const int32_t bits = (int32_t)(8u * L);
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
@@ -158,7 +166,7 @@ __device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uin
     }
     return h;
 }
-__device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
+__device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[NAME_WORDS]) {
     const u32_any *w = (const u32_any *)(text + a0);
     const int32_t bits = (int32_t)(8u * L);
     const uint32_t x6 = w[6], x7 = w[7];
@@ -166,12 +174,25 @@ __device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uin
     d[7] = x7 & name_word_mask(bits - 224);
     return (uint64_t)d[6] * 0xFD7046C5u + (uint64_t)d[7] * 0xB55A4F09u;
 }
+__device__ inline uint64_t name_words_tail2(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[NAME_WORDS]) {
+    const u32_any *w = (const u32_any *)(text + a0);
+    const int32_t bits = (int32_t)(8u * L);
+    const uint32_t C[4] = {0x94D049BBu, 0xBF58476Du, 0x2545F491u, 0x9FB21C65u};
+    uint64_t h = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        d[8 + i] = w[8 + i] & name_word_mask(bits - 32 * (int32_t)(8 + i));
+        h += (uint64_t)d[8 + i] * C[i];
+    }
+    return h;
+}
 
 // record of the node-name table (svjg_host_tables.h): r0 = name bytes 0..15, r1 = bytes 16..23 | meta | length in bp,
-// r2.xy = bytes 24..31 (only names longer than 24 bytes look at them)
-__device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[8], uint32_t L) {
+// r2.xy = bytes 24..31 (only names longer than 24 bytes look at them); bytes 32..47 (r2.zw, r3.xy) are compared by the caller in
+// the branch only a pass with such a name takes
+__device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[NAME_WORDS], uint32_t L) {
     // one OR of differences instead of a chain of compares (three-input bit operations: (a ^ b) | c is one instruction)
-    uint32_t diff = ((r1.z & 31u) ^ (L - 1u)) | (r0.x ^ d[0]) | (r0.y ^ d[1]) | (r0.z ^ d[2]) | (r0.w ^ d[3]) | (r1.x ^ d[4]) | (r1.y ^ d[5]);
+    uint32_t diff = ((r1.z & NAME_LEN_MASK) ^ (L - 1u)) | (r0.x ^ d[0]) | (r0.y ^ d[1]) | (r0.z ^ d[2]) | (r0.w ^ d[3]) | (r1.x ^ d[4]) | (r1.y ^ d[5]);
     const uint32_t tail = (r2.x ^ d[6]) | (r2.y ^ d[7]);
     diff |= L > 24u ? tail : 0u;
     return diff == 0u;
@@ -428,7 +449,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         unsigned long long NL[NHALF], ORI[NHALF];
         SpanFlags fl = {0u, 0u, 0u};
         uint32_t dee_end = 0;                                            // wave-uniform: the first half ends with 'd'
-        bool idf_x = false;                                              // ... and the second half begins with ':'
+        unsigned long long IDM[NHALF];                                   // wave-uniform: lanes whose span of this half holds the 'd' of a pair "d:"
 #pragma unroll
         for (uint32_t h = 0; h < NHALF; ++h) {
             __builtin_amdgcn_s_setprio(P_A);
@@ -437,12 +458,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             if (h + 1 < NHALF) fetch_half(c0 + (h + 1) * HALF);           // the next half travels while this one is classified
             wave_sync();
             __builtin_amdgcn_s_setprio(0);
+            fl.idf = 0u;
             classify_span(a, text, ndbm, tbm, h * WG + lane, c0, V, NL[h], ORI[h], fl);
+            IDM[h] = ballot64(fl.idf != 0);
             if (h == 0) dee_end = rdlane(fl.dee_last, WG - 1);
-            else idf_x = dee_end != 0 && text[HALF] == ':';
+            else if (dee_end != 0 && text[HALF] == ':') IDM[0] |= 1ull << 63;   // (the pair straddles the halves: its 'd' is the first half's last byte)
         }
         if (ballot64(fl.high != 0) != 0 && lane == 0) a.st->non_ascii = 1;
-        const bool idf = idf_x || ballot64(fl.idf != 0) != 0;
+        const bool idf = (IDM[0] | IDM[1]) != 0;                         // some line of the stripe may hold an "id:f:" tag: the line phase finds which
         tick(0);
         // does the stripe begin at a line start?  (wave-uniform)
         const uint32_t head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
@@ -540,11 +563,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         }
         tick(1);
 
-        if (a.all_slow || idf || long_line || n_s > MAXL || tot_ori > CAP_O) {
-            // the lists cannot hold this stripe / "id:f:" somewhere in it / the caller wants the exact path: every owned line is deferred as it is
+        if (a.all_slow || long_line || n_s > MAXL || tot_ori > CAP_O) {
+            // the lists cannot hold this stripe / the caller wants the exact path: every owned line is deferred as it is
             if (n_own) {
                 unsigned long long dbase = 0;
-                if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)n_own);
+                if (lane == 0) { dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)n_own); atomicAdd(&a.st->cause[DC_STRIPE], (unsigned long long)n_own); }
                 dbase = __shfl(dbase, 0);
                 if (lane == 0 && head_own) { if (dbase < a.deferred_cap) a.deferred[dbase] = c0; else atomicOr(&a.st->overflow, 1u); }   // (ordinal 0 = l_first)
 #pragma unroll
@@ -628,13 +651,16 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t t1 = take_tab(wa, t0 + 1), t2 = take_tab(wa, t0 + 1), t3 = take_tab(wa, t0 + 1);
                     const uint32_t t4a = take_tab(wa, t0 + 1);
                     const uint32_t t4 = t4a < TEXT ? (t4a < e ? t4a : TEXT) : tab_from(tbm, t0 + 33 < TEXT ? t0 + 33 : TEXT, e);   // (nothing in the window: look further)
-                    // The path column ends at the first tab behind the line's LAST orientation mark (a node name has at most 32 bytes).  Should a tab sit in front of that mark (marks in later columns), the piece of text
+                    // The path column ends at the first tab behind the line's LAST orientation mark (a node name has at most 48 bytes).  Should a tab sit in front of that mark (marks in later columns), the piece of text
                     // between two marks that holds it is no node name, and the node pass sends the line to the exact path.
                     k = kall;
                     const bool kfit = k >= 1 && k <= KMAX;
                     const uint32_t m_first = OPL[o0] & 0xFFFFu, m_last = OPL[kfit ? o0 + k - 1 : o0] & 0xFFFFu;
                     uint32_t t5 = tab_near(tbm, m_last + 1);
-                    if (t5 == TEXT && (tab_window(tbm, m_last + 33 < TEXT ? m_last + 33 : TEXT) & 1u)) t5 = m_last + 33;   // (a 32-byte name)
+                    if (t5 == TEXT) {                                     // (a name of 32..48 bytes: the tab is at most 49 bytes behind the mark)
+                        const uint32_t far = tab_near(tbm, m_last + 33 < TEXT ? m_last + 33 : TEXT);
+                        t5 = far <= m_last + 49u ? far : TEXT;
+                    }
                     uint32_t wb = tab_window(tbm, t5 + 1);              // columns 7..9
                     const uint32_t t6 = take_tab(wb, t5 + 1), t7 = take_tab(wb, t5 + 1), t8 = take_tab(wb, t5 + 1);
                     uint32_t wc = tab_window(tbm, t8 + 1);              // columns 10..12
@@ -658,6 +684,16 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // (columns of at most nine digits and d_over < 2^31, svjg_load_graph: everything fits 32 bits)
                     const uint32_t tlen = field_val(text, u5 + 1, u6 - u5 - 1), ts = field_val(text, u6 + 1, u7 - u6 - 1), te = field_val(text, u7 + 1, u8 - u7 - 1);
                     ok = ok && digits && !alen0 && kfit && u5 > u4 + 1 && m_first == u4 + 1 && m_last < u5;
+                    if (idf) {
+                        // "id:f:" anywhere in a line changes what the reference does with it (:193-196): a line one of whose 64-byte spans
+                        // holds the pair "d:" takes the exact path (spans [s >> 6, (next line start - 1) >> 6] of the 128 of the stripe)
+                        const uint32_t sa = s >> 6, sb = ((nx != 0xFFFFu ? nx : Vh) - 1u) >> 6;
+                        const unsigned long long m0 = low_bits64(sb + 1u < 64u ? sb + 1u : 64u) & ~low_bits64(sa < 64u ? sa : 64u);
+                        const unsigned long long m1 = low_bits64(sb >= 64u ? sb - 63u : 0u) & ~low_bits64(sa > 64u ? sa - 64u : 0u);
+                        if (((IDM[0] & m0) | (IDM[1] & m1)) != 0ull) { ok = false; status = ST_DEFER + DC_IDF; }
+                    }
+                    if (!ok && status == ST_DEFER && kall > KMAX) status = ST_DEFER + DC_LONG_PATH;
+                    else if (!ok && status == ST_DEFER && t5 == TEXT && t4 < TEXT && kfit) status = ST_DEFER + DC_NAME;   // (no tab within 49 bytes of the last mark: a name beyond 48 bytes)
                     if (ok) {
                         status = k >= 2 ? ST_OK : ST_NOHIT;
                         r_need_l = ts + g.d_over;
@@ -696,11 +732,13 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t na0 = opv + 1u;
                 const uint32_t len = ((j + 1 < lk) ? (op2.y & 0xFFFFu) : rl.w) - na0;
                 const uint32_t oribit = text[opv] == '<' ? 1u : 0u;
-                const bool probe = live && len - 1u <= 31u;              // names of 1..32 bytes; longer ones: exact path
-                uint32_t d[8];
+                const bool probe = live && len - 1u <= 4u * NAME_WORDS - 1u;   // names of 1..48 bytes; longer ones: exact path
+                uint32_t d[NAME_WORDS];
                 tick_mem(8);                                             // (list and per-line record read)
                 uint64_t h = name_words_head(text, na0, len, d);         // the first six words of the name
                 if (ballot64(probe && len > 24u)) h += name_words_tail(text, na0, len, d);   // (wave-uniform: node names of the usual length fit six words)
+                const bool long_names = ballot64(probe && len > 32u) != 0;                   // (wave-uniform: some name of the pass has 33..48 bytes)
+                if (long_names) h += name_words_tail2(text, na0, len, d);
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
@@ -718,15 +756,17 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 __builtin_amdgcn_s_setprio(P_REST);
                 uint32_t id = NONE32, lbp = 0;
                 bool row_inline = false;
-                // id << 7 | flags << 5 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
-                if (probe && name_match(r0, r1, r2, d, len) && r1.z != 0xFFFFFFFFu && !(r1.z & 0x60u)) { id = r1.z >> 7; lbp = r1.w & 0x7FFFFFFFu; row_inline = (r1.w >> 31) != 0; }
+                // id << 8 | flags << 6 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
+                bool same = probe && name_match(r0, r1, r2, d, len);
+                if (long_names) same = same && (len <= 32u || ((r2.z ^ d[8]) | (r2.w ^ d[9]) | (r3.x ^ d[10]) | (r3.y ^ d[11])) == 0u);
+                if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = (r1.w >> 31) != 0; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
                 // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
                 // (all nodes of a line sit in this pass).  Ordinary text never gets here.
                 {
                     const bool bad = live && (id == NONE32 || lbp >= (1u << 25));
                     if (ballot64(bad)) {
-                        if (bad) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | (ST_DEFER << 24);
+                        if (bad) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | ((ST_DEFER + DC_NAME) << 24);
                         wave_sync();
                         if ((((const uint32_t *)&RL[ln])[2] >> 24) != ST_OK) live = false;
                     }
@@ -771,7 +811,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const bool go = live && j + 1 < lk && pre_l >= need_l && tot - (fr > lnb ? pre_rx : 0u) >= need_r;
                 const bool moved = revisits && (fl != lane || fr != lane + 1u);
                 const uint32_t want = (idr << 2) | orl | (orr << 1);
-                const bool m0 = len <= 24u && r2.x == want, m1 = r2.z == want, m2 = r3.x == want, m3 = r3.z == want;
+                const bool m0 = len <= 24u && r2.x == want, m1 = len <= 32u && r2.z == want, m2 = len <= 32u && r3.x == want, m3 = r3.z == want;   // (a longer name's bytes sit where the first links would)
                 const bool inl = m0 || m1 || m2 || m3;
                 const uint32_t v = m0 ? r2.y : m1 ? r2.w : m2 ? r3.y : r3.w;
                 const bool found = go && !moved && inl;
@@ -828,9 +868,15 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             wave_sync();
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {
-                const bool defer = lane < cnt && (RL[lane].z >> 24) == ST_DEFER;
+                const uint32_t fin = RL[lane].z >> 24;
+                const bool defer = lane < cnt && fin >= ST_DEFER;
                 unsigned long long db = ballot64(defer);
                 if (db) {
+#pragma unroll
+                    for (uint32_t cse = 0; cse < DC_STRIPE; ++cse) {
+                        const unsigned long long cb = ballot64(defer && fin == ST_DEFER + cse);
+                        if (cb && lane == 0) atomicAdd(&a.st->cause[cse], (unsigned long long)__popcll(cb));
+                    }
                     unsigned long long dbase = 0;
                     if (lane == 0) dbase = atomicAdd(&a.st->n_deferred, (unsigned long long)__popcll(db));
                     dbase = __shfl(dbase, 0);

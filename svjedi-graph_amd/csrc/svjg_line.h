@@ -47,15 +47,19 @@ struct GraphView {
 
 
 // ---- perfect hash of the node names (hash and displace; built by svjg_host_tables.h) -------------------------------
-// pre-hash = 64-bit multilinear sum of the name's eight zero-padded words and its length; bucket from the pre-hash,
+// pre-hash = 64-bit multilinear sum of the name's twelve zero-padded words and its length; bucket from the pre-hash,
 // slot from the pre-hash and the bucket's displacement: every name of the graph has a slot of its own, so a lookup
 // touches one 2-byte displacement (a small, cache-resident array) and exactly ONE 64-byte record.
 SVJG_HD uint32_t fmix32(uint32_t z) { z ^= z >> 16; z *= 0x7FEB352Du; z ^= z >> 15; z *= 0x846CA68Bu; z ^= z >> 16; return z; }
 SVJG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-SVJG_HD uint64_t name_prehash(const uint32_t d[8], uint32_t len) {
-    const uint32_t C[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+constexpr uint32_t NAME_WORDS = 12;                               // a node name of the main kernel: up to 48 bytes, zero padded
+constexpr uint32_t NAME_LEN_BITS = 6, NAME_LEN_MASK = 63u;        // record word 6 = id << 8 | flags << 6 | (byte length - 1)
+constexpr uint32_t NAME_FLAG_HAZARD = 1u << 6, NAME_FLAG_NOLEN = 1u << 7, NAME_ID_SHIFT = 8;
+SVJG_HD uint64_t name_prehash(const uint32_t d[NAME_WORDS], uint32_t len) {
+    const uint32_t C[NAME_WORDS] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u,
+                                    0x94D049BBu, 0xBF58476Du, 0x2545F491u, 0x9FB21C65u};
     uint64_t h = (uint64_t)len * 0x7FEB352Du;
-    for (int i = 0; i < 8; ++i) h += (uint64_t)d[i] * C[i];
+    for (uint32_t i = 0; i < NAME_WORDS; ++i) h += (uint64_t)d[i] * C[i];
     return h;
 }
 // The pre-hash is a multiply-and-add with 32-bit factors: its words are only lightly mixed (names that differ in a digit or
@@ -228,20 +232,21 @@ SVJG_HD bool next_node(P t, uint64_t pe, bool oriented, uint64_t &pos, NameRef &
     return false;
 }
 
-// Node-name table of the main kernel (svjg_host_tables.h), probed with the raw bytes of a name of 1..32 bytes:
+// Node-name table of the main kernel (svjg_host_tables.h), probed with the raw bytes of a name of 1..48 bytes:
 // node id, or NONE32 when the name's slot does not hold this spelling.
 template <class P>
 SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
     const uint32_t len = (uint32_t)(nm.e - nm.s);
-    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t d[NAME_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t b = 0; b < len; ++b) d[b >> 2] |= (uint32_t)(uint8_t)t[nm.s + b] << (8 * (b & 3));
     const uint64_t h = name_prehash(d, len);
     const uint32_t slot = name_slot(h, g.name_disp[name_bucket(h, g.name_buckets)], g.name_slots);
     const uint32_t *e = g.name_tab + (uint64_t)slot * 16;
     const uint32_t meta = e[6];
-    if (meta == 0xFFFFFFFFu || (meta & 31u) != len - 1u) return NONE32;
-    if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && (len <= 24u || (e[8] == d[6] && e[9] == d[7])))
-        return meta >> 7;
+    if (meta == 0xFFFFFFFFu || (meta & NAME_LEN_MASK) != len - 1u) return NONE32;
+    if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && (len <= 24u || (e[8] == d[6] && e[9] == d[7])) &&
+        (len <= 32u || (e[10] == d[8] && e[11] == d[9] && e[12] == d[10] && e[13] == d[11])))
+        return meta >> NAME_ID_SHIFT;
     return NONE32;
 }
 
@@ -255,7 +260,7 @@ SVJG_HD uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_
         for (uint64_t q = (colon == nm.e ? nm.s : colon + 1); q < nm.e; ++q) if (t[q] == '.') *is_alt_form = true;
     }
     if (colon == nm.e) return NONE32;
-    if (g.name_tab && nm.e - nm.s <= 32) {                             // the canonical spelling is the only one that resolves
+    if (g.name_tab && nm.e - nm.s <= 4 * NAME_WORDS) {                             // the canonical spelling is the only one that resolves
         uint32_t id = name_tab_find(g, t, nm);
         if (id != NONE32 || g.name_complete) return id;
     }

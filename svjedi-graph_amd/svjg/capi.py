@@ -51,6 +51,7 @@ _SIGS = {
     "svjg_destroy": (None, [ctypes.c_void_p]),
     "svjg_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "svjg_load_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CGraph)]),
+    "svjg_release_host_tables": (None, []),
     "svjg_gaf_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "svjg_classify_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
     "svjg_classify": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
@@ -58,6 +59,7 @@ _SIGS = {
     "svjg_classify_file": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
     "svjg_reset_counts": (ctypes.c_int, [ctypes.c_void_p]),
     "svjg_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CStats)]),
+    "svjg_get_defer_causes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "svjg_input_error": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
     "svjg_get_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
     "svjg_set_counts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]),
@@ -356,6 +358,12 @@ class Context:
         self._chk(self.lib.svjg_get_stats(self.h, ctypes.byref(s)))
         return {"n_lines": s.n_lines, "n_deferred": s.n_deferred, "n_hitrecs": s.n_hitrecs, "non_ascii": s.non_ascii}
 
+    def defer_causes(self):
+        """why lines took the exact path (svjg_get_defer_causes)"""
+        out = np.zeros(8, dtype=np.uint64)
+        self._chk(self.lib.svjg_get_defer_causes(self.h, out.ctypes.data))
+        return dict(zip(("columns", "id_tag_filter", "long_path", "node_name", "whole_stripe"), (int(x) for x in out[:5])))
+
     def counts(self):
         out = np.zeros((self.n_slots, 2), dtype=np.uint32)
         self._chk(self.lib.svjg_get_counts(self.h, out.ctypes.data, self.n_slots))
@@ -456,6 +464,11 @@ class Context:
 
     def sync(self):
         self._chk(self.lib.svjg_sync(self.h))
+
+
+def release_host_tables():
+    """drop the host copy of the kernels' lookup tables that load_graph keeps for the next context with the same graph"""
+    load_library().svjg_release_host_tables()
 
 
 def device_count():

@@ -307,6 +307,7 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
             remap = resolve_host_lines(ctxs, data, want_hits, err)       # (lines with non-ASCII digits: Python's int() decides)
         except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
             raise reference_error(data, e)
+        capi.release_host_tables()                 # (every context has the graph: the shared host copy of the kernels' tables can go)
         _stamp(t, f"tables -> device, upload + classify on {len(distinct)} GPU(s)")
         if any(c.stats()["non_ascii"] for c in ctxs):
             check_utf8(data)

@@ -90,7 +90,7 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
         const uint32_t *e = &kt.names[j * NAME_ENT_WORDS];
         if (name_ent_empty(e)) { if (e[8] != REC_NO_LINK || e[10] != REC_NO_LINK || e[12] != REC_NO_LINK || e[14] != REC_NO_LINK) ++bad; continue; }
         ++found;
-        uint32_t d[8];
+        uint32_t d[NAME_WORDS];
         name_ent_words(e, d);
         const uint64_t h = name_prehash(d, name_ent_len(e));
         if (j != name_slot(h, kt.disp[name_bucket(h, kt.name_buckets)], kt.name_slots)) ++bad;   // the kernel's one probe lands here
@@ -98,8 +98,8 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
         if (!kt.node_has[id] || kt.node_slot[id] != j || kt.node_pre[id] != h) ++bad;
         const svjg_node &nd = g->nodes[id];
         uint32_t kind = (uint32_t)(nd.key >> 15) & 1u, pos = (uint32_t)(nd.key >> 16);
-        if ((e[7] & ~REC_ROW_INLINE) != (kind ? nd.aux : nd.aux - pos + 1) && !(e[6] & 0x40u)) ++bad;
-        for (uint32_t b = name_ent_len(e); b < 32; ++b) if ((d[b >> 2] >> (8 * (b & 3))) & 0xFFu) ++bad;     // zero padded
+        if ((e[7] & ~REC_ROW_INLINE) != (kind ? nd.aux : nd.aux - pos + 1) && !(e[6] & NAME_FLAG_NOLEN)) ++bad;
+        for (uint32_t b = name_ent_len(e); b < 4 * NAME_WORDS; ++b) if ((d[b >> 2] >> (8 * (b & 3))) & 0xFFu) ++bad;     // zero padded
         // inline links = rows of this node, with the hits of the CSR row; REC_ROW_INLINE only if no row is missing
         const uint32_t ra = nd.row & 0x7FFFFFFFu, rb = g->nodes[id + 1].row & 0x7FFFFFFFu;
         uint32_t live = 0, inl = 0;
@@ -137,7 +137,7 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
             const uint32_t *e = &kt.links[(uint64_t)s1 * LINK_ENT_WORDS];
             if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) e = &kt.links[(uint64_t)s2 * LINK_ENT_WORDS];
             if (!(e[0] == (uint32_t)key && e[1] == (uint32_t)(key >> 32))) {
-                if (!(kt.names[(size_t)kt.node_slot[n] * NAME_ENT_WORDS + 6] & (1u << 5))) ++bad;        // unplaced link: its left node must be flagged for the exact path
+                if (!(kt.names[(size_t)kt.node_slot[n] * NAME_ENT_WORDS + 6] & NAME_FLAG_HAZARD)) ++bad;        // unplaced link: its left node must be flagged for the exact path
                 continue;
             }
             const uint32_t nh = ed.meta >> 2;

@@ -284,6 +284,20 @@ def walk_tables(g, seed):
             "ptr": ptr, "to": to, "sv": sv, "gt": gt}
 
 
+def save_tables(tab, prefix):
+    """the walk tables of generate() -> {prefix}_walk.npz (another process can then write lines of the same stream)"""
+    np.savez(prefix + "_walk.npz", blob=np.frombuffer(tab["blob"], dtype=np.uint8), n_ref=np.array([tab["n_ref"]]),
+             **{k: tab[k] for k in ("off", "len", "ptr", "to", "sv", "gt")})
+
+
+def load_tables(prefix):
+    z = np.load(prefix + "_walk.npz")
+    tab = {k: np.ascontiguousarray(z[k]) for k in ("off", "len", "ptr", "to", "sv", "gt")}
+    tab["blob"] = z["blob"].tobytes()
+    tab["n_ref"] = int(z["n_ref"][0])
+    return tab
+
+
 def gaf_bytes(tab, seed, first, n, threads=8):
     """GAF text for lines [first, first+n) as one numpy uint8 array."""
     lib = build_lib()
