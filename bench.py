@@ -38,10 +38,35 @@ WORKLOADS = {
 }
 
 
+def _passes(c, n, min_support, err, ms):
+    """n passes on one context, two in flight: pass k + 1 is enqueued before the results of pass k are waited for, so they cross
+    PCIe while the next pass computes (svjg_run_begin / svjg_run_end).  -> the last pass's results"""
+    out = None
+    if n <= 0:
+        return out
+    if os.environ.get("SVJG_BENCH_SYNC"):                      # measurement only: one pass at a time (no copy behind the next pass)
+        for _ in range(n):
+            out = c.run_resident(min_support, err)
+            if ms is not None:
+                ms.append(c.kernel_ms())
+        return out
+    c.run_begin(min_support, err)
+    for _ in range(n - 1):
+        c.run_begin(min_support, err)
+        out = c.run_end()
+        if ms is not None:
+            ms.append(c.kernel_ms())
+    out = c.run_end()
+    if ms is not None:
+        ms.append(c.kernel_ms())
+    return out
+
+
 def timed_steps(ctxs, steps, warmup, min_support=3, err=0.00005, outer_barrier=None):
     """`warmup` untimed and `steps` timed passes on every context of this process — one thread per context when there are
-    several: their all-reduce keeps them in step — between two barriers.  A pass = Context.run_resident(): zero counts, classify
-    the resident shard, all-reduce (if the context has a communicator), genotype the resident rows; one host wait per pass.
+    several: their all-reduce keeps them in step — between two barriers.  A pass = zero counts, classify the resident shard,
+    all-reduce (if the context has a communicator), genotype the resident rows, results to the host; one host wait per pass,
+    and the results of a pass travel while the next one computes (_passes).
     -> (seconds for the timed passes, per context [(main, exact, genotype) kernel ms per pass], the last pass's outputs of context 0)"""
     import threading
     n = len(ctxs)
@@ -49,15 +74,12 @@ def timed_steps(ctxs, steps, warmup, min_support=3, err=0.00005, outer_barrier=N
     outs = [None] * n
     if n == 1:
         c = ctxs[0]
-        for _ in range(warmup):
-            c.run_resident(min_support, err)
+        _passes(c, warmup, min_support, err, None)
         c.sync()
         if outer_barrier:
             outer_barrier()
         t = time.perf_counter()
-        for _ in range(steps):
-            outs[0] = c.run_resident(min_support, err)
-            ms[0].append(c.kernel_ms())
+        outs[0] = _passes(c, steps, min_support, err, ms[0])
         c.sync()
         if outer_barrier:
             outer_barrier()
@@ -68,13 +90,10 @@ def timed_steps(ctxs, steps, warmup, min_support=3, err=0.00005, outer_barrier=N
     def worker(i):
         try:
             c = ctxs[i]
-            for _ in range(warmup):
-                c.run_resident(min_support, err)
+            _passes(c, warmup, min_support, err, None)
             c.sync()
             bar.wait()                                           # start line
-            for _ in range(steps):
-                outs[i] = c.run_resident(min_support, err)
-                ms[i].append(c.kernel_ms())
+            outs[i] = _passes(c, steps, min_support, err, ms[i])
             c.sync()
             bar.wait()                                           # finish line
         except BaseException as e:                               # noqa: BLE001 (reported by the caller)

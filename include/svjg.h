@@ -212,6 +212,12 @@ int svjg_genotype_view(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *sl
 int svjg_set_rows(svjg_ctx *ctx, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows);
 int svjg_run_resident(svjg_ctx *ctx, uint64_t base_offset, uint32_t min_support, double err,
                       const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags, const uint8_t **boundary);
+/* The same in two halves, for a loop over batches: svjg_run_begin enqueues a pass (kernels on the context's stream, the copy of
+ * its results to pinned host memory on a second stream) and returns; svjg_run_end waits for the OLDEST pass in flight and hands
+ * out its results (valid until the second svjg_run_begin after it).  At most two passes are in flight, so the results of pass k
+ * cross PCIe while pass k + 1 computes: begin(0); for k: begin(k + 1); end() -> results of k; ...; end(). */
+int svjg_run_begin(svjg_ctx *ctx, uint64_t base_offset, uint32_t min_support, double err);
+int svjg_run_end(svjg_ctx *ctx, const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags, const uint8_t **boundary);
 
 /* ---- host-side writer of <prefix>_informative_aln.json (libsvjg_host.so, no GPU involved) -----------------
  * Byte-identical to json.dumps(dict_of_informative_aln, sort_keys=True, indent=4) (filter-alignments.py:174-175)

@@ -15,6 +15,7 @@
 #include <vector>
 
 using namespace svjg;
+typedef struct svjg_ctx svjg_ctx;
 
 static thread_local std::string g_init_error;
 
@@ -100,7 +101,13 @@ struct svjg_ctx {
     void *h_rows = nullptr;  uint64_t h_rows_cap = 0;   // pinned twin of d_rows
     uint64_t geno_rows = 0;                              // rows of the last svjg_genotype / svjg_genotype_view (svjg_genotype_boundary)
     // resident VCF rows of svjg_set_rows / svjg_run_resident: device block (results, row inputs) and the pinned host block the results land in
-    void *d_run = nullptr;  uint64_t d_run_cap = 0;  void *h_run = nullptr;  uint64_t h_run_cap = 0;  uint64_t run_rows = 0;
+    struct RunSlot {
+        void *d = nullptr;  uint64_t d_cap = 0;  void *h = nullptr;  uint64_t h_cap = 0;
+        hipEvent_t ev[6] = {};  hipEvent_t computed = nullptr, copied = nullptr;
+        uint64_t base_offset = 0;  uint32_t min_support = 0;  double err = 0;  bool had_text = false;
+    } run[2];
+    int run_head = 0, run_tail = 0, run_inflight = 0;
+    void *d_run_in = nullptr;  uint64_t d_run_in_cap = 0;  uint64_t run_rows = 0;  bool have_rows = false;
     // timing of the last calls
     float ms_main = 0, ms_slow = 0, ms_geno = 0;
     // rccl
@@ -175,9 +182,15 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     if (c->comm) ncclCommDestroy(c->comm);
     free_graph(c);
     hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_host); hipFree(c->d_st); hipFree(c->d_logfact);
-    hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows); hipFree(c->d_run);
+    hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows); hipFree(c->d_run_in);
+    for (auto &r : c->run) {
+        hipFree(r.d);
+        if (r.h) hipHostFree(r.h);
+        for (auto &e : r.ev) if (e) hipEventDestroy(e);
+        if (r.computed) hipEventDestroy(r.computed);
+        if (r.copied) hipEventDestroy(r.copied);
+    }
     if (c->h_rows) hipHostFree(c->h_rows);
-    if (c->h_run) hipHostFree(c->h_run);
     if (c->h_stp) hipHostFree(c->h_stp);
     for (auto &b : c->h_stage) if (b) hipHostFree(b);
     for (auto &ev : c->stage_ev) if (ev) hipEventDestroy(ev);
@@ -859,48 +872,61 @@ extern "C" int svjg_genotype_view(svjg_ctx *c, const uint8_t *sv_type, const uin
     return 0;
 }
 
-// ---- the whole pass in one call, one host wait ---------------------------------------------------------------------
-// svjg_set_rows leaves the VCF rows' three input arrays on the device; svjg_run_resident then enqueues — back to back on the
-// context's stream, no host round trip in between — zero counts, classify the resident text (the exact-path kernels take the
-// number of deferred lines from the device), the count all-reduce when the context has a communicator, genotype every row, and
-// copies the results (PLs as 32-bit integers) into the context's pinned block; then it waits ONCE.  What the host used to decide
-// between the kernels it checks afterwards, and repeats the pass the slow way if a buffer overflowed or the log10(i!) table was
-// too short (first call after a deeper sample than ever before).
-struct RunLayout { uint64_t pl32, raw, gt, flags, boundary, maxn, status, out_bytes, pl64, slot, type, ok, total; };
+// ---- the whole pass in one call, one host wait; two passes in flight ------------------------------------------------------
+// svjg_set_rows leaves the VCF rows' three input arrays on the device.  svjg_run_begin enqueues a pass — back to back on the
+// context's stream, no host round trip in between: zero counts, classify the resident text (the exact-path kernel takes the
+// number of deferred lines from the device), the count all-reduce when the context has a communicator, genotype every row — and,
+// on a second stream behind an event, the copy of the results (PLs as 32-bit integers) and of the pass's status block into pinned
+// host memory.  svjg_run_end waits for the OLDEST pass in flight, checks what the host used to decide between the kernels
+// (a list that overflowed, more deferred lines than one wave per line is good for, a log10(i!) table too short: the pass is then
+// repeated the slow way) and hands out its results.  Up to two passes may be in flight: the results of pass k travel over PCIe
+// while pass k + 1 computes.  svjg_run_resident = begin + end.
+struct RunLayout { uint64_t pl32, raw, gt, flags, boundary, maxn, status, guard, out_bytes, pl64, total; };
 static RunLayout run_layout(uint64_t n) {
     RunLayout L; uint64_t o = 0;
-    L.pl32 = o; o += n * 12; L.raw = o; o += n * 8; L.gt = o; o += n; L.flags = o; o += n; L.boundary = o; o += n; o = (o + 7) & ~7ull; L.maxn = o; o += 8; L.status = o; o += (sizeof(DevStatus) + 7) & ~7ull; L.out_bytes = o;
-    L.pl64 = o; o += n * 24; L.slot = o; o += n * 4; L.type = o; o += n; L.ok = o; o += n; L.total = o + 64;
+    L.pl32 = o; o += n * 12; L.raw = o; o += n * 8; L.gt = o; o += n; L.flags = o; o += n; L.boundary = o; o += n; o = (o + 7) & ~7ull; L.maxn = o; o += 8;
+    L.status = o; o += (sizeof(DevStatus) + 7) & ~7ull; L.guard = o; o += 16; L.out_bytes = o;
+    L.pl64 = o; o += n * 24; L.total = o + 64;
     return L;
 }
 
 extern "C" int svjg_set_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows) {
     if (!c || (n_rows && (!sv_type || !slot || !ok))) return SVJG_E_ARG;
+    if (c->run_inflight) { c->err = "svjg_set_rows with a pass in flight"; return SVJG_E_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const RunLayout L = run_layout(n_rows);
-    int rc = ensure(c, &c->d_run, &c->d_run_cap, L.total, 1, false);
-    if (rc) return rc;
-    if (L.out_bytes + 16 > c->h_run_cap) {
-        if (c->h_run) hipHostFree(c->h_run);
-        c->h_run = nullptr; c->h_run_cap = 0;
-        HIPCHK(c, hipHostMalloc(&c->h_run, L.out_bytes + 16, hipHostMallocDefault));
-        c->h_run_cap = L.out_bytes + 16;
+    int rc;
+    if ((rc = ensure(c, &c->d_run_in, &c->d_run_in_cap, n_rows * 6 + 64, 1, false))) return rc;
+    for (int k = 0; k < 2; ++k) {
+        svjg_ctx::RunSlot &r = c->run[k];
+        if ((rc = ensure(c, &r.d, &r.d_cap, L.total, 1, false))) return rc;
+        if (L.out_bytes > r.h_cap) {
+            if (r.h) hipHostFree(r.h);
+            r.h = nullptr; r.h_cap = 0;
+            HIPCHK(c, hipHostMalloc(&r.h, L.out_bytes, hipHostMallocDefault));
+            r.h_cap = L.out_bytes;
+        }
+        for (auto &e : r.ev) if (!e) HIPCHK(c, hipEventCreate(&e));
+        if (!r.computed) HIPCHK(c, hipEventCreateWithFlags(&r.computed, hipEventDisableTiming));
+        if (!r.copied) HIPCHK(c, hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
     }
-    uint8_t *base = (uint8_t *)c->d_run;
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    uint8_t *in = (uint8_t *)c->d_run_in;
     if (n_rows) {
-        HIPCHK(c, hipMemcpyAsync(base + L.slot, slot, n_rows * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(base + L.type, sv_type, n_rows, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(base + L.ok, ok, n_rows, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(in, slot, n_rows * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(in + n_rows * 4, sv_type, n_rows, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(in + n_rows * 5, ok, n_rows, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));               // (the caller's arrays may go away)
-    c->run_rows = n_rows;
+    c->run_rows = n_rows; c->have_rows = true;
     return 0;
 }
 
-static GenoArgs run_geno_args(svjg_ctx *c, const RunLayout &L, uint32_t min_support, double err) {
-    uint8_t *base = (uint8_t *)c->d_run;
+static GenoArgs run_geno_args(svjg_ctx *c, const svjg_ctx::RunSlot &r, const RunLayout &L, uint32_t min_support, double err) {
+    uint8_t *base = (uint8_t *)r.d;
+    const uint8_t *in = (const uint8_t *)c->d_run_in;
     GenoArgs a{};
-    a.counts = c->d_counts; a.sv_type = base + L.type; a.slot = (const uint32_t *)(base + L.slot); a.ok = base + L.ok; a.n_rows = c->run_rows;
+    a.counts = c->d_counts; a.slot = (const uint32_t *)in; a.sv_type = in + c->run_rows * 4; a.ok = in + c->run_rows * 5; a.n_rows = c->run_rows;
     a.min_support = min_support;
     a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
     a.gt = base + L.gt; a.pl = (int64_t *)(base + L.pl64); a.raw = (uint32_t *)(base + L.raw); a.genotyped = base + L.flags;
@@ -909,31 +935,29 @@ static GenoArgs run_geno_args(svjg_ctx *c, const RunLayout &L, uint32_t min_supp
     return a;
 }
 
-extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min_support, double err,
-                                 const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags, const uint8_t **boundary) {
-    if (!c || !gt || !pl || !raw || !flags || !boundary) return SVJG_E_ARG;
-    *gt = nullptr; *pl = nullptr; *raw = nullptr; *flags = nullptr; *boundary = nullptr;
-    if (!c->have_graph || !c->have_gaf) { c->err = "svjg_run_resident needs a graph and an uploaded GAF"; return SVJG_E_ARG; }
-    if (!c->d_run) { c->err = "svjg_set_rows has not been called"; return SVJG_E_ARG; }
+extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_support, double err) {
+    if (!c) return SVJG_E_ARG;
+    if (!c->have_graph || !c->have_gaf) { c->err = "svjg_run_begin needs a graph and an uploaded GAF"; return SVJG_E_ARG; }
+    if (!c->have_rows) { c->err = "svjg_set_rows has not been called"; return SVJG_E_ARG; }
+    if (c->run_inflight >= 2) { c->err = "two passes are in flight: svjg_run_end first"; return SVJG_E_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t n = c->gaf_bytes, n_rows = c->run_rows;
     const RunLayout L = run_layout(n_rows);
-    uint8_t *hb = (uint8_t *)c->h_run;
+    svjg_ctx::RunSlot &r = c->run[c->run_head];
     int rc;
     if ((rc = ensure(c, (void **)&c->d_deferred, &c->deferred_cap, deferred_want(c, n), sizeof(uint64_t), false))) return rc;
     if ((rc = ensure(c, (void **)&c->d_host, &c->host_cap, 4096, sizeof(uint64_t), false))) return rc;
     if (c->logfact_n == 0 && (rc = build_logfact(c, 65536))) return rc;
-    // ---- everything enqueued ----
-    uint8_t *base = (uint8_t *)c->d_run;
+    r.base_offset = base_offset; r.min_support = min_support; r.err = err;
+    uint8_t *base = (uint8_t *)r.d;
     DevStatus *d_st = (DevStatus *)(base + L.status);             // (the pass's status block sits behind the results: one copy brings both)
-    GenoArgs ga = run_geno_args(c, L, min_support, err);
+    GenoArgs ga = run_geno_args(c, r, L, min_support, err);
     {
         const uint64_t words = (uint64_t)c->n_slots + 2;
         uint32_t rg = (uint32_t)((words + TPB - 1) / TPB);
         if (rg > 1024) rg = 1024;
         hipLaunchKernelGGL(k_step_reset, dim3(rg), dim3(TPB), 0, c->stream, c->d_counts, words, d_st, ga.max_n);
     }
-    c->ms_slow = 0;
     const uint64_t max_blocks = (uint64_t)c->n_cu * 4, wave_limit = 16 * max_blocks;
     if (n) {
         ClassifyArgs a{};
@@ -941,40 +965,63 @@ extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min
         size_t lds = 0;
         main_launch_setup(c, 0, n, base_offset, 0, a, grid, lds);
         a.st = d_st;
-        HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        HIPCHK(c, hipEventRecord(r.ev[0], c->stream));
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(c, hipEventRecord(r.ev[1], c->stream));
         // the exact path for up to wave_limit lines, their number read on the device (more: the pass is repeated step by step)
         hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)c->n_cu), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, 0ull, wave_limit);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(c, hipEventRecord(r.ev[2], c->stream));
     }
     if (c->comm) {
         if ((rc = launch_guard(c))) return rc;
-        ncclResult_t r = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
-        if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return SVJG_E_RCCL; }
-        HIPCHK(c, hipMemcpyAsync(hb + L.out_bytes, c->d_counts + c->n_slots, 16, hipMemcpyDeviceToHost, c->stream));
+        ncclResult_t nr = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
+        if (nr != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(nr); return SVJG_E_RCCL; }
+        HIPCHK(c, hipMemcpyAsync(base + L.guard, c->d_counts + c->n_slots, 16, hipMemcpyDeviceToDevice, c->stream));
     }
     if (n_rows) {
-        HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+        HIPCHK(c, hipEventRecord(r.ev[4], c->stream));
         hipLaunchKernelGGL(k_genotype, dim3((uint32_t)((n_rows + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, ga);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+        HIPCHK(c, hipEventRecord(r.ev[5], c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(hb, c->d_run, L.out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));                           // the pass's one host wait
+    // the results go home on the copy stream while the compute stream is free for the next pass
+    HIPCHK(c, hipEventRecord(r.computed, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, r.computed, 0));
+    HIPCHK(c, hipMemcpyAsync(r.h, r.d, L.out_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(r.copied, c->copy_stream));
+    r.had_text = n != 0;
+    c->run_head ^= 1; ++c->run_inflight;
+    return 0;
+}
+
+extern "C" int svjg_run_end(svjg_ctx *c, const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags, const uint8_t **boundary) {
+    if (!c || !gt || !pl || !raw || !flags || !boundary) return SVJG_E_ARG;
+    *gt = nullptr; *pl = nullptr; *raw = nullptr; *flags = nullptr; *boundary = nullptr;
+    if (!c->run_inflight) { c->err = "no pass in flight"; return SVJG_E_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    svjg_ctx::RunSlot &r = c->run[c->run_tail];
+    c->run_tail ^= 1; --c->run_inflight;
+    const uint64_t n = c->gaf_bytes, n_rows = c->run_rows;
+    const RunLayout L = run_layout(n_rows);
+    uint8_t *hb = (uint8_t *)r.h;
+    int rc;
+    HIPCHK(c, hipEventSynchronize(r.copied));                              // the pass's one host wait
     c->hs() = *(const DevStatus *)(hb + L.status);
     // ---- what the host would have decided in between ----
-    if (n) {
-        HIPCHK(c, hipEventElapsedTime(&c->ms_main, c->ev[0], c->ev[1]));
-        if (c->hs().n_deferred) HIPCHK(c, hipEventElapsedTime(&c->ms_slow, c->ev[1], c->ev[3]));
+    c->ms_slow = 0;
+    if (r.had_text) {
+        HIPCHK(c, hipEventElapsedTime(&c->ms_main, r.ev[0], r.ev[1]));
+        if (c->hs().n_deferred) HIPCHK(c, hipEventElapsedTime(&c->ms_slow, r.ev[1], r.ev[2]));
     }
+    if (n_rows) HIPCHK(c, hipEventElapsedTime(&c->ms_geno, r.ev[4], r.ev[5]));
+    const uint64_t wave_limit = 16 * (uint64_t)c->n_cu * 4;
     bool again = false;
     if (c->hs().overflow || c->hs().n_deferred > wave_limit) {
         // the list of deferred lines was too short, or holds more lines than one wave per line is good for: the pass again, step by
-        // step (classify_range sizes the list, picks the exact-path kernel and retries)
+        // step (classify_range sizes the list, picks the exact-path kernel and retries), behind whatever is enqueued already
         if ((rc = svjg_reset_counts(c))) return rc;
-        rc = classify_range(c, 0, n, base_offset, 0);
+        rc = classify_range(c, 0, n, r.base_offset, 0);
         if (rc) return rc;
         if (c->comm && (rc = svjg_allreduce_counts(c))) return rc;
         again = true;
@@ -983,7 +1030,7 @@ extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min
         if (c->hs().err != ~0ull) return SVJG_E_INPUT;
         if (c->hs().n_host) { c->err = "the text holds lines only the host can decide (non-ASCII digits in a decimal column: svjg_get_host_lines); classify it with svjg_classify"; return SVJG_E_ARG; }
         if (c->comm) {
-            const unsigned long long *gd = (const unsigned long long *)(hb + L.out_bytes);
+            const unsigned long long *gd = (const unsigned long long *)(hb + L.guard);
             if (gd[0] >= (1ull << 32) || gd[1] >= (1ull << 32)) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
         }
     }
@@ -994,20 +1041,31 @@ extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min
                 const unsigned int max_n = *(const unsigned int *)(hb + L.maxn);
                 if (max_n == 0) break;                           // every row found its binomial term
                 if (attempt == 2) { c->err = "log10(i!) table could not be sized"; return SVJG_E_HIP; }
+                // (a pass already enqueued behind this one still uses the old table: it must drain before the table is replaced)
+                HIPCHK(c, hipStreamSynchronize(c->stream));
                 if ((rc = build_logfact(c, max_n + 1 + 1024))) return rc;
             }
             again = false;
-            ga = run_geno_args(c, L, min_support, err);
+            // NOTE: with a second pass in flight the counts on the device are that pass's (same text, same rows: the same counts)
+            GenoArgs ga = run_geno_args(c, r, L, r.min_support, r.err);
             HIPCHK(c, hipMemsetAsync(ga.max_n, 0, 8, c->stream));
             hipLaunchKernelGGL(k_genotype, dim3((uint32_t)((n_rows + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, ga);
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(hb, c->d_run, L.out_bytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(hb, r.d, L.out_bytes - 16 - ((sizeof(DevStatus) + 7) & ~7ull), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        HIPCHK(c, hipEventElapsedTime(&c->ms_geno, c->ev[4], c->ev[5]));
     }
     *pl = (const int32_t *)(hb + L.pl32); *raw = (const uint32_t *)(hb + L.raw); *gt = hb + L.gt; *flags = hb + L.flags; *boundary = hb + L.boundary;
     return 0;
+}
+
+extern "C" int svjg_run_resident(svjg_ctx *c, uint64_t base_offset, uint32_t min_support, double err,
+                                 const uint8_t **gt, const int32_t **pl, const uint32_t **raw, const uint8_t **flags, const uint8_t **boundary) {
+    if (!c || !gt || !pl || !raw || !flags || !boundary) return SVJG_E_ARG;
+    if (c->run_inflight) { c->err = "svjg_run_resident with a pass in flight (svjg_run_end first)"; return SVJG_E_ARG; }
+    const int rc = svjg_run_begin(c, base_offset, min_support, err);
+    if (rc) return rc;
+    return svjg_run_end(c, gt, pl, raw, flags, boundary);
 }
 
 // which rows of the last svjg_genotype / svjg_genotype_view call lie so close to a PL's integer boundary that the caller should

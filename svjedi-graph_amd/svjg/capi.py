@@ -78,6 +78,8 @@ _SIGS = {
                                           ctypes.c_uint32, ctypes.c_double] + [ctypes.POINTER(ctypes.c_void_p)] * 4),
     "svjg_set_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "svjg_run_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_double] + [ctypes.POINTER(ctypes.c_void_p)] * 5),
+    "svjg_run_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_double]),
+    "svjg_run_end": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_void_p)] * 5),
     "svjg_genotype_boundary": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "svjg_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                            ctypes.POINTER(ctypes.c_float)]),
@@ -430,16 +432,10 @@ class Context:
         self._n_rows = len(sv_type)
         self._chk(self.lib.svjg_set_rows(self.h, sv_type.ctypes.data, slot.ctypes.data, ok.ctypes.data, self._n_rows))
 
-    def run_resident(self, min_support, err, base_offset=0):
-        """One whole pass with one host wait (svjg_run_resident): zero the counts, classify the uploaded text, all-reduce the
-        counts if this context has a communicator, genotype the rows of set_rows().  -> (gt, pl[n, 3] int32, raw[n, 2], flags):
-        read-only views of the library's pinned result block, overwritten by the next call; flags bit 0 = genotyped, bit 1 =
-        the row's PLs need 64 bits (genotype() has them).  self.last_boundary: the rows to recompute like the reference
-        (svjg_genotype_boundary)."""
+    def _run_views(self, p):
         n = self._n_rows
-        p = [ctypes.c_void_p() for _ in range(5)]
-        self._chk(self.lib.svjg_run_resident(self.h, base_offset, min_support, float(err), *[ctypes.byref(x) for x in p]))
         if not n:
+            self.last_boundary = np.zeros(0, np.uint8)
             return np.zeros(0, np.uint8), np.zeros((0, 3), np.int32), np.zeros((0, 2), np.uint32), np.zeros(0, np.uint8)
 
         def view(ptr, count, dt):
@@ -448,6 +444,26 @@ class Context:
             return a
         self.last_boundary = view(p[4], n, np.uint8)
         return view(p[0], n, np.uint8), view(p[1], n * 3, np.int32).reshape(n, 3), view(p[2], n * 2, np.uint32).reshape(n, 2), view(p[3], n, np.uint8)
+
+    def run_resident(self, min_support, err, base_offset=0):
+        """One whole pass with one host wait (svjg_run_resident): zero the counts, classify the uploaded text, all-reduce the
+        counts if this context has a communicator, genotype the rows of set_rows().  -> (gt, pl[n, 3] int32, raw[n, 2], flags):
+        read-only views of the library's pinned result block, overwritten by the second pass after this one; flags bit 0 =
+        genotyped, bit 1 = the row's PLs need 64 bits (genotype() has them).  self.last_boundary: the rows to recompute like the
+        reference (svjg_genotype_boundary)."""
+        p = [ctypes.c_void_p() for _ in range(5)]
+        self._chk(self.lib.svjg_run_resident(self.h, base_offset, min_support, float(err), *[ctypes.byref(x) for x in p]))
+        return self._run_views(p)
+
+    def run_begin(self, min_support, err, base_offset=0):
+        """enqueue a pass (svjg_run_begin); at most two may be in flight"""
+        self._chk(self.lib.svjg_run_begin(self.h, base_offset, min_support, float(err)))
+
+    def run_end(self):
+        """wait for the oldest pass in flight and return its results like run_resident() (svjg_run_end)"""
+        p = [ctypes.c_void_p() for _ in range(5)]
+        self._chk(self.lib.svjg_run_end(self.h, *[ctypes.byref(x) for x in p]))
+        return self._run_views(p)
 
     def boundary_flags(self, n_rows):
         """rows of the last genotype() call whose PLs lie within 1e-6 of an integer boundary (to be recomputed by

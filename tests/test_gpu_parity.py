@@ -969,6 +969,20 @@ def test_run_resident_is_the_three_calls(tmp_path):
                 assert st["n_lines"] == want[1]["n_lines"] and st["n_deferred"] == want[1]["n_deferred"] >= min_def
                 assert np.array_equal(gt, want[2]) and np.array_equal(pl, want[3]) and pl.dtype == np.int32 and np.array_equal(raw, want[4])
                 assert np.array_equal(flags & 1, want[5]) and not (flags & 2).any()
+        # two passes in flight (svjg_run_begin / svjg_run_end): the same results, in order; a third is refused
+        c.upload(gaf)
+        want = _step_by_step(c, gaf, rows)
+        c.run_begin(3, 0.00005); c.run_begin(3, 0.00005)
+        with pytest.raises(capi.SvjgError):
+            c.run_begin(3, 0.00005)
+        for _ in range(3):
+            got = [np.array(x) for x in c.run_end()]
+            assert np.array_equal(got[0], want[2]) and np.array_equal(got[1], want[3]) and np.array_equal(got[2], want[4])
+            if _ < 2:
+                c.run_begin(3, 0.00005)
+        c.run_end()
+        with pytest.raises(capi.SvjgError):
+            c.run_end()
         shard.RcclGroup(c, 1, 0, lambda uid: uid)              # a communicator of one rank: the all-reduce leg runs, the counts stay
         want = _step_by_step(c, gaf, rows)
         gt, pl, raw, flags = (np.array(x) for x in c.run_resident(3, 0.00005))
