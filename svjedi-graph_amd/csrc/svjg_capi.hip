@@ -102,11 +102,13 @@ struct svjg_ctx {
     uint64_t geno_rows = 0;                              // rows of the last svjg_genotype / svjg_genotype_view (svjg_genotype_boundary)
     // resident VCF rows of svjg_set_rows / svjg_run_resident: device block (results, row inputs) and the pinned host block the results land in
     struct RunSlot {
-        void *d = nullptr;  uint64_t d_cap = 0;  void *h = nullptr;  uint64_t h_cap = 0;
+        void *d = nullptr;  uint64_t d_cap = 0;  void *h = nullptr;  uint64_t h_cap = 0;  void *h_dev = nullptr;   // h_dev: the pinned block as the device sees it
+        unsigned long long *counts = nullptr;  uint64_t counts_cap = 0;   // the pass's own count vector (+ guard words): the next pass may zero its own while this one is genotyped
         hipEvent_t ev[6] = {};  hipEvent_t computed = nullptr, copied = nullptr;
         uint64_t base_offset = 0;  uint32_t min_support = 0;  double err = 0;  bool had_text = false;
     } run[2];
     int run_head = 0, run_tail = 0, run_inflight = 0;
+    int counts_in_slot = -1;                             // >= 0: the newest counts live in that slot's vector, not yet in d_counts (fetch_slot_counts)
     void *d_run_in = nullptr;  uint64_t d_run_in_cap = 0;  uint64_t run_rows = 0;  bool have_rows = false;
     // timing of the last calls
     float ms_main = 0, ms_slow = 0, ms_geno = 0;
@@ -179,12 +181,13 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->comm) ncclCommDestroy(c->comm);
     free_graph(c);
     hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_host); hipFree(c->d_st); hipFree(c->d_logfact);
     hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows); hipFree(c->d_run_in);
     for (auto &r : c->run) {
-        hipFree(r.d);
+        hipFree(r.d); hipFree(r.counts);
         if (r.h) hipHostFree(r.h);
         for (auto &e : r.ev) if (e) hipEventDestroy(e);
         if (r.computed) hipEventDestroy(r.computed);
@@ -282,6 +285,7 @@ extern "C" int svjg_alloc_counts(svjg_ctx *c, uint32_t n_slots) {
 
 extern "C" int svjg_reset_counts(svjg_ctx *c) {
     if (!c || !c->have_counts) return SVJG_E_ARG;
+    c->counts_in_slot = -1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, ((uint64_t)c->n_slots + 2) * 8, c->stream));
     return reset_status(c, true);                             // (nothing to wait for: the next call on the stream comes behind both)
@@ -388,6 +392,17 @@ static int ensure(svjg_ctx *c, void **p, uint64_t *cap, uint64_t want, size_t el
 }
 
 // arguments and geometry of one k_classify_main launch over the lines of the resident text that lie in [begin, end)
+// The passes of svjg_run_begin keep their counts in vectors of their own; the rest of the API works on d_counts: the newest pass's
+// vector is copied there when someone asks for it (svjg_get_counts, svjg_genotype, svjg_classify adding to it, ...).
+static int fetch_slot_counts(svjg_ctx *c) {
+    if (c->counts_in_slot < 0) return 0;
+    const int k = c->counts_in_slot;
+    c->counts_in_slot = -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_counts, c->run[k].counts, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
 static uint64_t deferred_want(const svjg_ctx *c, uint64_t n) { return (c->gflags & SVJG_GRAPH_ALL_SLOW) ? n / 24 + 64 : (n / 4096 + 65536); }
 
 static void main_launch_setup(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t base_offset, int want_hits, ClassifyArgs &a, uint32_t &grid, size_t &lds) {
@@ -431,6 +446,7 @@ static void main_launch_setup(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_
 // the lines of the resident text that lie in [begin, end): begin is a line start, end the byte behind a terminator (or the text's end)
 static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t base_offset, int want_hits) {
     HIPCHK(c, hipSetDevice(c->device));
+    { const int rc0 = fetch_slot_counts(c); if (rc0) return rc0; }
     if (end <= begin) return 0;
     const uint64_t n = end - begin;
     uint64_t def_want = deferred_want(c, n);
@@ -635,6 +651,7 @@ extern "C" int svjg_input_error(svjg_ctx *c, int *cls, uint64_t *off) {
 extern "C" int svjg_get_counts(svjg_ctx *c, uint32_t *out, uint32_t n_slots) {
     if (!c || !c->have_counts || !out || n_slots != c->n_slots) return SVJG_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    { const int rc0 = fetch_slot_counts(c); if (rc0) return rc0; }
     std::vector<unsigned long long> tmp(n_slots);
     if (n_slots) HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_counts, (uint64_t)n_slots * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -644,6 +661,7 @@ extern "C" int svjg_get_counts(svjg_ctx *c, uint32_t *out, uint32_t n_slots) {
 
 extern "C" int svjg_set_counts(svjg_ctx *c, const uint32_t *in, uint32_t n_slots) {
     if (!c || !c->have_counts || !in || n_slots != c->n_slots) return SVJG_E_ARG;
+    c->counts_in_slot = -1;
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<unsigned long long> tmp(n_slots);
     for (uint32_t i = 0; i < n_slots; ++i) tmp[i] = (unsigned long long)in[2 * i] | ((unsigned long long)in[2 * i + 1] << 32);
@@ -696,13 +714,14 @@ extern "C" int svjg_comm_init(svjg_ctx *c, const char *id128, int n_ranks, int r
 }
 
 // the two guard elements behind the count vector <- largest ref / alt field (k_counts_guard)
-static int launch_guard(svjg_ctx *c) {
+static int launch_guard(svjg_ctx *c, unsigned long long *counts = nullptr) {
+    if (!counts) counts = c->d_counts;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(c->d_counts + c->n_slots, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(counts + c->n_slots, 0, 16, c->stream));
     if (c->n_slots) {
         uint32_t grid = (c->n_slots + TPB - 1) / TPB;
         if (grid > 1024) grid = 1024;
-        hipLaunchKernelGGL(k_counts_guard, dim3(grid), dim3(TPB), 0, c->stream, c->d_counts, c->n_slots);
+        hipLaunchKernelGGL(k_counts_guard, dim3(grid), dim3(TPB), 0, c->stream, counts, c->n_slots);
         HIPCHK(c, hipGetLastError());
     }
     return 0;
@@ -719,6 +738,7 @@ static int check_guard(svjg_ctx *c) {
 // the path's only collective: sum of the per-SV count vector (packed ref | alt << 32 as one u64 each, plus the two guard elements)
 extern "C" int svjg_allreduce_counts(svjg_ctx *c) {
     if (!c || !c->have_counts) return SVJG_E_ARG;
+    { const int rc0 = fetch_slot_counts(c); if (rc0) return rc0; }
     if (!c->comm) { c->err = "svjg_comm_init has not been called"; return SVJG_E_ARG; }
     int rc = launch_guard(c);
     if (rc) return rc;
@@ -755,7 +775,7 @@ extern "C" int svjg_allreduce_counts_all(svjg_ctx *const *ctxs, int n) {
         if (n > 1 && !ctxs[i]->comm) { ctxs[0]->err = "svjg_comm_init_all has not been called"; return SVJG_E_ARG; }
     }
     int rc;
-    for (int i = 0; i < n; ++i) if ((rc = launch_guard(ctxs[i]))) { if (i) ctxs[0]->err = ctxs[i]->err; return rc; }
+    for (int i = 0; i < n; ++i) if ((rc = fetch_slot_counts(ctxs[i])) || (rc = launch_guard(ctxs[i]))) { if (i) ctxs[0]->err = ctxs[i]->err; return rc; }
     if (n > 1) {
         ncclResult_t r = ncclGroupStart();
         for (int i = 0; i < n && r == ncclSuccess; ++i) {
@@ -791,6 +811,7 @@ static int build_logfact(svjg_ctx *c, uint32_t upto) {
 static int genotype_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows,
                          uint32_t min_support, double err) {
     HIPCHK(c, hipSetDevice(c->device));
+    { const int rc0 = fetch_slot_counts(c); if (rc0) return rc0; }
     // one device block and its pinned host twin: [ pl 24 | raw 8 | gt 1 | done 1 | boundary 1 ] n rows of output, max_n, then
     // [ slot 4 | type 1 | ok 1 ] n rows of input -> ONE copy in and ONE copy out per call whatever the number of arrays
     const uint64_t out_bytes = n_rows * 35, maxn_off = (out_bytes + 7) & ~7ull, in_off = maxn_off + 8, in_bytes = n_rows * 6;
@@ -881,18 +902,25 @@ extern "C" int svjg_genotype_view(svjg_ctx *c, const uint8_t *sv_type, const uin
 // (a list that overflowed, more deferred lines than one wave per line is good for, a log10(i!) table too short: the pass is then
 // repeated the slow way) and hands out its results.  Up to two passes may be in flight: the results of pass k travel over PCIe
 // while pass k + 1 computes.  svjg_run_resident = begin + end.
-struct RunLayout { uint64_t pl32, raw, gt, flags, boundary, maxn, status, guard, out_bytes, pl64, total; };
+// host block (pinned, mapped into the device: the genotype kernel writes its results straight into it — they cross PCIe as they
+// are produced, no copy kernel competes with the next pass —): pl32, raw, gt, flags, boundary, then the tail; device block: the
+// tail (max_n, the pass's status block, the guard words: written by atomics, copied to the host block's tail in one small copy), pl64
+struct RunLayout { uint64_t pl32, raw, gt, flags, boundary, h_tail, out_bytes;  uint64_t maxn, status, guard, tail_bytes, pl64, total; };
 static RunLayout run_layout(uint64_t n) {
     RunLayout L; uint64_t o = 0;
-    L.pl32 = o; o += n * 12; L.raw = o; o += n * 8; L.gt = o; o += n; L.flags = o; o += n; L.boundary = o; o += n; o = (o + 7) & ~7ull; L.maxn = o; o += 8;
-    L.status = o; o += (sizeof(DevStatus) + 7) & ~7ull; L.guard = o; o += 16; L.out_bytes = o;
-    L.pl64 = o; o += n * 24; L.total = o + 64;
+    L.pl32 = o; o += n * 12; L.raw = o; o += n * 8; L.gt = o; o += n; L.flags = o; o += n; L.boundary = o; o += n; o = (o + 63) & ~63ull; L.h_tail = o;
+    uint64_t d = 0;
+    L.maxn = d; d += 8; L.status = d; d += (sizeof(DevStatus) + 7) & ~7ull; L.guard = d; d += 16; L.tail_bytes = d;
+    L.out_bytes = L.h_tail + L.tail_bytes;
+    d = (d + 63) & ~63ull; L.pl64 = d; d += n * 24; L.total = d + 64;
     return L;
 }
 
 extern "C" int svjg_set_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t *slot, const uint8_t *ok, uint64_t n_rows) {
     if (!c || (n_rows && (!sv_type || !slot || !ok))) return SVJG_E_ARG;
     if (c->run_inflight) { c->err = "svjg_set_rows with a pass in flight"; return SVJG_E_ARG; }
+    if (!c->have_counts) { c->err = "svjg_set_rows needs the count vector (svjg_load_graph / svjg_alloc_counts first)"; return SVJG_E_ARG; }
+    { const int rc0 = fetch_slot_counts(c); if (rc0) return rc0; }
     HIPCHK(c, hipSetDevice(c->device));
     const RunLayout L = run_layout(n_rows);
     int rc;
@@ -903,14 +931,20 @@ extern "C" int svjg_set_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t
         if (L.out_bytes > r.h_cap) {
             if (r.h) hipHostFree(r.h);
             r.h = nullptr; r.h_cap = 0;
-            HIPCHK(c, hipHostMalloc(&r.h, L.out_bytes, hipHostMallocDefault));
+            HIPCHK(c, hipHostMalloc(&r.h, L.out_bytes, hipHostMallocMapped));
             r.h_cap = L.out_bytes;
+            HIPCHK(c, hipHostGetDevicePointer(&r.h_dev, r.h, 0));
         }
+        if ((rc = ensure(c, (void **)&r.counts, &r.counts_cap, (uint64_t)c->n_slots + 2, sizeof(unsigned long long), false))) return rc;
         for (auto &e : r.ev) if (!e) HIPCHK(c, hipEventCreate(&e));
         if (!r.computed) HIPCHK(c, hipEventCreateWithFlags(&r.computed, hipEventDisableTiming));
         if (!r.copied) HIPCHK(c, hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
     }
-    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->copy_stream) {                                    // (the lowest priority there is: what runs on it must not take issue slots from the classify kernel)
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, least));
+    }
     uint8_t *in = (uint8_t *)c->d_run_in;
     if (n_rows) {
         HIPCHK(c, hipMemcpyAsync(in, slot, n_rows * 4, hipMemcpyHostToDevice, c->stream));
@@ -922,15 +956,15 @@ extern "C" int svjg_set_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t
     return 0;
 }
 
-static GenoArgs run_geno_args(svjg_ctx *c, const svjg_ctx::RunSlot &r, const RunLayout &L, uint32_t min_support, double err) {
-    uint8_t *base = (uint8_t *)r.d;
+static GenoArgs run_geno_args(svjg_ctx *c, const svjg_ctx::RunSlot &r, const RunLayout &L, uint32_t min_support, double err, const unsigned long long *counts) {
+    uint8_t *base = (uint8_t *)r.d, *hostb = (uint8_t *)r.h_dev;
     const uint8_t *in = (const uint8_t *)c->d_run_in;
     GenoArgs a{};
-    a.counts = c->d_counts; a.slot = (const uint32_t *)in; a.sv_type = in + c->run_rows * 4; a.ok = in + c->run_rows * 5; a.n_rows = c->run_rows;
+    a.counts = counts; a.slot = (const uint32_t *)in; a.sv_type = in + c->run_rows * 4; a.ok = in + c->run_rows * 5; a.n_rows = c->run_rows;
     a.min_support = min_support;
     a.l_ok = log10(1.0 - err); a.l_err = log10(err); a.l_half = log10(1.0 / 2.0);     // host libm, as CPython's math.log10
-    a.gt = base + L.gt; a.pl = (int64_t *)(base + L.pl64); a.raw = (uint32_t *)(base + L.raw); a.genotyped = base + L.flags;
-    a.pl32 = (int32_t *)(base + L.pl32); a.boundary = base + L.boundary; a.max_n = (unsigned int *)(base + L.maxn); a.n_slots = c->n_slots;
+    a.gt = hostb + L.gt; a.pl = (int64_t *)(base + L.pl64); a.raw = (uint32_t *)(hostb + L.raw); a.genotyped = hostb + L.flags;
+    a.pl32 = (int32_t *)(hostb + L.pl32); a.boundary = hostb + L.boundary; a.max_n = (unsigned int *)(base + L.maxn); a.n_slots = c->n_slots;
     a.logfact = c->d_logfact; a.logfact_n = c->logfact_n;
     return a;
 }
@@ -950,13 +984,14 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
     if (c->logfact_n == 0 && (rc = build_logfact(c, 65536))) return rc;
     r.base_offset = base_offset; r.min_support = min_support; r.err = err;
     uint8_t *base = (uint8_t *)r.d;
-    DevStatus *d_st = (DevStatus *)(base + L.status);             // (the pass's status block sits behind the results: one copy brings both)
-    GenoArgs ga = run_geno_args(c, r, L, min_support, err);
+    DevStatus *d_st = (DevStatus *)(base + L.status);             // (the pass's own status block: its tail goes to the host in one small copy)
+    if (r.counts_cap < (uint64_t)c->n_slots + 2) { c->err = "svjg_set_rows must follow svjg_load_graph"; return SVJG_E_ARG; }
+    GenoArgs ga = run_geno_args(c, r, L, min_support, err, r.counts);
     {
         const uint64_t words = (uint64_t)c->n_slots + 2;
         uint32_t rg = (uint32_t)((words + TPB - 1) / TPB);
         if (rg > 1024) rg = 1024;
-        hipLaunchKernelGGL(k_step_reset, dim3(rg), dim3(TPB), 0, c->stream, c->d_counts, words, d_st, ga.max_n);
+        hipLaunchKernelGGL(k_step_reset, dim3(rg), dim3(TPB), 0, c->stream, r.counts, words, d_st, ga.max_n);
     }
     const uint64_t max_blocks = (uint64_t)c->n_cu * 4, wave_limit = 16 * max_blocks;
     if (n) {
@@ -964,7 +999,7 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         uint32_t grid = 0;
         size_t lds = 0;
         main_launch_setup(c, 0, n, base_offset, 0, a, grid, lds);
-        a.st = d_st;
+        a.st = d_st; a.counts = r.counts;
         HIPCHK(c, hipEventRecord(r.ev[0], c->stream));
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
         HIPCHK(c, hipEventRecord(r.ev[1], c->stream));
@@ -974,22 +1009,28 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         HIPCHK(c, hipEventRecord(r.ev[2], c->stream));
     }
     if (c->comm) {
-        if ((rc = launch_guard(c))) return rc;
-        ncclResult_t nr = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
+        if ((rc = launch_guard(c, r.counts))) return rc;
+        ncclResult_t nr = ncclAllReduce(r.counts, r.counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
         if (nr != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(nr); return SVJG_E_RCCL; }
-        HIPCHK(c, hipMemcpyAsync(base + L.guard, c->d_counts + c->n_slots, 16, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(base + L.guard, r.counts + c->n_slots, 16, hipMemcpyDeviceToDevice, c->stream));
     }
-    if (n_rows) {
-        HIPCHK(c, hipEventRecord(r.ev[4], c->stream));
-        hipLaunchKernelGGL(k_genotype, dim3((uint32_t)((n_rows + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, ga);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(r.ev[5], c->stream));
-    }
-    // the results go home on the copy stream while the compute stream is free for the next pass
+    // The genotypes on the second stream, behind an event: the kernel writes its results straight into the pinned host block — they
+    // cross PCIe as they are produced —, which takes ~45 us for 100 k rows during which the compute stream already runs the next
+    // pass (that one zeroes and fills ITS count vector).
     HIPCHK(c, hipEventRecord(r.computed, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, r.computed, 0));
-    HIPCHK(c, hipMemcpyAsync(r.h, r.d, L.out_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+    if (n_rows) {
+        HIPCHK(c, hipEventRecord(r.ev[4], c->copy_stream));
+        uint32_t gg = (uint32_t)((n_rows + TPB - 1) / TPB);
+        { const char *e = getenv("SVJG_GENO_GRID"); const uint32_t cap = e ? (uint32_t)atoi(e) : 64u; if (cap && gg > cap) gg = cap; }   // (few wave slots: see k_genotype)
+        hipLaunchKernelGGL(k_genotype, dim3(gg), dim3(TPB), 0, c->copy_stream, ga);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(r.ev[5], c->copy_stream));
+    }
+    // the pass's tail: max_n, status, guard words
+    HIPCHK(c, hipMemcpyAsync((uint8_t *)r.h + L.h_tail, r.d, L.tail_bytes, hipMemcpyDeviceToHost, c->copy_stream));
     HIPCHK(c, hipEventRecord(r.copied, c->copy_stream));
+    c->counts_in_slot = c->run_head;
     r.had_text = n != 0;
     c->run_head ^= 1; ++c->run_inflight;
     return 0;
@@ -1007,7 +1048,8 @@ extern "C" int svjg_run_end(svjg_ctx *c, const uint8_t **gt, const int32_t **pl,
     uint8_t *hb = (uint8_t *)r.h;
     int rc;
     HIPCHK(c, hipEventSynchronize(r.copied));                              // the pass's one host wait
-    c->hs() = *(const DevStatus *)(hb + L.status);
+    const uint8_t *tail = hb + L.h_tail;
+    c->hs() = *(const DevStatus *)(tail + L.status);
     // ---- what the host would have decided in between ----
     c->ms_slow = 0;
     if (r.had_text) {
@@ -1017,6 +1059,7 @@ extern "C" int svjg_run_end(svjg_ctx *c, const uint8_t **gt, const int32_t **pl,
     if (n_rows) HIPCHK(c, hipEventElapsedTime(&c->ms_geno, r.ev[4], r.ev[5]));
     const uint64_t wave_limit = 16 * (uint64_t)c->n_cu * 4;
     bool again = false;
+    const unsigned long long *redo_counts = r.counts;             // (a repeated genotype pass reads the slot's vector, or d_counts after the step-by-step fallback)
     if (c->hs().overflow || c->hs().n_deferred > wave_limit) {
         // the list of deferred lines was too short, or holds more lines than one wave per line is good for: the pass again, step by
         // step (classify_range sizes the list, picks the exact-path kernel and retries), behind whatever is enqueued already
@@ -1024,34 +1067,34 @@ extern "C" int svjg_run_end(svjg_ctx *c, const uint8_t **gt, const int32_t **pl,
         rc = classify_range(c, 0, n, r.base_offset, 0);
         if (rc) return rc;
         if (c->comm && (rc = svjg_allreduce_counts(c))) return rc;
-        again = true;
+        again = true; redo_counts = c->d_counts;
     } else {
         c->total_deferred = c->hs().n_deferred;
         if (c->hs().err != ~0ull) return SVJG_E_INPUT;
         if (c->hs().n_host) { c->err = "the text holds lines only the host can decide (non-ASCII digits in a decimal column: svjg_get_host_lines); classify it with svjg_classify"; return SVJG_E_ARG; }
         if (c->comm) {
-            const unsigned long long *gd = (const unsigned long long *)(hb + L.guard);
+            const unsigned long long *gd = (const unsigned long long *)(tail + L.guard);
             if (gd[0] >= (1ull << 32) || gd[1] >= (1ull << 32)) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
         }
     }
     if (n_rows) {
         for (int attempt = 0;; ++attempt) {
             if (!again) {
-                if (*(const unsigned int *)(hb + L.maxn + 4)) { c->err = "slot out of range"; return SVJG_E_ARG; }
-                const unsigned int max_n = *(const unsigned int *)(hb + L.maxn);
+                if (*(const unsigned int *)(tail + L.maxn + 4)) { c->err = "slot out of range"; return SVJG_E_ARG; }
+                const unsigned int max_n = *(const unsigned int *)(tail + L.maxn);
                 if (max_n == 0) break;                           // every row found its binomial term
                 if (attempt == 2) { c->err = "log10(i!) table could not be sized"; return SVJG_E_HIP; }
                 // (a pass already enqueued behind this one still uses the old table: it must drain before the table is replaced)
                 HIPCHK(c, hipStreamSynchronize(c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->copy_stream));
                 if ((rc = build_logfact(c, max_n + 1 + 1024))) return rc;
             }
             again = false;
-            // NOTE: with a second pass in flight the counts on the device are that pass's (same text, same rows: the same counts)
-            GenoArgs ga = run_geno_args(c, r, L, r.min_support, r.err);
+            GenoArgs ga = run_geno_args(c, r, L, r.min_support, r.err, redo_counts);
             HIPCHK(c, hipMemsetAsync(ga.max_n, 0, 8, c->stream));
             hipLaunchKernelGGL(k_genotype, dim3((uint32_t)((n_rows + TPB - 1) / TPB)), dim3(TPB), 0, c->stream, ga);
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(hb, r.d, L.out_bytes - 16 - ((sizeof(DevStatus) + 7) & ~7ull), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(hb + L.h_tail + L.maxn, (uint8_t *)r.d + L.maxn, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
     }

@@ -152,12 +152,11 @@ __device__ inline uint32_t name_word_mask(int32_t bits) {
     return (uint32_t)((0xFFFFFFFFull << n) >> 32);
 }
 typedef uint32_t u32_any __attribute__((aligned(1)));                   // LDS words at any byte address (gfx950 reads them as they are: tools/ubench/lds_unaligned.hip)
-__device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[NAME_WORDS]) {
+__device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
     const u32_any *w = (const u32_any *)(text + a0);
     uint64_t h = (uint64_t)L * 0x7FEB352Du;
     const uint32_t C[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du};
-#pragma unroll
-    for (uint32_t i = 6; i < NAME_WORDS; ++i) d[i] = 0u;
+    d[6] = 0u; d[7] = 0u;
     const int32_t bits = (int32_t)(8u * L);
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
@@ -166,7 +165,7 @@ __device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uin
     }
     return h;
 }
-__device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[NAME_WORDS]) {
+__device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
     const u32_any *w = (const u32_any *)(text + a0);
     const int32_t bits = (int32_t)(8u * L);
     const uint32_t x6 = w[6], x7 = w[7];
@@ -174,23 +173,24 @@ __device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uin
     d[7] = x7 & name_word_mask(bits - 224);
     return (uint64_t)d[6] * 0xFD7046C5u + (uint64_t)d[7] * 0xB55A4F09u;
 }
-__device__ inline uint64_t name_words_tail2(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[NAME_WORDS]) {
+// words 8..11 (names of 33..48 bytes) are not kept in registers while the record travels: they are read from the staged text twice,
+// for the hash and — in the branch only a pass with such a name takes — for the compare
+__device__ inline void name_words_far(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t f[4]) {
     const u32_any *w = (const u32_any *)(text + a0);
     const int32_t bits = (int32_t)(8u * L);
-    const uint32_t C[4] = {0x94D049BBu, 0xBF58476Du, 0x2545F491u, 0x9FB21C65u};
-    uint64_t h = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-        d[8 + i] = w[8 + i] & name_word_mask(bits - 32 * (int32_t)(8 + i));
-        h += (uint64_t)d[8 + i] * C[i];
-    }
-    return h;
+    for (uint32_t i = 0; i < 4; ++i) f[i] = w[8 + i] & name_word_mask(bits - 32 * (int32_t)(8 + i));
+}
+__device__ inline uint64_t name_words_tail2(const uint8_t *text, uint32_t a0, uint32_t L) {
+    uint32_t f[4];
+    name_words_far(text, a0, L, f);
+    return (uint64_t)f[0] * 0x94D049BBu + (uint64_t)f[1] * 0xBF58476Du + (uint64_t)f[2] * 0x2545F491u + (uint64_t)f[3] * 0x9FB21C65u;
 }
 
 // record of the node-name table (svjg_host_tables.h): r0 = name bytes 0..15, r1 = bytes 16..23 | meta | length in bp,
 // r2.xy = bytes 24..31 (only names longer than 24 bytes look at them); bytes 32..47 (r2.zw, r3.xy) are compared by the caller in
 // the branch only a pass with such a name takes
-__device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[NAME_WORDS], uint32_t L) {
+__device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[8], uint32_t L) {
     // one OR of differences instead of a chain of compares (three-input bit operations: (a ^ b) | c is one instruction)
     uint32_t diff = ((r1.z & NAME_LEN_MASK) ^ (L - 1u)) | (r0.x ^ d[0]) | (r0.y ^ d[1]) | (r0.z ^ d[2]) | (r0.w ^ d[3]) | (r1.x ^ d[4]) | (r1.y ^ d[5]);
     const uint32_t tail = (r2.x ^ d[6]) | (r2.y ^ d[7]);
@@ -466,6 +466,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         }
         if (ballot64(fl.high != 0) != 0 && lane == 0) a.st->non_ascii = 1;
         const bool idf = (IDM[0] | IDM[1]) != 0;                         // some line of the stripe may hold an "id:f:" tag: the line phase finds which
+        if (idf && lane == 0) {                                          // (kept in the line list's spare entries, not in scalar registers, until then)
+            LINE[MAXL + 4] = (uint32_t)IDM[0]; LINE[MAXL + 5] = (uint32_t)(IDM[0] >> 32); LINE[MAXL + 6] = (uint32_t)IDM[1]; LINE[MAXL + 7] = (uint32_t)(IDM[1] >> 32);
+        }
         tick(0);
         // does the stripe begin at a line start?  (wave-uniform)
         const uint32_t head = (head_byte == '\n') || (head_byte == '\r' && text[0] != '\n');
@@ -690,7 +693,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         const uint32_t sa = s >> 6, sb = ((nx != 0xFFFFu ? nx : Vh) - 1u) >> 6;
                         const unsigned long long m0 = low_bits64(sb + 1u < 64u ? sb + 1u : 64u) & ~low_bits64(sa < 64u ? sa : 64u);
                         const unsigned long long m1 = low_bits64(sb >= 64u ? sb - 63u : 0u) & ~low_bits64(sa > 64u ? sa - 64u : 0u);
-                        if (((IDM[0] & m0) | (IDM[1] & m1)) != 0ull) { ok = false; status = ST_DEFER + DC_IDF; }
+                        const unsigned long long i0 = (unsigned long long)LINE[MAXL + 4] | ((unsigned long long)LINE[MAXL + 5] << 32);
+                        const unsigned long long i1 = (unsigned long long)LINE[MAXL + 6] | ((unsigned long long)LINE[MAXL + 7] << 32);
+                        if (((i0 & m0) | (i1 & m1)) != 0ull) { ok = false; status = ST_DEFER + DC_IDF; }
                     }
                     if (!ok && status == ST_DEFER && kall > KMAX) status = ST_DEFER + DC_LONG_PATH;
                     else if (!ok && status == ST_DEFER && t5 == TEXT && t4 < TEXT && kfit) status = ST_DEFER + DC_NAME;   // (no tab within 49 bytes of the last mark: a name beyond 48 bytes)
@@ -733,12 +738,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t len = ((j + 1 < lk) ? (op2.y & 0xFFFFu) : rl.w) - na0;
                 const uint32_t oribit = text[opv] == '<' ? 1u : 0u;
                 const bool probe = live && len - 1u <= 4u * NAME_WORDS - 1u;   // names of 1..48 bytes; longer ones: exact path
-                uint32_t d[NAME_WORDS];
+                uint32_t d[8];
                 tick_mem(8);                                             // (list and per-line record read)
                 uint64_t h = name_words_head(text, na0, len, d);         // the first six words of the name
                 if (ballot64(probe && len > 24u)) h += name_words_tail(text, na0, len, d);   // (wave-uniform: node names of the usual length fit six words)
                 const bool long_names = ballot64(probe && len > 32u) != 0;                   // (wave-uniform: some name of the pass has 33..48 bytes)
-                if (long_names) h += name_words_tail2(text, na0, len, d);
+                if (long_names) h += name_words_tail2(text, na0, len);
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 bool row_inline = false;
                 // id << 8 | flags << 6 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
                 bool same = probe && name_match(r0, r1, r2, d, len);
-                if (long_names) same = same && (len <= 32u || ((r2.z ^ d[8]) | (r2.w ^ d[9]) | (r3.x ^ d[10]) | (r3.y ^ d[11])) == 0u);
+                if (long_names) { uint32_t f[4]; name_words_far(text, na0, probe ? len : 1u, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
                 if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = (r1.w >> 31) != 0; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
                 // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
@@ -1193,15 +1198,16 @@ __device__ inline int64_t trunc_dd(dd v) {               // int(Decimal): toward
     return (int64_t)t;
 }
 
+// (any grid: rows in strides of the grid.  svjg_run_begin launches a small one: there the kernel runs beside the next pass's classify
+//  kernel and is bound by PCIe — its results go straight to pinned host memory —, so it should hold few wave slots)
 __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
-    uint64_t r = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-    if (r >= a.n_rows) return;
+  for (uint64_t r = (uint64_t)blockIdx.x * TPB + threadIdx.x; r < a.n_rows; r += (uint64_t)gridDim.x * TPB) {
     uint32_t ref, alt;
     bool go = geno_gate(a, r, ref, alt);
     a.raw[r * 2] = go ? ref : 0; a.raw[r * 2 + 1] = go ? alt : 0;
     a.genotyped[r] = go;
     a.boundary[r] = 0;
-    if (!go) { a.gt[r] = 3; a.pl[r * 3] = a.pl[r * 3 + 1] = a.pl[r * 3 + 2] = 0; if (a.pl32) a.pl32[r * 3] = a.pl32[r * 3 + 1] = a.pl32[r * 3 + 2] = 0; return; }
+    if (!go) { a.gt[r] = 3; a.pl[r * 3] = a.pl[r * 3 + 1] = a.pl[r * 3 + 2] = 0; if (a.pl32) a.pl32[r * 3] = a.pl32[r * 3 + 1] = a.pl32[r * 3 + 2] = 0; continue; }
     double c1, c2; uint32_t r1, r2;
     geno_counts(a.sv_type[r], ref, alt, c1, c2, r1, r2);
     // products in double, sums exact (the reference adds Decimal images of the doubles, :295-297)
@@ -1235,6 +1241,7 @@ __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
     }
     if (wide) a.genotyped[r] = 3;
     if (near) a.boundary[r] = 1;
+  }
 }
 
 }  // namespace svjg
