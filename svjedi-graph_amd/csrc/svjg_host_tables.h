@@ -90,6 +90,7 @@ struct KernelTables {
     uint32_t names_skipped = 0;                               // node names the table cannot hold (> 32 bytes, id too large)
     std::vector<uint64_t> node_pre; std::vector<uint8_t> node_has;   // per node: name pre-hash, "is in the name table" (table checks)
     std::vector<uint32_t> node_slot;                          // per node: its record (table checks)
+    std::vector<uint32_t> kid, node_of_kid;                   // node index <-> the id the kernel sees (walk order: see build_kernel_tables)
 };
 
 // Two-choice placement by random-walk eviction.  pre[i] = pre-hash of key i; returns owner[slot] = key index or -1.
@@ -174,6 +175,18 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
         fprintf(stderr, "[svjg] kernel tables, %s: %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
         t_last = now;
     };
+    // The ids the kernel sees follow the order in which a walk along the genome meets the nodes: by chromosome and position, an
+    // insertion's node "c:p.n" BEFORE the reference node "c:p-e" that follows it in every path (the sorted node table has it behind:
+    // kind is the lower key bit).  The kernel skips its search for repeated names in lines whose ids rise or fall all the way.
+    kt.kid.assign((size_t)g.n_nodes, 0); kt.node_of_kid.assign((size_t)g.n_nodes, 0);
+    {
+        std::vector<uint32_t> ord((size_t)g.n_nodes);
+        for (uint32_t i = 0; i < g.n_nodes; ++i) ord[i] = i;
+        auto walk_key = [&](uint32_t i) { const uint64_t k = g.nodes[i].key; return (k & ~0xFFFFull) | (((k >> 15) & 1u) ? (k & 0x7FFFu) : 0x8000ull); };
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return walk_key(a) < walk_key(b); });
+        for (uint32_t r = 0; r < g.n_nodes; ++r) { kt.kid[ord[r]] = r; kt.node_of_kid[r] = ord[r]; }
+    }
+    const std::vector<uint32_t> &kid = kt.kid;
     std::vector<uint64_t> node_pre((size_t)g.n_nodes, 0);    // name pre-hash of every node the name table holds
     std::vector<uint8_t> node_has((size_t)g.n_nodes, 0);
     std::vector<uint32_t> node_slot((size_t)g.n_nodes, 0);
@@ -194,7 +207,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             uint32_t len_bp = kind ? nd.aux : nd.aux - pos + 1;
             if (len_bp & REC_ROW_INLINE) flags |= 2u;         // (no node is 2 Gbp long; keeps the flag bit free)
             for (uint32_t w = 0; w < NAME_WORDS; ++w) ent.push_back(d[w]);
-            ent.push_back(((uint32_t)i << NAME_ID_SHIFT) | (flags << NAME_LEN_BITS) | ((uint32_t)nm.size() - 1u));
+            ent.push_back((kid[i] << NAME_ID_SHIFT) | (flags << NAME_LEN_BITS) | ((uint32_t)nm.size() - 1u));
             ent.push_back(len_bp & ~REC_ROW_INLINE);
             hs.push_back(name_prehash(d, (uint32_t)nm.size()));
             key_node.push_back((uint32_t)i);
@@ -261,7 +274,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
                 const svjg_edge &ed = g.edges[rows[q]];
                 const uint32_t nh = ed.meta >> 2;
                 uint32_t *l = e + w0 + 2 * q;
-                l[0] = (ed.right << 2) | (ed.meta & 3u);
+                l[0] = (kid[ed.right] << 2) | (ed.meta & 3u);
                 if (nh == 1) l[1] = ed.h0;
                 else {
                     l[1] = REC_MANY | (uint32_t)kt.ihits.size();
@@ -287,7 +300,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             for (uint32_t i = a; i < b; ++i) {
                 const svjg_edge &ed = g.edges[i];
                 if (!node_has[n] || !node_has[ed.right]) continue;   // a node outside the name table sends its lines to the exact path anyway
-                uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
+                uint64_t key = ((uint64_t)kid[n] << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)kid[ed.right] << 1) | ((ed.meta >> 1) & 1u);
                 const uint32_t nh = ed.meta >> 2;
                 ent.push_back((uint32_t)key); ent.push_back((uint32_t)(key >> 32));
                 if (nh == 1) { ent.push_back(ed.h0); ent.push_back(LINK_NO_HIT); }

@@ -786,23 +786,31 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // -- first occurrence of every name in its line (the reference's list.index / str.split quirks): every lane looks at
                 //    the lanes below it, one DPP wave shift per distance (no LDS round trips), as far as the longest line of the pass
                 //    reaches.  key = id | line << 26: lanes of other lines never compare equal --
+                // A line whose node ids rise all the way, or fall all the way, cannot come back to a node (the ids follow the genome): only
+                // when some line of the pass does neither do the lanes of THOSE lines search, as far as the longest of them reaches.
+                const uint32_t nxv = lane_above((id << 1) | oribit);
+                const uint32_t idl = id, idr = nxv >> 1;
                 uint32_t f = lane;
                 {
-                    const uint32_t key = live ? (id | (ln << 26)) : NONE32;
-                    uint32_t y = key;
-                    for (uint32_t dd = 1; ballot64(j >= dd); dd += 4) {
-                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd;
-                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 1u;
-                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 2u;
-                        y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 3u;
+                    const uint32_t dir = idr > id ? 1u : idr < id ? 2u : 0u;
+                    const uint32_t dprev = lane_below(dir);
+                    const unsigned long long oddm = ballot64(live && j + 1 < lk && (dir == 0u || (j >= 1u && dir != dprev)));
+                    if (oddm) {
+                        const bool search = live && ((low_bits64(lk) << lnb) & oddm) != 0ull;      // this lane's line is one of them
+                        const uint32_t key = search ? (id | (ln << 26)) : NONE32;
+                        uint32_t y = key;
+                        for (uint32_t dd = 1; ballot64(search && j >= dd); dd += 4) {
+                            y = lane_below_or(y, NONE32); if (y == key) f = lane - dd;
+                            y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 1u;
+                            y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 2u;
+                            y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 3u;
+                        }
+                        if (!search) f = lane;                               // (a lane that did not look: NONE32 == NONE32 means nothing)
                     }
                 }
                 const bool revisits = ballot64(live && f != lane) != 0;  // wave-uniform: some line of the pass comes back to a node
-                tick(5);
                 // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
                 //    (str.split / list.index, filter-alignments.py:206, :269-271); equal names have equal ids and hashes --
-                const uint32_t nxv = lane_above((id << 1) | oribit);
-                const uint32_t idl = id, idr = nxv >> 1;
                 uint32_t fl = lane, fr = lane + 1u, pre_l = pre, pre_rx = pre, orl = oribit, orr = nxv & 1u;
                 if (revisits) {
                     fl = f; fr = lane_above(f);

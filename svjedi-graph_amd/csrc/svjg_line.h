@@ -39,6 +39,7 @@ struct GraphView {
     const uint32_t *name_ihits;  // hit lists of the records' inline links with more than one hit
     const uint32_t *name_tab;    // canonical node name -> node record (svjg_host_tables.h), 16 words (one 64-byte line) per slot
     const uint16_t *name_disp;   // perfect hash of the node names: displacement of every bucket
+    const uint32_t *node_of_kid; // the records hold the main kernel's node ids (walk order, svjg_host_tables.h): id -> index into nodes[] (exact path)
     uint32_t name_slots, name_buckets;
     uint32_t name_complete;      // every node name is in name_tab: a miss there means "no such node" (else: search the sorted table)
     const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 4 words per entry
@@ -246,7 +247,7 @@ SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
     if (meta == 0xFFFFFFFFu || (meta & NAME_LEN_MASK) != len - 1u) return NONE32;
     if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && (len <= 24u || (e[8] == d[6] && e[9] == d[7])) &&
         (len <= 32u || (e[10] == d[8] && e[11] == d[9] && e[12] == d[10] && e[13] == d[11])))
-        return meta >> NAME_ID_SHIFT;
+        return g.node_of_kid[meta >> NAME_ID_SHIFT];
     return NONE32;
 }
 

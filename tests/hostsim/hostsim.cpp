@@ -22,9 +22,9 @@ static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &has
     v.nodes = g->nodes; v.n_nodes = (uint32_t)g->n_nodes; v.edges = g->edges; v.hits = g->hits;
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
-    v.name_tab = nullptr; v.name_ihits = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
+    v.node_of_kid = nullptr; v.name_tab = nullptr; v.name_ihits = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
     if (kt) {                                                             // the exact path resolves names through the node-name table
-        v.name_tab = kt->names.data(); v.name_ihits = kt->ihits.data(); v.name_disp = kt->disp.data(); v.name_slots = kt->name_slots; v.name_buckets = kt->name_buckets;
+        v.node_of_kid = kt->node_of_kid.data(); v.name_tab = kt->names.data(); v.name_ihits = kt->ihits.data(); v.name_disp = kt->disp.data(); v.name_slots = kt->name_slots; v.name_buckets = kt->name_buckets;
         v.name_complete = (kt->names_left_out == 0 && kt->names_skipped == 0) ? 1u : 0u;
     }
     return v;
@@ -94,7 +94,7 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
         name_ent_words(e, d);
         const uint64_t h = name_prehash(d, name_ent_len(e));
         if (j != name_slot(h, kt.disp[name_bucket(h, kt.name_buckets)], kt.name_slots)) ++bad;   // the kernel's one probe lands here
-        const uint32_t id = name_ent_id(e);
+        const uint32_t id = kt.node_of_kid[name_ent_id(e)];    // (the record holds the kernel's id: walk order)
         if (!kt.node_has[id] || kt.node_slot[id] != j || kt.node_pre[id] != h) ++bad;
         const svjg_node &nd = g->nodes[id];
         uint32_t kind = (uint32_t)(nd.key >> 15) & 1u, pos = (uint32_t)(nd.key >> 16);
@@ -111,7 +111,7 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
             bool ok = false;
             for (uint32_t i = ra; i < rb; ++i) {
                 const svjg_edge &ed = g->edges[i];
-                if (((ed.right << 2) | (ed.meta & 3u)) != l[0]) continue;
+                if (((kt.kid[ed.right] << 2) | (ed.meta & 3u)) != l[0]) continue;
                 const uint32_t nh = ed.meta >> 2;
                 if (nh == 1) ok = l[1] == ed.h0;
                 else if (l[1] & REC_MANY) {
@@ -130,7 +130,7 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
     for (uint64_t n = 0; n < g->n_nodes; ++n)
         for (uint32_t i = g->nodes[n].row & 0x7FFFFFFFu; i < (g->nodes[n + 1].row & 0x7FFFFFFFu); ++i) {
             const svjg_edge &ed = g->edges[i];
-            uint64_t key = ((uint64_t)n << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)ed.right << 1) | ((ed.meta >> 1) & 1u);
+            uint64_t key = ((uint64_t)kt.kid[n] << 33) | ((uint64_t)(ed.meta & 1u) << 32) | ((uint64_t)kt.kid[ed.right] << 1) | ((ed.meta >> 1) & 1u);
             uint32_t s1, s2;
             if (!kt.node_has[n] || !kt.node_has[ed.right]) continue;          // such lines take the exact path
             link_slots(link_prehash(kt.node_pre[n], ed.meta & 1u, kt.node_pre[ed.right], (ed.meta >> 1) & 1u), kt.link_seed, kt.link_mask, s1, s2);
