@@ -488,12 +488,13 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         if (n_def && !(c->hs().overflow & 1u)) {
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
             const uint64_t max_blocks = (uint64_t)c->n_cu * 4;              // 32 KB of LDS each: four per CU
+            const uint64_t lane_blocks = (uint64_t)c->n_cu * (160u * 1024u / (SLOW_LANE_LDS + 1024u));   // the lane-per-line kernel: as many as its staging buffer admits
             if (n_def <= 16 * max_blocks) {
                 // few lines: one wave per line (latency of a line O(k) instead of O(k^2) name resolutions)
                 hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)(n_def < max_blocks ? n_def : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def, 0ull, 0ull);
             } else {
                 const uint64_t want_blocks = (n_def + SLOW_TPB - 1) / SLOW_TPB;
-                hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)(want_blocks < max_blocks ? want_blocks : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def, 0ull, 0ull);
+                hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)(want_blocks < lane_blocks ? want_blocks : lane_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def, 0ull, 0ull);
             }
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

@@ -963,7 +963,11 @@ struct SlowEmit {
 // the text byte by byte, so every wave first packs its 64 lines into LDS (each lane finds its line's terminator and
 // copies the line, 16 bytes per step) and the string logic then pays LDS latency per byte, not HBM latency.  A line
 // that does not fit (longer than SLOW_MAXLINE, or the 64 lines together exceed the buffer) is read in place.
+#ifndef SVJG_SLOW_LANE_LDS
+#define SVJG_SLOW_LANE_LDS (16 * 1024)   /* measured (tools/slowpath_bench.py, 1 M lines): 32 KB 61 ms, 16 KB 30 ms (eight blocks per CU: the register limit), 8 KB 41 ms (lines no longer fit) */
+#endif
 constexpr uint32_t SLOW_TPB = 64, SLOW_LDS = 32 * 1024, SLOW_MAXLINE = 16 * 1024;
+constexpr uint32_t SLOW_LANE_LDS = SVJG_SLOW_LANE_LDS;      // staging buffer of the one-lane-per-line kernel (64 lines: 16 KB holds lines of 256 bytes on average)
 // n_def = SLOW_ASK_DEVICE: the launch was enqueued right behind the main kernel without a host round trip (svjg_run_resident); the
 // number of deferred lines is what the main kernel left in the status block, and the kernel works only if it lies in (lo, hi]
 // (two launches share the range: one wave per line up to a limit, one lane per line beyond it).  A list that overflowed is not
@@ -977,7 +981,7 @@ __device__ inline uint64_t slow_n_def(const ClassifyArgs &a, uint64_t n_def, uin
 }
 __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint64_t n_def_arg, uint64_t lo, uint64_t hi) {
     const uint64_t n_def = slow_n_def(a, n_def_arg, lo, hi);
-    __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LANE_LDS];
     const uint32_t lane = threadIdx.x;
     for (uint64_t b0 = (uint64_t)blockIdx.x * SLOW_TPB; b0 < n_def; b0 += (uint64_t)gridDim.x * SLOW_TPB) {
         const bool have = b0 + lane < n_def;
@@ -995,10 +999,10 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
         }
         const uint64_t a0 = s & ~15ull;
         const uint64_t span = have ? ((e - a0 + 15) & ~15ull) : 0;        // bytes of the aligned blocks that hold the line
-        const uint32_t want = span <= SLOW_MAXLINE ? (uint32_t)span : 0u;
+        const uint32_t want = span <= (SLOW_MAXLINE < SLOW_LANE_LDS ? SLOW_MAXLINE : SLOW_LANE_LDS) ? (uint32_t)span : 0u;
         uint32_t tot;
         const uint32_t off = wave_excl_scan(want, tot);
-        const bool staged = have && want && off + want <= SLOW_LDS;
+        const bool staged = have && want && off + want <= SLOW_LANE_LDS;
         if (staged)
             for (uint32_t o = 0; o < want; o += 16) *(uint4 *)(stage + off + o) = *(const uint4 *)(a.gaf + a0 + o);
         __syncthreads();
