@@ -1023,9 +1023,13 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, r.computed, 0));
     if (n_rows) {
         HIPCHK(c, hipEventRecord(r.ev[4], c->copy_stream));
-        uint32_t gg = (uint32_t)((n_rows + TPB - 1) / TPB);
-        { const char *e = getenv("SVJG_GENO_GRID"); const uint32_t cap = e ? (uint32_t)atoi(e) : 64u; if (cap && gg > cap) gg = cap; }   // (few wave slots: see k_genotype)
-        hipLaunchKernelGGL(k_genotype, dim3(gg), dim3(TPB), 0, c->copy_stream, ga);
+        // one wave per CU (see k_genotype); SVJG_GENO_GRID / SVJG_GENO_BLOCK: measurement only
+        uint32_t gb = 64, gg = (uint32_t)c->n_cu;
+        { const char *e = getenv("SVJG_GENO_BLOCK"); if (e && atoi(e) > 0) gb = (uint32_t)atoi(e); }
+        { const char *e = getenv("SVJG_GENO_GRID"); if (e && atoi(e) > 0) gg = (uint32_t)atoi(e); }
+        if (gb > TPB) gb = TPB;
+        if ((uint64_t)gg * gb > n_rows + gb) gg = (uint32_t)((n_rows + gb - 1) / gb);
+        hipLaunchKernelGGL(k_genotype, dim3(gg), dim3(gb), 0, c->copy_stream, ga);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(r.ev[5], c->copy_stream));
     }

@@ -1210,10 +1210,12 @@ __device__ inline int64_t trunc_dd(dd v) {               // int(Decimal): toward
     return (int64_t)t;
 }
 
-// (any grid: rows in strides of the grid.  svjg_run_begin launches a small one: there the kernel runs beside the next pass's classify
-//  kernel and is bound by PCIe — its results go straight to pinned host memory —, so it should hold few wave slots)
+// (any grid and block size up to TPB: rows in strides of the grid.  svjg_run_begin launches one WAVE per CU: there the kernel runs beside the
+//  next pass's classify kernel and is bound by PCIe — its results go straight to pinned host memory.  A single wave of 56 VGPRs fits on a
+//  SIMD that holds three classify workers (3 x 128 + 56 <= 512), so the fourteen workers of a CU keep their places whichever kernel
+//  arrives first; a 256-thread block needs room on all four SIMDs and displaces a worker)
 __global__ __launch_bounds__(TPB) void k_genotype(GenoArgs a) {
-  for (uint64_t r = (uint64_t)blockIdx.x * TPB + threadIdx.x; r < a.n_rows; r += (uint64_t)gridDim.x * TPB) {
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (uint64_t)gridDim.x * blockDim.x) {
     uint32_t ref, alt;
     bool go = geno_gate(a, r, ref, alt);
     a.raw[r * 2] = go ? ref : 0; a.raw[r * 2 + 1] = go ? alt : 0;
