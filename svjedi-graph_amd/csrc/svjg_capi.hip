@@ -400,6 +400,7 @@ static int fetch_slot_counts(svjg_ctx *c) {
     const int k = c->counts_in_slot;
     c->counts_in_slot = -1;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->run[k].copied) HIPCHK(c, hipStreamWaitEvent(c->stream, c->run[k].copied, 0));   // (the pass's all-reduce runs on the second stream)
     HIPCHK(c, hipMemcpyAsync(c->d_counts, c->run[k].counts, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
@@ -716,14 +717,15 @@ extern "C" int svjg_comm_init(svjg_ctx *c, const char *id128, int n_ranks, int r
 }
 
 // the two guard elements behind the count vector <- largest ref / alt field (k_counts_guard)
-static int launch_guard(svjg_ctx *c, unsigned long long *counts = nullptr) {
+static int launch_guard(svjg_ctx *c, unsigned long long *counts = nullptr, hipStream_t stream = nullptr) {
     if (!counts) counts = c->d_counts;
+    if (!stream) stream = c->stream;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(counts + c->n_slots, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(counts + c->n_slots, 0, 16, stream));
     if (c->n_slots) {
         uint32_t grid = (c->n_slots + TPB - 1) / TPB;
         if (grid > 1024) grid = 1024;
-        hipLaunchKernelGGL(k_counts_guard, dim3(grid), dim3(TPB), 0, c->stream, counts, c->n_slots);
+        hipLaunchKernelGGL(k_counts_guard, dim3(grid), dim3(TPB), 0, stream, counts, c->n_slots);
         HIPCHK(c, hipGetLastError());
     }
     return 0;
@@ -1010,17 +1012,18 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(r.ev[2], c->stream));
     }
-    if (c->comm) {
-        if ((rc = launch_guard(c, r.counts))) return rc;
-        ncclResult_t nr = ncclAllReduce(r.counts, r.counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
-        if (nr != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(nr); return SVJG_E_RCCL; }
-        HIPCHK(c, hipMemcpyAsync(base + L.guard, r.counts + c->n_slots, 16, hipMemcpyDeviceToDevice, c->stream));
-    }
-    // The genotypes on the second stream, behind an event: the kernel writes its results straight into the pinned host block — they
-    // cross PCIe as they are produced —, which takes ~45 us for 100 k rows during which the compute stream already runs the next
-    // pass (that one zeroes and fills ITS count vector).
+    // Behind an event, on the second (low-priority) stream: the count all-reduce of this pass — every rank issues its collectives in
+    // the same order, one per pass —, then the genotypes: the kernel writes its results straight into the pinned host block — they
+    // cross PCIe as they are produced —, which takes ~45 us for 100 k rows.  Meanwhile the compute stream already runs the next pass
+    // (that one zeroes and fills ITS count vector).
     HIPCHK(c, hipEventRecord(r.computed, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, r.computed, 0));
+    if (c->comm) {
+        if ((rc = launch_guard(c, r.counts, c->copy_stream))) return rc;
+        ncclResult_t nr = ncclAllReduce(r.counts, r.counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->copy_stream);
+        if (nr != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(nr); return SVJG_E_RCCL; }
+        HIPCHK(c, hipMemcpyAsync(base + L.guard, r.counts + c->n_slots, 16, hipMemcpyDeviceToDevice, c->copy_stream));
+    }
     if (n_rows) {
         HIPCHK(c, hipEventRecord(r.ev[4], c->copy_stream));
         // one wave per CU (see k_genotype); SVJG_GENO_GRID / SVJG_GENO_BLOCK: measurement only
