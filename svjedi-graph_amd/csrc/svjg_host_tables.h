@@ -49,11 +49,11 @@ namespace svjg {
 // (a small array that stays cached), fetches the one record the name can be in and compares the spelling: no number
 // parsing on the device, and only names spelled exactly like the graph's can match (anything else: exact path).
 //   record = 16 words (one 64-byte line):
-//     [0..5] name bytes 0..23   [6] node id << 8 | flags << 6 | (byte length - 1)   (flags: bit 0 hazard-prone name,
+//     [0..5] the name's first three windows (svjg_line.h: name_windows)   [6] node id << 8 | flags << 6 | (byte length - 1)   (flags: bit 0 hazard-prone name,
 //     bit 1 length unknown; all ones = empty slot)   [7] node length in bp | REC_ROW_INLINE if the node has no other links
 //     than the inline ones
-//     names of up to 24 bytes: [8..15] = four inline links;  25..32 bytes: [8..9] = name bytes 24..31, [10..15] = three
-//     inline links;  33..48 bytes (contig names like chr1_KI270706v1_random): [8..13] = name bytes 24..47, [14..15] = one
+//     names of up to 24 bytes: [8..15] = four inline links;  25..32 bytes: [8..9] = window words 6, 7, [10..15] = three
+//     inline links;  33..48 bytes (contig names like chr1_KI270706v1_random): [8..13] = window words 6..11, [14..15] = one
 //     inline link.  An inline link = two words: key = right id << 2 | left strand | right strand << 1 (all ones = none),
 //     value = the hit (slot << 1 | allele) of a one-hit link, or REC_MANY | index into the inline hit list
 //     (ihits[index] = number of hits, then the hits).  Reference-allele links come first.  Nearly every path step is
@@ -201,8 +201,8 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             std::string nm(g.chrom_names + g.chrom_off[c], g.chrom_off[c + 1] - g.chrom_off[c]);
             nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
             if (nm.size() > 4 * NAME_WORDS || i > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path
-            uint32_t d[NAME_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (size_t b = 0; b < nm.size(); ++b) d[b >> 2] |= (uint32_t)(uint8_t)nm[b] << (8 * (b & 3));
+            uint32_t d[NAME_WORDS];
+            name_windows(nm.data(), 0, (uint32_t)nm.size(), d);
             uint32_t flags = ((nd.row & 0x80000000u) ? 1u : 0u) | ((kind && nd.aux == SVJG_LEN_UNKNOWN) ? 2u : 0u);
             uint32_t len_bp = kind ? nd.aux : nd.aux - pos + 1;
             if (len_bp & REC_ROW_INLINE) flags |= 2u;         // (no node is 2 Gbp long; keeps the flag bit free)

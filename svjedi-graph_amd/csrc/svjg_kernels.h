@@ -122,6 +122,17 @@ __device__ inline void wave_incl_scan2(uint32_t &x, uint32_t &y) {
 }
 // ballot without the bool -> int detour of __ballot (one v_cmp into an SGPR pair), value of a lane whose number is wave-uniform
 __device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Lane predicates as wave masks.  A ballot of a COMPOUND condition (a && b) costs two extra vector instructions with this compiler
+// (the and of two compares lives in an SGPR pair, is turned into 0 / 1 per lane and compared again); a compare that yields its mask
+// at once (llvm.amdgcn.icmp), scalar logic on the masks, and a mask taken as a lane predicate where one is needed cost none.
+typedef unsigned long long wmask;
+__device__ inline wmask m_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
+__device__ inline wmask m_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
+__device__ inline wmask m_gt(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 34); }
+__device__ inline wmask m_ge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35); }
+__device__ inline wmask m_lt(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 36); }
+__device__ inline wmask m_le(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
+__device__ inline bool in_mask(wmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }   // this lane's bit of a wave-uniform mask
 __device__ inline uint32_t rdlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 // value of the lane below, lane 0 gets `first`
 __device__ inline uint32_t lane_below_or(uint32_t v, uint32_t first) { return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
@@ -142,44 +153,43 @@ enum : uint32_t { DC_COLUMNS = 0,      // the line's columns are not twelve plai
                   DC_STRIPE = 4,       // the whole stripe: denser than the lists hold, a line longer than the staged text, or the caller asked for the exact path
                   DC_N = 5 };
 
-// Path segment text[a0, a0+L), 1 <= L <= 48: its twelve zero-padded words -> d, and the 64-bit pre-hash of the node-name table
-// (svjg_line.h: name_prehash), in three parts: words 0..5 (enough for names of up to 24 bytes; d[6..11] = 0), words 6 and 7
-// (names of 25..32 bytes) and words 8..11 (33..48 bytes: contig names like chr1_KI270706v1_random), each with what it adds to the hash.
-// words in front of word L / 4 are name bytes only, that word keeps its first L % 4 bytes, the ones behind it are zero
-// the low min(max(bits, 0), 32) bits set (bits = name bits left from this word on): high half of 0x00000000FFFFFFFF << that
-__device__ inline uint32_t name_word_mask(int32_t bits) {
-    const uint32_t n = (uint32_t)(bits < 0 ? 0 : bits > 32 ? 32 : bits);       // (one v_med3_i32)
-    return (uint32_t)((0xFFFFFFFFull << n) >> 32);
-}
-typedef uint32_t u32_any __attribute__((aligned(1)));                   // LDS words at any byte address (gfx950 reads them as they are: tools/ubench/lds_unaligned.hip)
-__device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
-    const u32_any *w = (const u32_any *)(text + a0);
-    uint64_t h = (uint64_t)L * 0x7FEB352Du;
-    const uint32_t C[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du};
-    d[6] = 0u; d[7] = 0u;
-    const int32_t bits = (int32_t)(8u * L);
-#pragma unroll
-    for (uint32_t i = 0; i < 6; ++i) {
-        d[i] = w[i] & name_word_mask(bits - 32 * (int32_t)i);
-        h += (uint64_t)d[i] * C[i];
+// Path segment text[a0, a0+L), 1 <= L <= 48: its window words (svjg_line.h: name_windows) and the 64-bit pre-hash of the node-name
+// table (name_prehash), in three parts: words 0..5 (three 8-byte windows that cover a name of up to 24 bytes; d[6..7] = 0), words 6
+// and 7 (names of 25..32 bytes) and words 8..11 (33..48 bytes: contig names like chr1_KI270706v1_random), each with what it adds to
+// the hash.  A window ends where the name ends at the latest, so the words are read from the staged text as they are (LDS words at
+// any byte address: tools/ubench/lds_unaligned.hip); only a name of fewer than eight bytes has foreign bytes in its windows, and
+// `any_short` (wave-uniform) says whether some lane of the pass holds one.
+typedef uint32_t u32_any __attribute__((aligned(1)));
+typedef unsigned long long u64_any __attribute__((aligned(1)));
+__device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uint32_t L, bool any_short, uint32_t d[8]) {
+    const uint32_t o2 = (uint32_t)min(max((int32_t)L - 8, 0), 16), o1 = o2 >> 1;   // (svjg_line.h: name_windows)
+    const uint8_t *p = text + a0;
+    unsigned long long w0 = *(const u64_any *)p, w1 = *(const u64_any *)(p + o1), w2 = *(const u64_any *)(p + o2);
+    if (any_short) {                                                  // (o1 = o2 = 0 for these lanes: all three windows are the first eight bytes)
+        const unsigned long long m = L < 8u ? ~(~0ull << (8u * L)) : ~0ull;
+        w0 &= m; w1 &= m; w2 &= m;
     }
+    d[0] = (uint32_t)w0; d[1] = (uint32_t)(w0 >> 32); d[2] = (uint32_t)w1; d[3] = (uint32_t)(w1 >> 32); d[4] = (uint32_t)w2; d[5] = (uint32_t)(w2 >> 32);
+    d[6] = 0u; d[7] = 0u;
+    const uint32_t C[6] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du};
+    uint64_t h = (uint64_t)L * 0x7FEB352Du;
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) h += (uint64_t)d[i] * C[i];
     return h;
 }
+// (L is a probed lane's length — 1..48 — or 8 for the others: the addresses stay inside the staged text)
 __device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t d[8]) {
-    const u32_any *w = (const u32_any *)(text + a0);
-    const int32_t bits = (int32_t)(8u * L);
-    const uint32_t x6 = w[6], x7 = w[7];
-    d[6] = x6 & name_word_mask(bits - 192);
-    d[7] = x7 & name_word_mask(bits - 224);
+    const unsigned long long w = *(const u64_any *)(text + a0 + (L > 24u ? L - 8u : 0u));
+    d[6] = L > 24u ? (uint32_t)w : 0u;
+    d[7] = L > 24u ? (uint32_t)(w >> 32) : 0u;
     return (uint64_t)d[6] * 0xFD7046C5u + (uint64_t)d[7] * 0xB55A4F09u;
 }
 // words 8..11 (names of 33..48 bytes) are not kept in registers while the record travels: they are read from the staged text twice,
 // for the hash and — in the branch only a pass with such a name takes — for the compare
 __device__ inline void name_words_far(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t f[4]) {
-    const u32_any *w = (const u32_any *)(text + a0);
-    const int32_t bits = (int32_t)(8u * L);
+    const u32_any *w = (const u32_any *)(text + a0 + (L > 32u ? L - 24u : 0u));
 #pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) f[i] = w[8 + i] & name_word_mask(bits - 32 * (int32_t)(8 + i));
+    for (uint32_t i = 0; i < 4; ++i) f[i] = L > 32u ? w[i] : 0u;
 }
 __device__ inline uint64_t name_words_tail2(const uint8_t *text, uint32_t a0, uint32_t L) {
     uint32_t f[4];
@@ -187,8 +197,8 @@ __device__ inline uint64_t name_words_tail2(const uint8_t *text, uint32_t a0, ui
     return (uint64_t)f[0] * 0x94D049BBu + (uint64_t)f[1] * 0xBF58476Du + (uint64_t)f[2] * 0x2545F491u + (uint64_t)f[3] * 0x9FB21C65u;
 }
 
-// record of the node-name table (svjg_host_tables.h): r0 = name bytes 0..15, r1 = bytes 16..23 | meta | length in bp,
-// r2.xy = bytes 24..31 (only names longer than 24 bytes look at them); bytes 32..47 (r2.zw, r3.xy) are compared by the caller in
+// record of the node-name table (svjg_host_tables.h): r0 = window words 0..3, r1 = words 4, 5 | meta | length in bp,
+// r2.xy = words 6, 7 (only names longer than 24 bytes look at them); words 8..11 (r2.zw, r3.xy) are compared by the caller in
 // the branch only a pass with such a name takes
 __device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2, const uint32_t d[8], uint32_t L) {
     // one OR of differences instead of a chain of compares (three-input bit operations: (a ^ b) | c is one instruction)
@@ -713,37 +723,43 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             tick(3);
             if (DIAG(2u)) continue;                                      // measurement only: stop after R1
             // ---- node passes: up to 64 consecutive marks that cover whole lines; one mark (path node) per lane ----------------
+            const wmask ok_lines = m_eq(status, ST_OK);                  // (lanes beyond cnt: ST_NONE)
+            const uint32_t relend = rel + kall;
             for (uint32_t i0 = 0; i0 < cnt;) {
                 const uint32_t p0 = rdlane(rel, i0);
-                const unsigned long long nofit = ballot64(lane >= i0 && lane < cnt && rel + kall - p0 > 64u);
+                const wmask nofit = m_gt(relend - p0, 64u) & low_bits64(cnt) & ~low_bits64(i0);
                 uint32_t i1 = nofit ? (uint32_t)__builtin_ctzll(nofit) : cnt;
                 if (i1 == i0) { ++i0; continue; }                        // a line with more than 64 marks (> KMAX): already deferred
-                const uint32_t n_pass = rdlane(rel + kall, i1 - 1) - p0;
-                const unsigned long long okl = ballot64(lane >= i0 && lane < i1 && status == ST_OK);
+                const uint32_t n_pass = rdlane(relend, i1 - 1) - p0;
+                const wmask okl = ok_lines & low_bits64(i1) & ~low_bits64(i0);
                 i0 = i1;
                 if (!okl) continue;                                      // no line of the pass has a path to look at
                 __builtin_amdgcn_s_setprio(P_LOAD);
                 // -- the node of this lane: line, index in the line, name.  Every lane runs the same straight code on indices that
                 //    are safe to read (a lane beyond the pass looks at the pass's first mark); `live` says whose results count --
-                const bool act = lane < n_pass;
+                const wmask act_m = low_bits64(n_pass);
+                const bool act = in_mask(act_m);
                 const uint32_t o = obase + p0 + (act ? lane : 0u);
                 const uint2 op2 = *(const uint2 *)(OPL + o);             // (8-byte aligned or not: two dwords)
                 const uint32_t opv = op2.x & 0xFFFFu;
                 const uint32_t ln = ((op2.x >> 16) - lbase) & (LRW - 1u);
                 const uint4 rl = RL[ln];
                 const uint32_t meta = rl.z, need_l = rl.x, need_r = rl.y;
-                bool live = act && (meta >> 24) == ST_OK;
+                wmask live_m = act_m & m_eq(meta >> 24, ST_OK);
+                bool live = in_mask(live_m);
                 uint32_t lnb = live ? (meta & 0xFFFFu) - p0 : 0u, lk = live ? (meta >> 16) & 0xFFu : 0u, j = live ? lane - lnb : 0u;
                 const uint32_t na0 = opv + 1u;
                 const uint32_t len = ((j + 1 < lk) ? (op2.y & 0xFFFFu) : rl.w) - na0;
                 const uint32_t oribit = text[opv] == '<' ? 1u : 0u;
-                const bool probe = live && len - 1u <= 4u * NAME_WORDS - 1u;   // names of 1..48 bytes; longer ones: exact path
+                const wmask probe_m = live_m & m_le(len - 1u, 4u * NAME_WORDS - 1u);   // names of 1..48 bytes; longer ones: exact path
+                const bool probe = in_mask(probe_m);
                 uint32_t d[8];
                 tick_mem(8);                                             // (list and per-line record read)
-                uint64_t h = name_words_head(text, na0, len, d);         // the first six words of the name
-                if (ballot64(probe && len > 24u)) h += name_words_tail(text, na0, len, d);   // (wave-uniform: node names of the usual length fit six words)
-                const bool long_names = ballot64(probe && len > 32u) != 0;                   // (wave-uniform: some name of the pass has 33..48 bytes)
-                if (long_names) h += name_words_tail2(text, na0, len);
+                const uint32_t plen = probe ? len : 8u;                  // (keeps the longer names' window addresses inside the staged text)
+                uint64_t h = name_words_head(text, na0, len, (probe_m & m_lt(len, 8u)) != 0, d);   // the first three windows of the name
+                if (probe_m & m_gt(len, 24u)) h += name_words_tail(text, na0, plen, d);      // (wave-uniform: node names of the usual length fit three windows)
+                const bool long_names = (probe_m & m_gt(len, 32u)) != 0;                     // (wave-uniform: some name of the pass has 33..48 bytes)
+                if (long_names) h += name_words_tail2(text, na0, plen);
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
@@ -760,20 +776,21 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 }
                 __builtin_amdgcn_s_setprio(P_REST);
                 uint32_t id = NONE32, lbp = 0;
-                bool row_inline = false;
+                uint32_t row_inline = 0;
                 // id << 8 | flags << 6 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
                 bool same = probe && name_match(r0, r1, r2, d, len);
-                if (long_names) { uint32_t f[4]; name_words_far(text, na0, probe ? len : 1u, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
-                if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = (r1.w >> 31) != 0; }
+                if (long_names) { uint32_t f[4]; name_words_far(text, na0, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
+                if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = r1.w >> 31; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
                 // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
                 // (all nodes of a line sit in this pass).  Ordinary text never gets here.
                 {
-                    const bool bad = live && (id == NONE32 || lbp >= (1u << 25));
-                    if (ballot64(bad)) {
-                        if (bad) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | ((ST_DEFER + DC_NAME) << 24);
+                    const wmask bad = live_m & (m_eq(id, NONE32) | m_ge(lbp, 1u << 25));
+                    if (bad) {
+                        if (in_mask(bad)) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | ((ST_DEFER + DC_NAME) << 24);
                         wave_sync();
-                        if ((((const uint32_t *)&RL[ln])[2] >> 24) != ST_OK) live = false;
+                        live_m &= m_eq(((const uint32_t *)&RL[ln])[2] >> 24, ST_OK);
+                        live = in_mask(live_m);
                     }
                 }
                 if (!live) { j = 0; lk = 0; lnb = 0; id = NONE32; lbp = 0; }
@@ -788,18 +805,20 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 //    reaches.  key = id | line << 26: lanes of other lines never compare equal --
                 // A line whose node ids rise all the way, or fall all the way, cannot come back to a node (the ids follow the genome): only
                 // when some line of the pass does neither do the lanes of THOSE lines search, as far as the longest of them reaches.
+                const wmask step_m = m_lt(j + 1u, lk);                   // lanes with a step to the next node of their line (a dead lane: lk = 0)
                 const uint32_t nxv = lane_above((id << 1) | oribit);
                 const uint32_t idl = id, idr = nxv >> 1;
                 uint32_t f = lane;
                 {
                     const uint32_t dir = idr > id ? 1u : idr < id ? 2u : 0u;
                     const uint32_t dprev = lane_below(dir);
-                    const unsigned long long oddm = ballot64(live && j + 1 < lk && (dir == 0u || (j >= 1u && dir != dprev)));
+                    const wmask oddm = step_m & (m_eq(dir, 0u) | (m_ge(j, 1u) & m_ne(dir, dprev)));
                     if (oddm) {
-                        const bool search = live && ((low_bits64(lk) << lnb) & oddm) != 0ull;      // this lane's line is one of them
+                        const wmask search_m = live_m & ballot64(((low_bits64(lk) << lnb) & oddm) != 0ull);   // this lane's line is one of them
+                        const bool search = in_mask(search_m);
                         const uint32_t key = search ? (id | (ln << 26)) : NONE32;
                         uint32_t y = key;
-                        for (uint32_t dd = 1; ballot64(search && j >= dd); dd += 4) {
+                        for (uint32_t dd = 1; search_m & m_ge(j, dd); dd += 4) {
                             y = lane_below_or(y, NONE32); if (y == key) f = lane - dd;
                             y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 1u;
                             y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 2u;
@@ -808,12 +827,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (!search) f = lane;                               // (a lane that did not look: NONE32 == NONE32 means nothing)
                     }
                 }
-                const bool revisits = ballot64(live && f != lane) != 0;  // wave-uniform: some line of the pass comes back to a node
+                const bool revisits = m_ne(f, lane) != 0;                // wave-uniform: some line of the pass comes back to a node
                 // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
                 //    (str.split / list.index, filter-alignments.py:206, :269-271); equal names have equal ids and hashes --
                 uint32_t fl = lane, fr = lane + 1u, pre_l = pre, pre_rx = pre, orl = oribit, orr = nxv & 1u;
+                wmask moved_m = 0;
                 if (revisits) {
                     fl = f; fr = lane_above(f);
+                    moved_m = m_ne(fl, lane) | m_ne(fr, lane + 1u);
                     pre_l = (uint32_t)__shfl((int)pre, (int)fl);
                     pre_rx = (uint32_t)__shfl((int)pre, (int)((fr - 1u) & 63u));
                     orl = (uint32_t)__shfl((int)oribit, (int)fl); orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
@@ -821,20 +842,23 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // overlap test of the step (a lane without a step fails it); then the link is looked for among the (up to four)
                 // that sit in the left node's record — straight selects, no branches —; the link table is asked only if it is not
                 // there and the node has more links, or for a revisited node (the link between the first occurrences)
-                const bool go = live && j + 1 < lk && pre_l >= need_l && tot - (fr > lnb ? pre_rx : 0u) >= need_r;
-                const bool moved = revisits && (fl != lane || fr != lane + 1u);
+                const wmask go_m = step_m & m_ge(pre_l, need_l) & m_ge(tot - (fr > lnb ? pre_rx : 0u), need_r);
                 const uint32_t want = (idr << 2) | orl | (orr << 1);
-                const bool m0 = len <= 24u && r2.x == want, m1 = len <= 32u && r2.z == want, m2 = len <= 32u && r3.x == want, m3 = r3.z == want;   // (a longer name's bytes sit where the first links would)
-                const bool inl = m0 || m1 || m2 || m3;
-                const uint32_t v = m0 ? r2.y : m1 ? r2.w : m2 ? r3.y : r3.w;
-                const bool found = go && !moved && inl;
-                const bool ask = go && (moved || (!inl && !row_inline));
-                uint32_t nh = found ? 1u : 0u, h0 = v, h1 = 0;
+                const wmask le24 = m_le(len, 24u), le32 = m_le(len, 32u);   // (a longer name's bytes sit where the first links would)
+                const wmask m0 = le24 & m_eq(r2.x, want), m1 = le32 & m_eq(r2.z, want), m2 = le32 & m_eq(r3.x, want), m3 = m_eq(r3.z, want);
+                const wmask inl = m0 | m1 | m2 | m3;
+                const uint32_t v = in_mask(m0) ? r2.y : in_mask(m1) ? r2.w : in_mask(m2) ? r3.y : r3.w;
+                const wmask found_m = go_m & ~moved_m & inl;
+                const wmask ask_m = go_m & (moved_m | ~(inl | m_ne(row_inline, 0u)));
+                const bool ask = in_mask(ask_m);
+                // hits of the lane: count; bit 31: they are in a list (hp), else in h0 (and h1)
+                uint32_t nh = in_mask(found_m) ? 1u : 0u, h0 = v, h1 = 0;
                 const uint32_t *hp = nullptr;                             // more than two hits: the list
-                if (ballot64(found && (v & 0x80000000u))) {              // (wave-uniform: a link with several hits)
-                    if (found && (v & 0x80000000u)) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1]; }
+                {
+                    const wmask many = found_m & m_ge(v, 0x80000000u);   // (wave-uniform: a link with several hits)
+                    if (many) { if (in_mask(many)) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1] | 0x80000000u; } }
                 }
-                if (ballot64(ask)) {
+                if (ask_m) {
                     const uint64_t hl = h;                               // (the first occurrence spells the same name)
                     const uint64_t hr = ((uint64_t)lane_above((uint32_t)(h >> 32)) << 32) | lane_above((uint32_t)h);
                     if (ask) {
@@ -846,7 +870,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (!(ek.x == klo && ek.y == khi)) ek = ek2;                          // the other candidate slot
                         if (ek.x == klo && ek.y == khi) {
                             // one hit: (hit, NO_HIT); two: (hit, hit); more: (MANY | index into hits[], count)
-                            if ((ek.z & 0x80000000u) && ek.w != 0xFFFFFFFFu && ek.z != 0xFFFFFFFFu) { hp = g.hits + (ek.z & 0x7FFFFFFFu); nh = ek.w; }
+                            if ((ek.z & 0x80000000u) && ek.w != 0xFFFFFFFFu && ek.z != 0xFFFFFFFFu) { hp = g.hits + (ek.z & 0x7FFFFFFFu); nh = ek.w | 0x80000000u; }
                             else { h0 = ek.z; h1 = ek.w; nh = ek.w == 0xFFFFFFFFu ? 1u : 2u; }
                         }
                     }
@@ -854,7 +878,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // hit records: one aggregated atomic per wave reserves the slots
                 unsigned long long rbase = 0;
                 if (a.want_hits) {
-                    uint32_t wtot2, ex = wave_excl_scan(nh, wtot2);
+                    uint32_t wtot2, ex = wave_excl_scan(nh & 0x7FFFFFFFu, wtot2);
                     if (wtot2) {
                         if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot2);
                         rbase = __shfl(rbase, 0) + ex;
@@ -872,9 +896,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         } else atomicOr(&a.st->overflow, 2u);
                     }
                 };
-                if (nh && !hp) emit(h0, 0);                              // the usual case: one hit, held in a register
-                if (ballot64(nh > 1u || (nh && hp))) {
-                    for (uint32_t jj = hp ? 0u : 1u; jj < nh; ++jj) emit(hp ? hp[jj] : h1, jj);
+                if (in_mask(m_le(nh - 1u, 1u))) emit(h0, 0);            // the usual case: one hit (or two), held in registers
+                if (m_gt(nh, 1u)) {
+                    const uint32_t n = nh & 0x7FFFFFFFu;
+                    for (uint32_t jj = hp ? 0u : 1u; jj < n; ++jj) emit(hp ? hp[jj] : h1, jj);
                 }
                 tick(6);
             }

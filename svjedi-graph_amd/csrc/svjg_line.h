@@ -48,14 +48,35 @@ struct GraphView {
 
 
 // ---- perfect hash of the node names (hash and displace; built by svjg_host_tables.h) -------------------------------
-// pre-hash = 64-bit multilinear sum of the name's twelve zero-padded words and its length; bucket from the pre-hash,
+// pre-hash = 64-bit multilinear sum of the name's twelve WINDOW WORDS and its length; bucket from the pre-hash,
 // slot from the pre-hash and the bucket's displacement: every name of the graph has a slot of its own, so a lookup
 // touches one 2-byte displacement (a small, cache-resident array) and exactly ONE 64-byte record.
+//
+// Window words (name_windows): a name is hashed and compared through 8-byte windows that END where the name ends, so the
+// kernel reads them from the staged text as they are — no masking of the bytes behind a name, which was 30 of the node
+// pass's instructions.  For a name of len bytes, o2 = min(max(len - 8, 0), 16) and o1 = o2 / 2:
+//     d[0..1] = bytes [0, 8)      d[2..3] = bytes [o1, o1 + 8)      d[4..5] = bytes [o2, o2 + 8)          (they cover a name of 8..24 bytes)
+//     d[6..7] = bytes [len - 8, len) if len > 24, else 0                                        (.. of 25..32 bytes)
+//     d[8..11] = bytes [len - 24, len - 8) if len > 32, else 0                                  (.. of 33..48 bytes)
+// Only a name shorter than 8 bytes has bytes behind its end in a window (all three are [0, 8) then): those read as zero.
+// (windows, len) determine the name, so comparing them is comparing the spelling.
 SVJG_HD uint32_t fmix32(uint32_t z) { z ^= z >> 16; z *= 0x7FEB352Du; z ^= z >> 15; z *= 0x846CA68Bu; z ^= z >> 16; return z; }
 SVJG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-constexpr uint32_t NAME_WORDS = 12;                               // a node name of the main kernel: up to 48 bytes, zero padded
+constexpr uint32_t NAME_WORDS = 12;                               // a node name of the main kernel: up to 48 bytes, as window words
 constexpr uint32_t NAME_LEN_BITS = 6, NAME_LEN_MASK = 63u;        // record word 6 = id << 8 | flags << 6 | (byte length - 1)
 constexpr uint32_t NAME_FLAG_HAZARD = 1u << 6, NAME_FLAG_NOLEN = 1u << 7, NAME_ID_SHIFT = 8;
+template <class P>
+SVJG_HD void name_windows(P t, uint64_t s, uint32_t len, uint32_t d[NAME_WORDS]) {      // 1 <= len <= 48 bytes at t[s ..]
+    const uint32_t o2 = len < 8u ? 0u : (len - 8u < 16u ? len - 8u : 16u), o1 = o2 >> 1;
+    auto word = [&](uint32_t at) -> uint32_t {                   // four bytes from name offset `at`, zero behind the name's end
+        uint32_t w = 0;
+        for (uint32_t b = 0; b < 4; ++b) if (at + b < len) w |= (uint32_t)(uint8_t)t[s + at + b] << (8 * b);
+        return w;
+    };
+    d[0] = word(0); d[1] = word(4); d[2] = word(o1); d[3] = word(o1 + 4); d[4] = word(o2); d[5] = word(o2 + 4);
+    d[6] = len > 24u ? word(len - 8u) : 0u; d[7] = len > 24u ? word(len - 4u) : 0u;
+    for (uint32_t i = 0; i < 4; ++i) d[8 + i] = len > 32u ? word(len - 24u + 4u * i) : 0u;
+}
 SVJG_HD uint64_t name_prehash(const uint32_t d[NAME_WORDS], uint32_t len) {
     const uint32_t C[NAME_WORDS] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u,
                                     0x94D049BBu, 0xBF58476Du, 0x2545F491u, 0x9FB21C65u};
@@ -238,8 +259,8 @@ SVJG_HD bool next_node(P t, uint64_t pe, bool oriented, uint64_t &pos, NameRef &
 template <class P>
 SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
     const uint32_t len = (uint32_t)(nm.e - nm.s);
-    uint32_t d[NAME_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t b = 0; b < len; ++b) d[b >> 2] |= (uint32_t)(uint8_t)t[nm.s + b] << (8 * (b & 3));
+    uint32_t d[NAME_WORDS];
+    name_windows(t, nm.s, len, d);
     const uint64_t h = name_prehash(d, len);
     const uint32_t slot = name_slot(h, g.name_disp[name_bucket(h, g.name_buckets)], g.name_slots);
     const uint32_t *e = g.name_tab + (uint64_t)slot * 16;

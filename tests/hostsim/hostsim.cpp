@@ -8,6 +8,7 @@
 #include "../../svjedi-graph_amd/csrc/svjg_host_tables.h"
 #include "../../svjedi-graph_amd/csrc/svjg_planes.h"
 #include <cstring>
+#include <string>
 #include <vector>
 
 using namespace svjg;
@@ -99,7 +100,14 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
         const svjg_node &nd = g->nodes[id];
         uint32_t kind = (uint32_t)(nd.key >> 15) & 1u, pos = (uint32_t)(nd.key >> 16);
         if ((e[7] & ~REC_ROW_INLINE) != (kind ? nd.aux : nd.aux - pos + 1) && !(e[6] & NAME_FLAG_NOLEN)) ++bad;
-        for (uint32_t b = name_ent_len(e); b < 4 * NAME_WORDS; ++b) if ((d[b >> 2] >> (8 * (b & 3))) & 0xFFu) ++bad;     // zero padded
+        {                                                       // the record's words are the window words of the node's canonical name
+            const uint32_t c = (uint32_t)(nd.key >> 48), cnt = (uint32_t)nd.key & 0x7FFFu;
+            std::string nm(g->chrom_names + g->chrom_off[c], g->chrom_off[c + 1] - g->chrom_off[c]);
+            nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
+            uint32_t w[NAME_WORDS];
+            name_windows(nm.data(), 0, (uint32_t)nm.size(), w);
+            if (nm.size() != name_ent_len(e) || memcmp(w, d, sizeof w) != 0) ++bad;
+        }
         // inline links = rows of this node, with the hits of the CSR row; REC_ROW_INLINE only if no row is missing
         const uint32_t ra = nd.row & 0x7FFFFFFFu, rb = g->nodes[id + 1].row & 0x7FFFFFFFu;
         uint32_t live = 0, inl = 0;
