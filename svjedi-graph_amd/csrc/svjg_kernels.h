@@ -126,6 +126,7 @@ __device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_
 // (the and of two compares lives in an SGPR pair, is turned into 0 / 1 per lane and compared again); a compare that yields its mask
 // at once (llvm.amdgcn.icmp), scalar logic on the masks, and a mask taken as a lane predicate where one is needed cost none.
 typedef unsigned long long wmask;
+#define RARELY(c) __builtin_expect((c) != 0, 0)                     /* a wave-uniform branch the usual text does not take: its block is laid out of line, so the usual path has no taken branch there */
 __device__ inline wmask m_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
 __device__ inline wmask m_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
 __device__ inline wmask m_gt(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 34); }
@@ -165,7 +166,7 @@ __device__ inline uint64_t name_words_head(const uint8_t *text, uint32_t a0, uin
     const uint32_t o2 = (uint32_t)min(max((int32_t)L - 8, 0), 16), o1 = o2 >> 1;   // (svjg_line.h: name_windows)
     const uint8_t *p = text + a0;
     unsigned long long w0 = *(const u64_any *)p, w1 = *(const u64_any *)(p + o1), w2 = *(const u64_any *)(p + o2);
-    if (any_short) {                                                  // (o1 = o2 = 0 for these lanes: all three windows are the first eight bytes)
+    if (RARELY(any_short)) {                                                  // (o1 = o2 = 0 for these lanes: all three windows are the first eight bytes)
         const unsigned long long m = L < 8u ? ~(~0ull << (8u * L)) : ~0ull;
         w0 &= m; w1 &= m; w2 &= m;
     }
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // (columns of at most nine digits and d_over < 2^31, svjg_load_graph: everything fits 32 bits)
                     const uint32_t tlen = field_val(text, u5 + 1, u6 - u5 - 1), ts = field_val(text, u6 + 1, u7 - u6 - 1), te = field_val(text, u7 + 1, u8 - u7 - 1);
                     ok = ok && digits && !alen0 && kfit && u5 > u4 + 1 && m_first == u4 + 1 && m_last < u5;
-                    if (idf) {
+                    if (RARELY(idf)) {
                         // "id:f:" anywhere in a line changes what the reference does with it (:193-196): a line one of whose 64-byte spans
                         // holds the pair "d:" takes the exact path (spans [s >> 6, (next line start - 1) >> 6] of the 128 of the stripe)
                         const uint32_t sa = s >> 6, sb = ((nx != 0xFFFFu ? nx : Vh) - 1u) >> 6;
@@ -757,9 +758,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 tick_mem(8);                                             // (list and per-line record read)
                 const uint32_t plen = probe ? len : 8u;                  // (keeps the longer names' window addresses inside the staged text)
                 uint64_t h = name_words_head(text, na0, len, (probe_m & m_lt(len, 8u)) != 0, d);   // the first three windows of the name
-                if (probe_m & m_gt(len, 24u)) h += name_words_tail(text, na0, plen, d);      // (wave-uniform: node names of the usual length fit three windows)
+                if (RARELY(probe_m & m_gt(len, 24u))) h += name_words_tail(text, na0, plen, d);      // (wave-uniform: node names of the usual length fit three windows)
                 const bool long_names = (probe_m & m_gt(len, 32u)) != 0;                     // (wave-uniform: some name of the pass has 33..48 bytes)
-                if (long_names) h += name_words_tail2(text, na0, plen);
+                if (RARELY(long_names)) h += name_words_tail2(text, na0, plen);
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
@@ -779,14 +780,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 uint32_t row_inline = 0;
                 // id << 8 | flags << 6 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
                 bool same = probe && name_match(r0, r1, r2, d, len);
-                if (long_names) { uint32_t f[4]; name_words_far(text, na0, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
+                if (RARELY(long_names)) { uint32_t f[4]; name_words_far(text, na0, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
                 if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = r1.w >> 31; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
                 // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
                 // (all nodes of a line sit in this pass).  Ordinary text never gets here.
                 {
                     const wmask bad = live_m & (m_eq(id, NONE32) | m_ge(lbp, 1u << 25));
-                    if (bad) {
+                    if (RARELY(bad)) {
                         if (in_mask(bad)) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | ((ST_DEFER + DC_NAME) << 24);
                         wave_sync();
                         live_m &= m_eq(((const uint32_t *)&RL[ln])[2] >> 24, ST_OK);
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t dir = idr > id ? 1u : idr < id ? 2u : 0u;
                     const uint32_t dprev = lane_below(dir);
                     const wmask oddm = step_m & (m_eq(dir, 0u) | (m_ge(j, 1u) & m_ne(dir, dprev)));
-                    if (oddm) {
+                    if (RARELY(oddm)) {
                         const wmask search_m = live_m & ballot64(((low_bits64(lk) << lnb) & oddm) != 0ull);   // this lane's line is one of them
                         const bool search = in_mask(search_m);
                         const uint32_t key = search ? (id | (ln << 26)) : NONE32;
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 //    (str.split / list.index, filter-alignments.py:206, :269-271); equal names have equal ids and hashes --
                 uint32_t fl = lane, fr = lane + 1u, pre_l = pre, pre_rx = pre, orl = oribit, orr = nxv & 1u;
                 wmask moved_m = 0;
-                if (revisits) {
+                if (RARELY(revisits)) {
                     fl = f; fr = lane_above(f);
                     moved_m = m_ne(fl, lane) | m_ne(fr, lane + 1u);
                     pre_l = (uint32_t)__shfl((int)pre, (int)fl);
@@ -856,9 +857,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t *hp = nullptr;                             // more than two hits: the list
                 {
                     const wmask many = found_m & m_ge(v, 0x80000000u);   // (wave-uniform: a link with several hits)
-                    if (many) { if (in_mask(many)) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1] | 0x80000000u; } }
+                    if (RARELY(many)) { if (in_mask(many)) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1] | 0x80000000u; } }
                 }
-                if (ask_m) {
+                if (RARELY(ask_m)) {
                     const uint64_t hl = h;                               // (the first occurrence spells the same name)
                     const uint64_t hr = ((uint64_t)lane_above((uint32_t)(h >> 32)) << 32) | lane_above((uint32_t)h);
                     if (ask) {
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 }
                 // hit records: one aggregated atomic per wave reserves the slots
                 unsigned long long rbase = 0;
-                if (a.want_hits) {
+                if (RARELY(a.want_hits)) {
                     uint32_t wtot2, ex = wave_excl_scan(nh & 0x7FFFFFFFu, wtot2);
                     if (wtot2) {
                         if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot2);
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 };
                 if (in_mask(m_le(nh - 1u, 1u))) emit(h0, 0);            // the usual case: one hit (or two), held in registers
-                if (m_gt(nh, 1u)) {
+                if (RARELY(m_gt(nh, 1u))) {
                     const uint32_t n = nh & 0x7FFFFFFFu;
                     for (uint32_t jj = hp ? 0u : 1u; jj < n; ++jj) emit(hp ? hp[jj] : h1, jj);
                 }
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t fin = RL[lane].z >> 24;
                 const bool defer = lane < cnt && fin >= ST_DEFER;
                 unsigned long long db = ballot64(defer);
-                if (db) {
+                if (RARELY(db)) {
 #pragma unroll
                     for (uint32_t cse = 0; cse < DC_STRIPE; ++cse) {
                         const unsigned long long cb = ballot64(defer && fin == ST_DEFER + cse);
