@@ -514,6 +514,62 @@ def test_node_names_of_25_to_48_bytes(ctx, tmp_path):
     assert st["n_deferred"] == sum(cause.values()) <= n_long and cause["node_name"] == st["n_deferred"] > 0   # only the names beyond 48 bytes leave the main kernel
 
 
+def test_node_names_shorter_than_a_window(ctx, tmp_path):
+    """Node names of 5..7 bytes (shorter than one 8-byte hash window: the only names with foreign bytes inside a window, masked in a
+    branch of their own) next to names of 8, 9 and 11 bytes in the same passes, walked forwards and backwards, first and last in
+    their lines; and look-alikes that differ from a node's name in the byte behind a short name.  Counts are the oracle's, no line
+    leaves the main kernel except the ones that name no node."""
+    import json
+    from svjg.graph import Graph
+    edges, gfa = {}, []
+    for c in "1234":
+        n = [f"{c}:1-9", f"{c}:10-400", f"{c}:401-700", f"{c}:701-999", f"{c}:1000-1500"]      # 5, 8, 9, 9, 11 bytes
+        alt = f"{c}:401.1"                                                                        # 7 bytes, 300 bp
+        for x in n:
+            gfa.append(f"S\t{x}\t*\n")
+        gfa.append(f"S\t{alt}\t{'ACGT' * 75}\n")
+        k = lambda a, b: f"{a}@+@{b}@+"
+        edges[k(n[0], n[1])] = [[f"{c}:DEL-9-400", 0]]
+        edges[k(n[0], n[2])] = [[f"{c}:DEL-9-400", 1]]
+        edges[k(n[1], n[2])] = [[f"{c}:DEL-9-400", 0], [f"{c}:INS-400-1", 0], [f"{c}:DEL-400-700", 0]]
+        edges[k(n[1], alt)] = [[f"{c}:INS-400-1", 1]]
+        edges[k(alt, n[2])] = [[f"{c}:INS-400-1", 1]]
+        edges[k(n[2], n[3])] = [[f"{c}:DEL-400-700", 0]]
+        edges[k(n[1], n[3])] = [[f"{c}:DEL-400-700", 1]]
+        edges[k(n[3], n[4])] = [[f"{c}:DEL-999-1500", 0]]
+    pre = str(tmp_path / "s")
+    json.dump(edges, open(pre + "_svs_edges.json", "w"))
+    open(pre + ".gfa", "w").write("".join(gfa))
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    assert sorted({len(x) for x in g.node_names}) == [5, 7, 8, 9, 11]
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    ln = {x: (300 if "." in x else int(x.split("-")[1]) - int(x.split(":")[1].split("-")[0]) + 1) for x in g.node_names}
+    rng = np.random.default_rng(77)
+    walks = [[0, 1, 2, 3, 4], [0, 2, 3, 4], [1, "a", 2, 3], [1, 3, 4], [0, 1, 3], [1, 2], [0, 1], [0], [2, 3, 4], [1, "a", 2]]
+    lines = []
+    for i in range(30000):
+        c = "1234"[int(rng.integers(4))]
+        n = [f"{c}:1-9", f"{c}:10-400", f"{c}:401-700", f"{c}:701-999", f"{c}:1000-1500"]
+        w = [f"{c}:401.1" if x == "a" else n[x] for x in walks[int(rng.integers(len(walks)))]]
+        if i % 97 == 0:
+            w[int(rng.integers(len(w)))] = f"{c}:1-90"          # no such node (a node's name plus a digit): KeyError-free, the line just has no known link
+        tot = sum(ln.get(x, 90) for x in w)
+        back = bool(rng.integers(2))
+        path = "".join(("<" if back else ">") + x for x in (w[::-1] if back else w))
+        ts = int(rng.integers(0, 120)); te = tot - int(rng.integers(0, 120))
+        lines.append(f"r{i}\t{tot}\t0\t{tot}\t+\t{path}\t{tot}\t{ts}\t{max(te, ts + 1)}\t{tot}\t{tot}\t60\ttp:A:P")
+    data = np.frombuffer(("\n".join(lines) + "\n").encode(), dtype=np.uint8)
+    want, _, n_lines = orc.filter(data, want_hits=False)
+    ctx.load_graph(g)
+    ctx.reset_counts()
+    ctx.classify(data)
+    assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 20000
+    st, cause = ctx.stats(), ctx.defer_causes()
+    n_unknown = sum(1 for l in lines if ":1-90" in l.split("\t")[5] and l.split("\t")[5].count(":") >= 2)
+    assert st["n_lines"] == n_lines == 30000
+    assert st["n_deferred"] == cause["node_name"] <= n_unknown + 5 and n_unknown > 100
+
+
 def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
     """What sends a line to the exact path is that line's business (r03): an id:f: tag defers the lines whose 64-byte spans hold the
     pair "d:", not the stripe; a path of more than 64 nodes only that line; columns with blanks only theirs.  The causes are counted
