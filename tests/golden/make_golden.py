@@ -496,6 +496,51 @@ def make_unicode():
     print("unicode:", {k: (v["rc"], v.get("error", "")) for k, v in manifest.items()})
 
 
+def make_nosv():
+    """golden/nosv: a VCF none of whose records makes the constructor add an SV (a DUP, a symbolic INS without a sequence, an INS
+    with a long REF): the graph the reference builds from it has no link with an SV (`{}`), the filter writes `{}` whatever the
+    alignments say, and predict-genotype.py answers ./. for every row."""
+    out = f"{HERE}/nosv"
+    os.makedirs(out, exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    fa = f"{REF}/test-dir/reference_genome.fasta"
+    chrom = open(fa).readline()[1:].split()[0]
+    hdr = [ln for ln in open(f"{REF}/test-dir/test.vcf") if ln.startswith("#")]
+    rows = [f"{chrom}\t1000\tdup1\tN\t<DUP>\t.\tPASS\tSVTYPE=DUP;END=1400;SVLEN=400\n",
+            f"{chrom}\t3000\tins_noseq\tN\t<INS>\t.\tPASS\tSVTYPE=INS;END=3000;SVLEN=120\n",
+            f"{chrom}\t5000\tins_longref\tACGT\t{'ACGT' * 30}\t.\tPASS\tSVTYPE=INS;END=5000;SVLEN=116\n"]
+    with open(f"{out}/nosv.vcf", "w") as fh:
+        fh.write("".join(hdr) + "".join(rows))
+    subprocess.run([sys.executable, f"{REF}/construct-graph.py", "-v", f"{out}/nosv.vcf", "-r", fa, "-o", f"{tmp}/nosv.gfa"], check=True)
+    shutil.copy(f"{tmp}/nosv_svs_edges.json", f"{out}/nosv_svs_edges.json")
+    names = []
+    with open(f"{tmp}/nosv.gfa") as fi, open(f"{out}/nosv.gfa", "w") as fo:      # reference-node sequences elided, as in testdir
+        for ln in fi:
+            c = ln.rstrip("\n").split("\t")
+            if c[0] == "S":
+                names.append((c[1], len(c[2])))
+                fo.write(f"S\t{c[1]}\t*\n")
+            elif c[0] == "P":
+                fo.write("\t".join([c[0], c[1], c[2], "*"]) + "\n")
+            else:
+                fo.write(ln)
+    L = dict(names)
+    first = names[0][0]
+    lines = [gaf_line("r0", [first], [">"], L), gaf_line("r1", [first], ["<"], L, ts=50, te_back=20)]
+    if len(names) > 1:
+        lines.append(gaf_line("r2", [names[0][0], names[1][0]], [">", ">"], L))
+    with open(f"{out}/nosv.gaf", "w") as fh:
+        fh.write("".join(lines))
+    rc, err = run_ref_filter(f"{out}/nosv.gaf", f"{out}/nosv.gfa", f"{tmp}/nosv")
+    assert rc == 0, err
+    shutil.copy(f"{tmp}/nosv_informative_aln.json", f"{out}/nosv.ref.json")
+    rc, so = run_ref_genotype(f"{tmp}/nosv_informative_aln.json", f"{out}/nosv.vcf", f"{out}/nosv.ref_genotype.vcf")
+    with open(f"{out}/manifest.json", "w") as fh:
+        json.dump({"edges": json.load(open(f"{out}/nosv_svs_edges.json")), "json": open(f"{out}/nosv.ref.json").read(), "genotype_rc": rc,
+                   "genotype_stdout": so, "nodes": len(names)}, fh, indent=1, sort_keys=True)
+    print("nosv:", open(f"{out}/manifest.json").read()[:400])
+
+
 # ----------------------------------------------------------------------------------------------
 # G4 likelihood known answers
 # ----------------------------------------------------------------------------------------------
@@ -908,7 +953,7 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order"]
+    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv"]
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))

@@ -182,6 +182,28 @@ def test_testdir_files(ctx, golden, tmp_path):
     assert [l for l in open(pre + "_genotype.vcf") if not l.startswith("#")] == exp
 
 
+def test_graph_without_svs_files(golden, tmp_path):
+    """golden/nosv: the graph the reference's constructor builds from a VCF without a usable SV has no link with an SV.  The drop-in
+    filter writes `{}` and the genotyper ./. for every row, as the reference does — with an empty count vector on the device."""
+    import shutil
+    import subprocess
+    import sys
+    t = f"{golden}/nosv"
+    for f in ("nosv.gaf", "nosv.gfa", "nosv_svs_edges.json", "nosv.vcf"):
+        shutil.copy(f"{t}/{f}", tmp_path / f)
+    amd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svjedi-graph_amd")
+    pre = str(tmp_path / "nosv")
+    p = subprocess.run([sys.executable, f"{amd}/filter-alignments.py", "-a", pre + ".gaf", "-g", pre + ".gfa", "-p", pre],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(pre + "_informative_aln.json").read() == open(f"{t}/nosv.ref.json").read() == "{}"
+    p = subprocess.run([sys.executable, f"{amd}/predict-genotype.py", "-d", pre + "_informative_aln.json", "-v", pre + ".vcf",
+                        "--minsupport", "3", "-o", pre + "_genotype.vcf"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == json.load(open(f"{t}/manifest.json"))["genotype_stdout"]
+    assert open(pre + "_genotype.vcf").read() == open(f"{t}/nosv.ref_genotype.vcf").read()
+
+
 def test_cli_error_exit_code(golden, tmp_path):
     import shutil
     import subprocess

@@ -80,6 +80,19 @@ def test_py_testdir_end_to_end(golden):
     assert len(exp) == 40
 
 
+def test_py_graph_without_svs(golden):
+    """golden/nosv: a VCF none of whose records becomes an SV of the graph (reference's constructor: `{}`), reference outputs `{}`
+    and ./. for every row."""
+    t = f"{golden}/nosv"
+    man = json.load(open(f"{t}/manifest.json"))
+    edges = O.load_edges(f"{t}/nosv_svs_edges.json")
+    assert edges == {} == man["edges"]
+    D = O.classify(_read_lines(f"{t}/nosv.gaf"), edges, O.load_alt_node_len(f"{t}/nosv.gfa"))
+    assert O.dump_informative(D) == open(f"{t}/nosv.ref.json").read() == "{}"
+    text, n = O.genotype_vcf(_read_lines(f"{t}/nosv.vcf"), D)
+    assert text == open(f"{t}/nosv.ref_genotype.vcf").read() and f"Genotyped svs: {n}\n" == man["genotype_stdout"]
+
+
 def test_py_likelihood_known_answers(golden):
     z = np.load(f"{golden}/lik/lik_kat.npz")
     cases, errs, txt = z["cases"], z["err"], z["dp_ad"]

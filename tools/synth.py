@@ -303,13 +303,15 @@ def gaf_bytes(tab, seed, first, n, threads=8):
     lib = build_lib()
     threads = max(1, min(threads, (n + 9999) // 10000))
     step = (n + threads - 1) // threads
+    # measurement only (SVJG_SYNTH_HOT=d): reads start in the first 1/d of the reference nodes, so that the records they touch fit the L2
+    n_start = max(2, tab["n_ref"] // max(1, int(os.environ.get("SVJG_SYNTH_HOT", "1"))))
 
     def work(t):
         a = first + t * step
         cnt = max(0, min(step, first + n - a))
         cap = cnt * 700 + 4096
         buf = np.empty(cap, dtype=np.uint8)
-        got = lib.svjg_synth_gaf(tab["blob"], tab["off"].ctypes.data, tab["len"].ctypes.data, tab["n_ref"],
+        got = lib.svjg_synth_gaf(tab["blob"], tab["off"].ctypes.data, tab["len"].ctypes.data, n_start,
                                  tab["ptr"].ctypes.data, tab["to"].ctypes.data, tab["sv"].ctypes.data,
                                  tab["gt"].ctypes.data, seed, a, cnt, buf.ctypes.data, cap)
         assert got >= 0
