@@ -248,7 +248,13 @@ struct SpanFlags {
     uint32_t high;          // some byte >= 0x80 (per lane)
     uint32_t idf;           // the byte pair "d:" begins in this lane's spans (per lane)
     uint32_t dee_last;      // half 0: the span's last byte is 'd' (the ':' would be the next lane's, or the next half's, first byte)
+    uint32_t idsum;         // per half one byte: pairs "d:" whose 'd' lies in this lane's span — min(count, 3) << 6 | position of the last one
 };
+__device__ inline uint32_t idsum_of(uint32_t pair_lo, uint32_t pair_hi) {   // (pair_lo | pair_hi != 0)
+    const uint32_t cnt = (uint32_t)__popc(pair_lo) + (uint32_t)__popc(pair_hi);
+    const uint32_t pos = pair_hi ? 63u - (uint32_t)__builtin_clz(pair_hi) : 31u - (uint32_t)__builtin_clz(pair_lo);
+    return ((cnt < 3u ? cnt : 3u) << 6) | pos;
+}
 __device__ inline uint32_t lane_above_or0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }   // wave_shl:1, lane 63 gets 0
 __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t *tbm, uint32_t slot, uint64_t c0, uint32_t V,
                                      unsigned long long &NL, unsigned long long &ORI, SpanFlags &fl) {
@@ -276,7 +282,11 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
         const unsigned long long dee = place(lo.dee, hi.dee), col = place(lo.colon, hi.colon);
         const uint32_t nxt = lane_above_or0((uint32_t)col);
         const uint32_t s_lo = __builtin_amdgcn_alignbit((uint32_t)(col >> 32), (uint32_t)col, 1), s_hi = __builtin_amdgcn_alignbit(nxt, (uint32_t)(col >> 32), 1);
-        fl.idf |= ((uint32_t)dee & s_lo) | ((uint32_t)(dee >> 32) & s_hi);
+        const uint32_t pair_lo = (uint32_t)dee & s_lo, pair_hi = (uint32_t)(dee >> 32) & s_hi;
+        fl.idf |= pair_lo | pair_hi;
+        if (RARELY(m_ne(pair_lo | pair_hi, 0u))) {                       // (wave-uniform: no tag minigraph writes holds the pair)
+            if ((pair_lo | pair_hi) != 0u) fl.idsum |= idsum_of(pair_lo, pair_hi) << (slot >= WG ? 8 : 0);
+        }
         fl.dee_last = (uint32_t)(dee >> 63);
     }
     // carriage returns (no text file has them in practice)
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
         //      the "id:f:" filter: every such tag holds the byte pair "d:"; a hit sends the stripe's lines to the exact path) ----------
         const uint32_t head_byte = pf_head;
         unsigned long long NL[NHALF], ORI[NHALF];
-        SpanFlags fl = {0u, 0u, 0u};
+        SpanFlags fl = {0u, 0u, 0u, 0u};
         uint32_t dee_end = 0;                                            // wave-uniform: the first half ends with 'd'
         unsigned long long IDM[NHALF];                                   // wave-uniform: lanes whose span of this half holds the 'd' of a pair "d:"
 #pragma unroll
@@ -473,7 +483,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             classify_span(a, text, ndbm, tbm, h * WG + lane, c0, V, NL[h], ORI[h], fl);
             IDM[h] = ballot64(fl.idf != 0);
             if (h == 0) dee_end = rdlane(fl.dee_last, WG - 1);
-            else if (dee_end != 0 && text[HALF] == ':') IDM[0] |= 1ull << 63;   // (the pair straddles the halves: its 'd' is the first half's last byte)
+            else if (dee_end != 0 && text[HALF] == ':') {                // (the pair straddles the halves: its 'd' is the first half's last byte)
+                IDM[0] |= 1ull << 63;
+                if (lane == WG - 1) { const uint32_t c = (fl.idsum >> 6) & 3u; fl.idsum = (fl.idsum & 0xFF00u) | ((c < 3u ? c + 1u : 3u) << 6) | 63u; }
+            }
         }
         if (ballot64(fl.high != 0) != 0 && lane == 0) a.st->non_ascii = 1;
         const bool idf = (IDM[0] | IDM[1]) != 0;                         // some line of the stripe may hold an "id:f:" tag: the line phase finds which
@@ -646,6 +659,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             const uint32_t obase = LINE[lbase] >> 16;
             // ---- R1: one line per lane --------------------------------------------------------------
             uint32_t status = ST_NONE, k = 0, s = 0, rel = 0, kall = 0, r_need_l = 0, r_need_r = 0, r_pend = 0;
+            uint32_t id_span = NONE32, id_end = 0;         // (only when some span of the stripe holds a pair "d:")
             if (lane < cnt) {
                 const uint32_t L = lbase + lane;
                 const uint32_t l0 = LINE[L], l1 = LINE[L + 1];
@@ -697,25 +711,84 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // the two right-hand sides are fixed per line
                     // (columns of at most nine digits and d_over < 2^31, svjg_load_graph: everything fits 32 bits)
                     const uint32_t tlen = field_val(text, u5 + 1, u6 - u5 - 1), ts = field_val(text, u6 + 1, u7 - u6 - 1), te = field_val(text, u7 + 1, u8 - u7 - 1);
-                    ok = ok && digits && !alen0 && kfit && u5 > u4 + 1 && m_first == u4 + 1 && m_last < u5;
-                    if (RARELY(idf)) {
-                        // "id:f:" anywhere in a line changes what the reference does with it (:193-196): a line one of whose 64-byte spans
-                        // holds the pair "d:" takes the exact path (spans [s >> 6, (next line start - 1) >> 6] of the 128 of the stripe)
-                        const uint32_t sa = s >> 6, sb = ((nx != 0xFFFFu ? nx : Vh) - 1u) >> 6;
+                    const bool ok_cols = ok && digits && kfit && u5 > u4 + 1 && m_first == u4 + 1 && m_last < u5;
+                    ok = ok_cols && !alen0;
+                    if (RARELY(idf)) {                                   // which spans of this line hold a pair "d:" (decided behind the block, all lanes together)
+                        const uint32_t lend = nx != 0xFFFFu ? nx : Vh;  // spans [s >> 6, (next line start - 1) >> 6] of the 128 of the stripe
+                        const uint32_t sa = s >> 6, sb = (lend - 1u) >> 6;
                         const unsigned long long m0 = low_bits64(sb + 1u < 64u ? sb + 1u : 64u) & ~low_bits64(sa < 64u ? sa : 64u);
                         const unsigned long long m1 = low_bits64(sb >= 64u ? sb - 63u : 0u) & ~low_bits64(sa > 64u ? sa - 64u : 0u);
-                        const unsigned long long i0 = (unsigned long long)LINE[MAXL + 4] | ((unsigned long long)LINE[MAXL + 5] << 32);
-                        const unsigned long long i1 = (unsigned long long)LINE[MAXL + 6] | ((unsigned long long)LINE[MAXL + 7] << 32);
-                        if (((i0 & m0) | (i1 & m1)) != 0ull) { ok = false; status = ST_DEFER + DC_IDF; }
+                        unsigned long long f0 = ((unsigned long long)LINE[MAXL + 4] | ((unsigned long long)LINE[MAXL + 5] << 32)) & m0;
+                        unsigned long long f1 = ((unsigned long long)LINE[MAXL + 6] | ((unsigned long long)LINE[MAXL + 7] << 32)) & m1;
+                        auto take = [&](uint32_t sp) -> uint32_t {       // is span sp flagged?  (and no longer, afterwards)
+                            unsigned long long &f = sp < 64u ? f0 : f1;
+                            const unsigned long long bit = 1ull << (sp & 63u);
+                            const uint32_t r = (f & bit) ? 1u : 0u;
+                            f &= ~bit;
+                            return r;
+                        };
+                        const uint32_t fa = take(sa), fb = take(sb);     // the line's first and last span may hold a neighbour's pair
+                        const uint32_t n_int = (uint32_t)__popcll(f0) + (uint32_t)__popcll(f1);   // the spans in between hold only this line's
+                        const uint32_t isp = f0 ? (uint32_t)__builtin_ctzll(f0) : f1 ? 64u + (uint32_t)__builtin_ctzll(f1) : 0u;
+                        if (fa | fb | n_int) id_span = fa | (fb << 1) | ((n_int < 3u ? n_int : 3u) << 2) | (isp << 4) | (ok_cols ? 1u << 11 : 0u);
+                        id_end = e | (lend << 16);
                     }
                     if (!ok && status == ST_DEFER && kall > KMAX) status = ST_DEFER + DC_LONG_PATH;
                     else if (!ok && status == ST_DEFER && t5 == TEXT && t4 < TEXT && kfit) status = ST_DEFER + DC_NAME;   // (no tab within 49 bytes of the last mark: a name beyond 48 bytes)
-                    if (ok) {
-                        status = k >= 2 ? ST_OK : ST_NOHIT;
+                    if (ok_cols) {
+                        if (ok) status = k >= 2 ? ST_OK : ST_NOHIT;
                         r_need_l = ts + g.d_over;
                         r_need_r = tlen + g.d_over > te + 1u ? tlen + g.d_over - te - 1u : 0u;
                         r_pend = t5;
                     }
+                }
+            }
+            if (RARELY(idf)) {
+                // "id:f:" anywhere in a line changes what the reference does with it (:193-196): float() of the text behind the LAST "id:f:"
+                // up to the next tab may raise, and Alen == 0 no longer does.  The byte classes know every pair "d:" — which every such tag
+                // holds —: IDM = the 64-byte spans with the 'd' of a pair, idsum = how many pairs a span has and where its last one is.  A line
+                // whose spans hold exactly one pair is decided here: the pair in another line of the span, or no "id:f:" around it -> an ordinary
+                // line; a tag whose value is digits with at most one '.' in or next to them (what aligners write) -> an ordinary line whose
+                // Alen may be zero; any other value, and a line with several pairs, takes the exact path.
+                const bool has = id_span != NONE32;
+                const uint32_t lend = id_end >> 16, e = id_end & 0xFFFFu;
+                const uint32_t sa = has ? s >> 6 : 0u, sb = has ? (lend - 1u) >> 6 : 0u, isp = has ? (id_span >> 4) & 127u : 0u;
+                auto summary = [&](uint32_t sp) -> uint32_t { return ((uint32_t)__shfl((int)fl.idsum, (int)(sp & 63u)) >> (sp & 64u ? 8 : 0)) & 0xFFu; };
+                const uint32_t sum_a = summary(sa), sum_b = summary(sb), sum_i = summary(isp);   // (all lanes: the values come from the lanes that own the spans)
+                if (has) {
+                    uint32_t mine = 0, q = 0;                            // pairs whose 'd' lies in this line: how many (if that can be told), where the only one is
+                    bool unsure = false;
+                    if (id_span & 1u) {                                  // first span: the pairs in front of the line's start are a neighbour's
+                        const uint32_t qa = sa * SPAN + (sum_a & 63u);
+                        if (qa >= s && qa < lend) { if ((sum_a >> 6) == 1u) { ++mine; q = qa; } else unsure = true; }
+                        else if (qa >= lend && (sum_a >> 6) != 1u) unsure = true;   // (a line inside one span, several pairs in it)
+                    }
+                    if (id_span & 2u) {                                  // last span (not the first): a single pair behind the line's end is a neighbour's
+                        const uint32_t qb = sb * SPAN + (sum_b & 63u);
+                        if ((sum_b >> 6) != 1u) unsure = true;
+                        else if (qb < lend) { ++mine; q = qb; }
+                    }
+                    const uint32_t n_int = (id_span >> 2) & 3u;
+                    if (n_int == 1u) { if ((sum_i >> 6) == 1u) { ++mine; q = isp * SPAN + (sum_i & 63u); } else unsure = true; }
+                    else if (n_int) unsure = true;
+                    uint32_t verdict = 2u;                               // 0: no tag in this line, 1: a tag with a plain value, 2: the exact path decides
+                    if (!unsure && mine == 0u) verdict = 0u;
+                    else if (!unsure && mine == 1u) {
+                        if (!(q > s && q + 4u <= e && text[q - 1u] == 'i' && text[q + 2u] == 'f' && text[q + 3u] == ':')) verdict = 0u;   // (inside the stripped line, like `in line`)
+                        else {
+                            const uint32_t v0 = q + 4u;                  // value = text[v0, first tab or end of the stripped line)
+                            const uint32_t tw = tab_window(tbm, v0), nw = tab_window(ndbm, v0);
+                            uint32_t n = tw ? (uint32_t)__builtin_ctz(tw) : 32u;
+                            if (e - v0 < n) n = e - v0;
+                            if (n >= 1u && n <= 31u) {
+                                const uint32_t nd = nw & ((1u << n) - 1u);
+                                if (nd == 0u) verdict = 1u;
+                                else if ((nd & (nd - 1u)) == 0u && n >= 2u && text[v0 + (uint32_t)__builtin_ctz(nd)] == '.') verdict = 1u;
+                            }
+                        }
+                    }
+                    if (verdict == 2u) { if (status < ST_DEFER || status == ST_DEFER + DC_COLUMNS) status = ST_DEFER + DC_IDF; }
+                    else if (verdict == 1u && (id_span & (1u << 11)) && status == ST_DEFER + DC_COLUMNS) status = k >= 2 ? ST_OK : ST_NOHIT;   // (it was only Alen == 0 that held the line back)
                 }
             }
             if (status != ST_OK) k = 0;

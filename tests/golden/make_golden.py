@@ -373,6 +373,22 @@ def make_quirks():
     cases["cg_tag"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>", extra=tags + "\tcg:Z:100M5D200M"),
                        g("r1", ["1:1-1000", "1:1501-3000"], ">>", extra="cg:Z:300M\t" + tags)]
     cases["id_tag"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>", extra="NM:i:3\tid:f:0.987\t" + tags)]
+    # id:f: tags of every shape next to one another (the value is float()ed, Alen is not divided by; the LAST tag of a line counts)
+    z = "r{}\t500\t0\t500\t+\t>1:1-1000>1:1001-1500\t1500\t0\t1500\t0\t0\t60\t"          # Alen == 0 lines: fine only with a tag
+    cases["id_tag_forms"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>", extra=tags + "\tid:f:1"),
+                             g("r1", ["1:1-1000", "1:1501-3000"], ">>", extra="id:f:.5\t" + tags),
+                             g("r2", ["1:1-1000", "1:1001-1500"], ">>", extra=tags + "\tid:f:7."),
+                             z.format(3) + "id:f:0.000001\t" + tags + "\n",
+                             z.format(4) + tags + "\tid:f:12345678.25\n",
+                             g("r5", ["1:1-1000", "1:1501-3000"], ">>", extra="id:f:junk\t" + tags + "\tid:f:0.75"),        # two tags: the last one counts
+                             z.format(6) + "id:f:1e-3\n", z.format(7) + "id:f:+0.5\n", z.format(8) + "id:f:nan\n", z.format(9) + "id:f: 0.25\n",
+                             g("sd:3_r10", ["1:1-1000", "1:1501-3000"], ">>", extra=tags),                                   # "d:" in the read name only: no tag
+                             g("xid:f:0.5", ["1:1-1000", "1:1501-3000"], ">>", extra=tags).replace("xid:f:0.5\t", "xid:f:0.5\t", 1)]   # the tag IS the read name's tail
+    cases["err_id_tag_in_read_name"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>"), g("id:f:0.5/ccs", ["1:1-1000", "1:1501-3000"], ">>", extra=tags)]
+    cases["err_id_tag_empty"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>", extra=tags + "\tid:f:")]
+    cases["err_id_tag_two_dots"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>", extra="id:f:1.2.3\t" + tags)]
+    cases["err_id_tag_last_is_junk"] = [g("r0", ["1:1-1000", "1:1501-3000"], ">>", extra="id:f:0.5\t" + tags + "\tid:f:x")]
+    cases["err_zero_alen_behind_tagged_lines"] = [z.format(0) + "id:f:0.5\n", z.format(1) + tags + "\n"]
     cases["json_escapes"] = [g('r"q\\x', ["1:1-1000", "1:1501-3000"], ">>"),
                              g("ré中", ["1:1-1000", "1:1501-3000"], ">>"),
                              g("r\x01\x7f", ["1:1-1000", "1:1501-3000"], ">>")]

@@ -135,7 +135,7 @@ def test_realshape_lines(ctx, golden, all_slow, tmp_path):
         assert st["n_lines"] == n_lines and st["n_deferred"] == sum(cause.values())
         # (a path of hundreds of nodes also overfills its stripe's lists, a line beyond 8 KB has no stripe: those count as whole stripes)
         assert cause["long_path"] + cause["whole_stripe"] >= n_long > 0 and cause["long_path"] > 0 and cause["node_name"] == 0 and cause["columns"] == 0
-        assert n_tag <= cause["id_tag_filter"] <= 2 * n_tag + 2, (cause, n_tag)          # (read names / cg:Z: strings hold no "d:")
+        assert cause["id_tag_filter"] <= 2 * n_tag + 2, (cause, n_tag)                   # (read names / cg:Z: strings hold no "d:"; a tag with a plain decimal value stays in the main kernel)
         assert st["n_deferred"] <= n_long + 2 * n_tag + 4, (st, cause)                  # r02: up to 70 % of the 176 lines; now 15
 
 
@@ -592,6 +592,73 @@ def test_node_names_shorter_than_a_window(ctx, tmp_path):
     assert st["n_deferred"] == cause["node_name"] <= n_unknown + 5 and n_unknown > 100
 
 
+def test_every_line_with_an_identity_tag(ctx, tmp_path):
+    """A GAF in which every line carries `id:f:<decimal>` (what GraphAligner writes; the reference then takes the identity from the
+    tag, filter-alignments.py:193-196, and no longer divides by Alen): plain decimal values are decided in the main kernel — no line
+    takes the exact path —, a zero Alen raises nothing on a tagged line and still raises ZeroDivisionError on an untagged one, a
+    "d:" inside a read name is no tag, two tags / exponents / junk go to the exact path and come out as the reference has them."""
+    pre, gaf, g, orc = _synth_case(tmp_path, 30000, 900, 3, "mixed", 123)
+    lines = bytes(gaf).split(b"\n")[:-1]
+    vals = [b"0.9731", b"1", b"0", b".5", b"7.", b"0.000001", b"12345678.25", b"0.99999999999999"]
+    ctx.load_graph(g)
+    for name_pairs in (False, True):
+        out = []
+        for i, l in enumerate(lines):
+            c = l.split(b"\t")
+            if i % 11 == 0:
+                c[10] = b"0"                                     # Alen == 0: fine with a tag
+            if name_pairs and i % 7 == 0:
+                c[0] = b"sd:3_" + c[0]                           # a pair "d:" that is no tag, next to the real one: two pairs -> exact path
+            tag = b"id:f:" + vals[i % len(vals)]
+            c = c[:12] + ([tag] + c[12:] if i % 3 else c[12:] + [tag])   # first or last of the tags
+            out.append(b"\t".join(c))
+        data = np.frombuffer(b"\n".join(out) + b"\n", dtype=np.uint8)
+        want, _, n_lines = orc.filter(data, want_hits=False)
+        ctx.reset_counts()
+        ctx.classify(data)
+        assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 30000
+        st, cause = ctx.stats(), ctx.defer_causes()
+        assert st["n_lines"] == n_lines == len(lines) and st["n_deferred"] == cause["id_tag_filter"]
+        if not name_pairs:
+            assert st["n_deferred"] == 0                         # every line tagged, none on the exact path
+        else:                                                    # the lines with two pairs, and neighbours whose last span holds the next line's pair as well
+            n_two = sum(1 for i in range(len(lines)) if i % 7 == 0)
+            assert n_two <= st["n_deferred"] <= n_two + n_two // 2
+    # the same lines without their tags: the ones with Alen == 0 raise, as in the reference
+    bare = np.frombuffer(b"\n".join(b"\t".join(x for x in l.split(b"\t") if not x.startswith(b"id:f:")) for l in out[:50]) + b"\n", dtype=np.uint8)
+    ctx.reset_counts()
+    with pytest.raises(ZeroDivisionError):
+        ctx.classify(bare)
+    with pytest.raises(ZeroDivisionError):
+        orc.filter(bare, want_hits=False)
+    # values that are floats to Python but not plain decimals, and a pair in the read name only: counts as the oracle's
+    odd_vals = [b"1e-3", b"+0.5", b"nan", b"inf", b"1_0.5", b" 0.25", b"-0.0", b"0x1p-2" if False else b"5E1"]
+    odd = []
+    for i, l in enumerate(lines[:4000]):
+        c = l.split(b"\t")
+        if i % 5 == 4:
+            c[0] = b"rd:" + c[0]                                 # "d:" in the read name, no tag at all: an ordinary line
+        else:
+            c.append(b"id:f:" + odd_vals[i % len(odd_vals)])
+        odd.append(b"\t".join(c))
+    data = np.frombuffer(b"\n".join(odd) + b"\n", dtype=np.uint8)
+    want, _, n_lines = orc.filter(data, want_hits=False)
+    ctx.reset_counts()
+    ctx.classify(data)
+    assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 3000
+    st = ctx.stats()
+    # the 3 200 tagged lines; of the 800 with a pair in the name only, those whose first span also holds the tag at the end of the line before
+    # (two pairs in one span: whose they are is not known there) — the others stay in the main kernel
+    assert 3200 <= st["n_deferred"] <= 3200 + 720
+    for junk, exc in ((b"id:f:0.5x", ValueError), (b"id:f:", ValueError), (b"id:f:1.2.3", ValueError), (b"id:f:.", ValueError)):
+        bad = np.frombuffer(b"\n".join(lines[:30] + [lines[30] + b"\t" + junk] + lines[31:60]) + b"\n", dtype=np.uint8)
+        ctx.reset_counts()
+        with pytest.raises(exc):
+            ctx.classify(bad)
+        with pytest.raises(exc):
+            orc.filter(bad, want_hits=False)
+
+
 def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
     """What sends a line to the exact path is that line's business (r03): an id:f: tag defers the lines whose 64-byte spans hold the
     pair "d:", not the stripe; a path of more than 64 nodes only that line; columns with blanks only theirs.  The causes are counted
@@ -604,7 +671,7 @@ def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
     out = []
     for i, l in enumerate(lines):
         if i in tagged:
-            l = l + b"\tid:f:0.93"
+            l = l + b"\tid:f:9.3e-1"                   # (a value the main kernel does not decide: the exact path's float() does)
         elif i in blank:
             c = l.split(b"\t"); c[7] = b" " + c[7]; l = b"\t".join(c)
         out.append(l)
@@ -1013,6 +1080,11 @@ def test_id_tag_across_span_and_half_boundaries(ctx, tmp_path):
         ctx.reset_counts()
         ctx.classify(np.frombuffer(good, dtype=np.uint8))
         assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want), p
+        assert ctx.stats()["n_deferred"] == 0          # (r03: a tag with a plain decimal value is decided in the main kernel)
+        odd = with_tag_at(p, b"id:f:9e-1")             # float() takes it, the main kernel does not try to: exact path, same counts
+        ctx.reset_counts()
+        ctx.classify(np.frombuffer(odd, dtype=np.uint8))
+        assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want), p
         assert ctx.stats()["n_deferred"] >= 1
 
 
@@ -1032,8 +1104,9 @@ def test_run_resident_is_the_three_calls(tmp_path):
     from svjg import capi, genotype, shard
     pre, gaf, g, orc = _synth_case(tmp_path, 40000, 1500, 3, "mixed", 33)
     rows = genotype.VcfRows(pre + ".vcf", g.slot_of)
-    tagged = bytes(gaf).replace(b"\tdv:f:", b"\tid:f:0.9\tdv:f:", 40).replace(b"\n", b"\r\n", 3)
-    many = np.frombuffer(bytes(gaf).replace(b"\tdv:f:", b"\tid:f:0.5\tdv:f:") * 4, dtype=np.uint8)   # 160 k lines, every one with the tag
+    # (id:f: values in exponent form: float() takes them, the main kernel leaves them to the exact path)
+    tagged = bytes(gaf).replace(b"\tdv:f:", b"\tid:f:9e-1\tdv:f:", 40).replace(b"\n", b"\r\n", 3)
+    many = np.frombuffer(bytes(gaf).replace(b"\tdv:f:", b"\tid:f:5e-1\tdv:f:") * 4, dtype=np.uint8)   # 160 k lines, every one with the tag
     c = capi.Context(0)
     try:
         c.load_graph(g)
