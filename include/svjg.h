@@ -148,7 +148,8 @@ int svjg_get_stats(svjg_ctx *ctx, svjg_stats *out);
 int svjg_input_error(svjg_ctx *ctx, int *exc_class, uint64_t *line_offset);
 /* Why lines took the exact string path since the last svjg_reset_counts (their sum is svjg_stats.n_deferred):
  * out[0] columns that are not twelve plain ones (blanks, signs, too few, Alen = 0, ...), [1] a 64-byte span of the line holds the
- * byte pair "d:" (an id:f: tag, filter-alignments.py:193-196, or a false alarm), [2] a path of more than 64 nodes, [3] a node name
+ * byte pair "d:" and the line is not decided in the main kernel (an id:f: tag, filter-alignments.py:193-196, whose value is not a
+ * plain decimal, or several pairs in the line's spans), [2] a path of more than 64 nodes, [3] a node name
  * the kernel's name table does not hold (not in the graph, a substring of another name, longer than 48 bytes, alt node without a
  * length), [4] whole stripes of 8 KB (more than 64 lines or 216 orientation marks, a line longer than 8 KB, SVJG_GRAPH_ALL_SLOW),
  * [5..7] reserved (0). */
