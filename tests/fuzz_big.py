@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "svjedi-graph_amd"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
 import synth
-from make_fuzz import mutate
+from make_fuzz import mutate, MORE_TAGS
 from oracle import oracle_c as OC, oracle_py as O
 from svjg import capi
 from svjg.graph import Graph
@@ -32,7 +32,7 @@ def od(want):
 
 good, bad = [], []
 for _ in range(n_mut):
-    m = mutate(rng.choice(lines), rng)
+    m = mutate(rng.choice(lines), rng, MORE_TAGS)
     if b"\xd9\xa3" in m or any(c >= 0x80 for c in m):
         continue                                   # documented divergences / UTF-8 handling is the host's
     if len(m) > 32768:

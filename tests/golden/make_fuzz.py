@@ -25,7 +25,13 @@ NASTY = [b"\t", b" ", b"<", b">", b":", b"-", b".", b"0", b"9", b"x", b"\r", b"\
 NUMS = [b"+5", b" 7", b"7 ", b"1_0", b"", b"-3", b"0", b"00", b"1e3", b"12345678901", b"9999999999", b"3.0", b"0x10", b"\xd9\xa3"]
 
 
-def mutate(line, rng):
+TAGS = (b"\tcg:Z:10M2D", b"\tid:f:0.97", b"\tid:f:abc", b"cg:Z:", b"\tid:f:", b"\txx:Z:a>b<c")
+# (tests/fuzz_big.py only: the committed fixture was drawn from TAGS)  identity tags of every shape, in front of and behind other tags, in the read name
+MORE_TAGS = TAGS + (b"\tid:f:.5", b"\tid:f:7.", b"\tid:f:1e-3", b"\tid:f:0.5\tid:f:0.25", b"\tid:f:x\tid:f:1", b"\tid:f:1\tzd:Z:d:", b"\tid:f:0.123456789012345678901234567890123",
+                    b"\tid:f:0..5", b"\tid:f:0.5 ", b"\tNM:i:3\tid:f:1.0\tdv:f:0.01", b"id:f:0.5", b"\tid:f", "\tid:f:\u0660".encode(), b"\tbd:i:3")
+
+
+def mutate(line, rng, tags=TAGS):
     """1-3 edits of one GAF line (bytes, newline terminated)."""
     b = bytearray(line)
     for _ in range(rng.choice((1, 1, 1, 2, 2, 3))):
@@ -60,7 +66,7 @@ def mutate(line, rng):
             del cols[rng.randrange(len(cols))]
             b = bytearray(b"\t".join(cols) + b"\n")
         elif op == 7:                                               # tags the reference looks at
-            b = bytearray(bytes(b).rstrip(b"\n") + rng.choice((b"\tcg:Z:10M2D", b"\tid:f:0.97", b"\tid:f:abc", b"cg:Z:", b"\tid:f:", b"\txx:Z:a>b<c")) + b"\n")
+            b = bytearray(bytes(b).rstrip(b"\n") + rng.choice(tags) + b"\n")
         elif op == 8:                                               # trailing blanks / another terminator
             b = bytearray(bytes(b).rstrip(b"\n") + rng.choice((b" \n", b"\t\n", b"\r\n", b"\r", b"", b" \t \n", b"\n\n", b"\x0c\n")))
         elif op == 9 and len(cols) > 8:                             # alignment coordinates around the 100 bp rule
