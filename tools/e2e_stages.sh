@@ -1,3 +1,4 @@
+# measurement only (GPU box): the two drop-in scripts on the configs[2] files with SVJG_VERBOSE=1, stage timers on stderr
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 python3 - <<'PY'
 import os, sys, time, subprocess, tempfile
