@@ -1012,18 +1012,28 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(r.ev[2], c->stream));
     }
-    // Behind an event, on the second (low-priority) stream: the count all-reduce of this pass — every rank issues its collectives in
-    // the same order, one per pass —, then the genotypes: the kernel writes its results straight into the pinned host block — they
-    // cross PCIe as they are produced —, which takes ~45 us for 100 k rows.  Meanwhile the compute stream already runs the next pass
-    // (that one zeroes and fills ITS count vector).
+    // The count all-reduce of this pass — every rank issues its collectives in the same order, one per pass — runs on the compute
+    // stream, between this pass's kernels and the next pass's: the classify kernel fills every CU (fourteen workers take 126 of a
+    // CU's 128 LDS granules and all the registers of two SIMDs), so a collective's workgroups find no room beside it and one queued
+    // on the second stream would only start when the NEXT pass's classify kernel drains — and hold back this pass's results, which
+    // the host waits for before it may enqueue the pass after.  (SVJG_ALLREDUCE_STREAM=second puts it there all the same: for a
+    // measurement on a multi-GPU box.)  Then, behind an event, on the second (low-priority) stream, the genotypes: one wave per CU
+    // fits beside the classify workers; the kernel writes its results straight into the pinned host block — they cross PCIe as they
+    // are produced —, which takes ~45 us for 100 k rows.  Meanwhile the compute stream already runs the next pass (that one zeroes
+    // and fills ITS count vector).
+    static const bool allreduce_second = [] { const char *e = getenv("SVJG_ALLREDUCE_STREAM"); return e && !strcmp(e, "second"); }();
+    auto reduce_on = [&](hipStream_t st) -> int {
+        int rc2 = launch_guard(c, r.counts, st);
+        if (rc2) return rc2;
+        ncclResult_t nr = ncclAllReduce(r.counts, r.counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, st);
+        if (nr != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(nr); return SVJG_E_RCCL; }
+        HIPCHK(c, hipMemcpyAsync(base + L.guard, r.counts + c->n_slots, 16, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    if (c->comm && !allreduce_second && (rc = reduce_on(c->stream))) return rc;
     HIPCHK(c, hipEventRecord(r.computed, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, r.computed, 0));
-    if (c->comm) {
-        if ((rc = launch_guard(c, r.counts, c->copy_stream))) return rc;
-        ncclResult_t nr = ncclAllReduce(r.counts, r.counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->copy_stream);
-        if (nr != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(nr); return SVJG_E_RCCL; }
-        HIPCHK(c, hipMemcpyAsync(base + L.guard, r.counts + c->n_slots, 16, hipMemcpyDeviceToDevice, c->copy_stream));
-    }
+    if (c->comm && allreduce_second && (rc = reduce_on(c->copy_stream))) return rc;
     if (n_rows) {
         HIPCHK(c, hipEventRecord(r.ev[4], c->copy_stream));
         // one wave per CU (see k_genotype); SVJG_GENO_GRID / SVJG_GENO_BLOCK: measurement only
