@@ -152,6 +152,9 @@ def main():
     import synth
     from svjg import capi, genotype, shard
     from svjg.graph import Graph
+    if os.environ.get("SVJG_BENCH_CAPI"):            # tests only: a stand-in for the library (tests/standin_capi.py), so that the
+        import importlib                             # launcher plumbing of this script can be run where there is no GPU
+        capi = importlib.import_module(os.environ["SVJG_BENCH_CAPI"])
 
     if n_local > 1:
         have = capi.device_count()
@@ -191,7 +194,7 @@ def main():
     rccl = None
     if world > 1:
         import dist_boot
-        shard.RcclGroup(ctxs[0], world, rank, dist_boot.torch_exchange)
+        getattr(capi, "RcclGroup", shard.RcclGroup)(ctxs[0], world, rank, dist_boot.torch_exchange)
         rccl = {"ranks": world, "init": "ncclCommInitRank, one process per GPU"}
     elif n_local > 1:
         capi.comm_init_all(ctxs)

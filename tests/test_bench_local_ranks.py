@@ -105,3 +105,25 @@ def test_bench_refuses_more_gpus_than_there_are(monkeypatch, capsys):
     with pytest.raises(SystemExit) as ei:
         bench.main()
     assert "needs 2 devices, found 1" in str(ei.value.code) and not capsys.readouterr().out.strip()
+
+
+def test_bench_under_the_launcher_two_ranks(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 …` — the form the scaling runs use — with the library
+    replaced by tests/standin_capi.py: rendezvous on 127.0.0.1, the unique id travelling from rank 0, one shard of the synthetic
+    stream per rank, the barriers around the timed passes, the maximum over the ranks, ONE JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SVJG_BENCH_CAPI="tests.standin_capi", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--aln", "2000", "--svs", "300", "--no-e2e", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["rccl"]["ranks"] == 2 and r["config"]["alignments_per_gpu"] == 2000
+    assert abs(r["value"] - 2 * 2000 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]
