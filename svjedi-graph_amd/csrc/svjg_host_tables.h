@@ -233,7 +233,9 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
         uint64_t slots = n + n / 4 + 16;                      // load <= 0.8
         for (int grow = 0;; ++grow) {
             kt.name_slots = (uint32_t)slots;
-            kt.name_buckets = (uint32_t)(n / 3 + 1);
+            uint32_t lambda = 3;                             // keys per bucket (SVJG_NAME_LAMBDA: measurement only)
+            { const char *e = getenv("SVJG_NAME_LAMBDA"); if (e && atoi(e) >= 1 && atoi(e) <= 16) lambda = (uint32_t)atoi(e); }
+            kt.name_buckets = (uint32_t)(n / lambda + 1);
             if (chd_place(hs, kt.name_slots, kt.name_buckets, kt.disp, slot_of)) break;
             if (grow == 6) { kt.names_left_out += n; hs.clear(); key_node.clear(); slot_of.clear(); break; }   // never seen: everything takes the exact path
             slots += slots / 4;
