@@ -475,8 +475,22 @@ def run(gaf_path, gfa_path, prefix, output_dir=None, device=None):
     t = [time.perf_counter()]
     graph = Graph.from_files(edges_json, gfa_path)
     _stamp(t, "edges JSON + GFA -> graph")
-    if gaf_path == "-":
-        counts, recs, data = classify_stream(graph, sys.stdin.buffer, want_hits=True, device=device or 0, _t=t)
+    stream = sys.stdin.buffer if gaf_path == "-" else None
+    if stream is None:
+        with open(gaf_path, "rb") as fh:
+            gz = fh.read(2) == b"\x1f\x8b"
+        if gz:
+            # An extension: a gzip-compressed GAF is inflated on the fly and classified while it is being read, like a
+            # pipe.  The reference cannot read such a file (its text-mode open() dies with UnicodeDecodeError on the second byte), so no
+            # input it accepts is treated differently.
+            import gzip
+            stream = gzip.open(gaf_path, "rb")
+    if stream is not None:
+        try:
+            counts, recs, data = classify_stream(graph, stream, want_hits=True, device=device or 0, _t=t)
+        finally:
+            if stream is not sys.stdin.buffer:
+                stream.close()
         capi.write_informative_json(out_json, data, recs, graph.sv_ids)
         _stamp(t, "write _informative_aln.json")
         write_handoff(out_json, graph.sv_ids, counts)

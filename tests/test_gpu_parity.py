@@ -1006,6 +1006,31 @@ def test_c4_whole_hundred_million_alignments(tmp_path):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def test_gzipped_gaf(ctx, tmp_path):
+    """`filter-alignments.py -a x.gaf.gz` (an extension: the reference cannot read it): the compressed file is inflated on the fly and
+    classified like a pipe; JSON and VCF are those of the plain file."""
+    import gzip
+    import subprocess
+    import sys
+    pre, gaf, g, orc = _synth_case(tmp_path, 30000, 800, 3, "mixed", 71)
+    open(pre + ".gaf", "wb").write(bytes(gaf))
+    with gzip.open(pre + "_z.gaf.gz", "wb", compresslevel=1) as fh:
+        fh.write(bytes(gaf))
+    amd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "svjedi-graph_amd")
+    outs = []
+    for name in (pre + ".gaf", pre + "_z.gaf.gz"):
+        p = subprocess.run([sys.executable, f"{amd}/filter-alignments.py", "-a", name, "-g", pre + ".gfa", "-p", pre], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        outs.append(open(pre + "_informative_aln.json", "rb").read())
+        os.remove(pre + "_informative_aln.json")
+    assert outs[0] == outs[1] and len(outs[0]) > 1000000
+    # a truncated gzip file: an error exit
+    raw = open(pre + "_z.gaf.gz", "rb").read()
+    open(pre + "_t.gaf.gz", "wb").write(raw[: len(raw) // 2])
+    p = subprocess.run([sys.executable, f"{amd}/filter-alignments.py", "-a", pre + "_t.gaf.gz", "-g", pre + ".gfa", "-p", pre], capture_output=True, text=True)
+    assert p.returncode == 1
+
+
 def test_gaf_through_a_pipe(tmp_path):
     """`filter-alignments.py -a -`: BASELINE configs[1]'s GAF (1 M alignments, 190 MB) written into the script's standard input in
     64 KB pieces; whole lines are classified while the rest is still arriving.  The JSON has the sha256 of the file the reference
