@@ -376,12 +376,17 @@ class Context:
         assert c.shape == (self.n_slots, 2)
         self._chk(self.lib.svjg_set_counts(self.h, c.ctypes.data, self.n_slots))
 
-    def hits(self):
+    def hits(self, out=None):
+        """the hit records of this context -> a new array, or into `out` (a contiguous slice of HITREC_DT sized stats()["n_hitrecs"]:
+        several contexts fill one array side by side, no concatenation afterwards)"""
         n = self.stats()["n_hitrecs"]
-        out = np.zeros(n, dtype=HITREC_DT)
+        if out is None:
+            out = np.empty(n, dtype=HITREC_DT)
+        assert out.dtype == HITREC_DT and out.flags["C_CONTIGUOUS"] and len(out) == n
         got = ctypes.c_uint64(0)
         self._chk(self.lib.svjg_get_hits(self.h, out.ctypes.data, n, ctypes.byref(got)))
-        return out[: got.value]
+        assert got.value == n
+        return out
 
     def host_lines(self):
         """byte offsets of the lines the kernels set aside for the host (svjg.h: SVJG_EXC_ASK_HOST), in file order"""

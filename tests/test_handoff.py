@@ -90,3 +90,35 @@ def test_error_order_of_a_file_that_is_not_utf8(golden):
     e = ValueError("x")
     e.svjg_offset = 8
     assert flt.reference_error(data, e) is e
+
+
+def test_gather_hits_fills_one_array():
+    """filter.gather_hits: the records of several contexts land side by side in one array, in context order (stand-in contexts)."""
+    import numpy as np
+    from svjg import capi, filter as flt
+
+    class Fake:
+        def __init__(self, n, tag):
+            self.n, self.tag = n, tag
+
+        def stats(self):
+            return {"n_hitrecs": self.n}
+
+        def hits(self, out=None):
+            if out is None:
+                out = np.empty(self.n, dtype=capi.HITREC_DT)
+            assert len(out) == self.n and out.flags["C_CONTIGUOUS"]
+            out["line_start"] = np.arange(self.n) + 1000 * self.tag
+            out["slot"] = self.tag
+            return out
+    ctxs = [Fake(5, 1), Fake(0, 2), Fake(7, 3)]
+    r = flt.gather_hits(ctxs)
+    assert len(r) == 12 and list(r["slot"]) == [1] * 5 + [3] * 7 and list(r["line_start"][:5]) == [1000 + i for i in range(5)] and r["line_start"][5] == 3000
+    assert len(flt.gather_hits([Fake(4, 9)])) == 4
+
+    class Broken(Fake):
+        def hits(self, out=None):
+            raise RuntimeError("copy failed")
+    import pytest
+    with pytest.raises(RuntimeError):
+        flt.gather_hits([Fake(2, 1), Broken(3, 2)])
