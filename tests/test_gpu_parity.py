@@ -51,6 +51,35 @@ def test_quirks(ctx, golden, name, all_slow, tmp_path):
         assert type(ei.value).__name__ == man["error"]
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_graphs(ctx, seed, tmp_path):
+    """tests/graph_fuzz.py: random GRAPHS — hazard-prone chromosome names, .1 / .10 insertion nodes, links with several SVs and both
+    alleles, links in both reading directions, palindromic links, hub nodes with more links than a record holds inline — and random
+    walks over them (up to 70 nodes, jumps, revisits, names the graph does not have, margins around the 100 bp rule): counts equal the
+    C oracle's, the JSON text equals the Python oracle's, main kernel and exact path."""
+    from tests import graph_fuzz
+    from svjg import capi
+    from svjg.graph import Graph
+    edges, alt, lines = graph_fuzz.make_case(1000 + seed, 3000)
+    text = "".join(lines).encode()
+    data = np.frombuffer(text, dtype=np.uint8)
+    orc = OC.COracle(edges, alt)
+    want, _, n = orc.filter(data, want_hits=False)
+    ref_text = O.dump_informative(O.classify(lines, edges, alt))
+    for all_slow in (False, True):
+        g = Graph(edges, alt, all_slow=all_slow)
+        ctx.load_graph(g)
+        ctx.reset_counts()
+        ctx.classify(data, want_hits=True)
+        assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 5000
+        st = ctx.stats()
+        assert st["n_lines"] == n == len(lines)
+        capi.write_informative_json(str(tmp_path / "o.json"), data, ctx.hits(), g.sv_ids)
+        assert open(tmp_path / "o.json").read() == ref_text
+        if not all_slow:                                           # most lines stay in the main kernel: long paths and unknown names leave it
+            assert st["n_deferred"] < 0.45 * n, st
+
+
 UNICODE = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "unicode")) if f.endswith(".gaf"))
 
 

@@ -95,3 +95,22 @@ def test_byte_classes_by_bit_planes():
     want = [b == 0x0A, b == 0x0D, b == 0x09, (b == 0x3C) | (b == 0x3E), ~(digit | (b == 0x09)), b == 0x64, b == 0x3A, b >= 0x80]
     for k, sel in enumerate(want):
         assert np.array_equal(got[:, k], mask(sel)), k
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_graphs(seed):
+    """tests/graph_fuzz.py: random graphs with hazard-prone names, multi-SV links, links in both reading directions, hub nodes; the
+    kernels' tables agree with the node table and the CSR rows, and the exact routine (through the tables and without them) counts
+    what the C oracle counts — which is what the Python oracle counts."""
+    from tests import graph_fuzz
+    edges, alt, lines = graph_fuzz.make_case(seed, 600)
+    g = Graph(edges, alt)
+    assert sim.check_tables(g) == 0
+    text = "".join(lines).encode()
+    orc = OC.COracle(edges, alt)
+    want, _, n = orc.filter(text, want_hits=False)
+    wd = {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
+    assert wd == {k: list(v) for k, v in O.counts_of(O.classify(lines, edges, alt)).items()} and sum(map(sum, wd.values())) > 1000
+    for tables in (True, False):
+        counts, n_lines = sim.classify(g, text, tables=tables)
+        assert n_lines == n and _as_dict(g, counts) == wd
