@@ -207,6 +207,9 @@ def graph_load_native(edges_json, gfa):
                 return np.zeros(0, dtype=dt)
             return np.frombuffer(ctypes.string_at(ptr, n * np.dtype(dt).itemsize), dtype=dt).copy()
         n_chrom = v.n_chrom
+        # (the field is declared c_char_p for the callers that PASS names in; read as such it is a Python bytes object cut at the first
+        #  NUL, and string_at() of that would run past its end: take the raw pointer)
+        names_ptr = ctypes.c_void_p.from_buffer(v, type(v).chrom_names.offset).value
         chrom_off = arr(v.chrom_off, n_chrom + 1, np.uint32)
         blob, blen, nhz = ctypes.c_void_p(), ctypes.c_uint64(0), ctypes.c_uint32(0)
         lib.svjg_graph_info(h, ctypes.byref(blob), ctypes.byref(blen), ctypes.byref(nhz))
@@ -215,7 +218,7 @@ def graph_load_native(edges_json, gfa):
             nodes=arr(v.nodes, v.n_nodes + 1, NODE_DT), n_nodes=int(v.n_nodes),
             edges=arr(v.edges, max(1, v.n_edges), EDGE_DT), n_edges=int(v.n_edges),
             hits=arr(v.hits, max(1, v.n_hits), np.uint32), n_hits=int(v.n_hits),
-            chrom_names=ctypes.string_at(v.chrom_names, int(chrom_off[-1]) + 4), chrom_off=chrom_off,
+            chrom_names=ctypes.string_at(names_ptr, int(chrom_off[-1]) + 4), chrom_off=chrom_off,
             chrom_lo=arr(v.chrom_node_lo, n_chrom + 1, np.uint32), sv_ids=sv, n_hazard=int(nhz.value))
     finally:
         lib.svjg_graph_free(h)

@@ -90,3 +90,24 @@ def test_irregular_inputs_are_left_to_python(tmp_path):
         assert capi.graph_load_native(p, q) is None, name
     with pytest.raises(OSError):
         capi.graph_load_native(str(tmp_path / "missing.json"), gfa)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_graphs(tmp_path, seed):
+    """tests/graph_fuzz.py's graphs (hazard-prone names, multi-SV links, links in both directions, hubs) written as the files the
+    reference's constructor writes (indent-4 JSON, GFA with the insertion nodes' sequences): native and Python loader build the same
+    tables, and those are the tables of the in-memory constructor."""
+    from tests import graph_fuzz
+    edges, alt, _ = graph_fuzz.make_case(300 + seed, 1)
+    p = str(tmp_path / "g_svs_edges.json")
+    open(p, "w").write(json.dumps(edges, indent=4))
+    with open(tmp_path / "g.gfa", "w") as fh:
+        fh.write("H\tVN:Z:1.0\n")
+        names = sorted({n for k in edges for n in (k.split("@")[0], k.split("@")[2])} | set(alt))
+        for n in names:
+            fh.write(f"S\t{n}\t{'ACGT' * (alt[n] // 4) + 'A' * (alt[n] % 4) if n in alt else '*'}\n")
+    py = Graph.from_files(p, str(tmp_path / "g.gfa"), native=False)
+    nat = Graph.from_files(p, str(tmp_path / "g.gfa"), native=True)
+    _same(py, nat)
+    _same(py, Graph(edges, alt))
+    assert py.n_hazard > 0 or seed >= 0
