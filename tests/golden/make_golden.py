@@ -694,6 +694,111 @@ def make_vcf():
     print("vcf: ok")
 
 
+def make_vcffuzz():
+    """golden/vcffuzz/cases.json: small VCFs whose rows are mutations of ordinary SV rows (INFO fields shuffled, dropped, doubled;
+    END / POS / ALT / SVTYPE edited; 8, 9 and 11 columns; blank columns) and, for each, a dictionary of informative alignments that
+    names the keys the untouched rows would get — through the reference's predict-genotype.py: its output text, stdout, or the
+    class of the exception it died with."""
+    import random
+    out = f"{HERE}/vcffuzz"
+    os.makedirs(out, exist_ok=True)
+    rng = random.Random(20260517)
+    hdr = ["##fileformat=VCFv4.2\n", "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"old\">\n", "##contig=<ID=1>\n",
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"]
+    seq = "ACGTTGCA" * 9
+
+    def base_row():
+        c = rng.choice(("1", "2", "chrX"))
+        pos = rng.choice((1000, 1000, 2000, 5000, 123456))
+        t = rng.choice(("DEL", "DEL", "INS", "INS", "INV", "BND", "DUP"))
+        if t == "DEL":
+            end = pos + rng.choice((30, 49, 50, 51, 700))
+            return [c, str(pos), "id", "N", "<DEL>", ".", "PASS", f"SVTYPE=DEL;END={end};SVLEN={pos - end}"], f"{c}:DEL-{pos}-{end}"
+        if t == "INV":
+            end = pos + rng.choice((10, 50, 900))
+            return [c, str(pos), "id", "N", "<INV>", ".", "PASS", f"SVTYPE=INV;END={end}"], f"{c}:INV-{pos}-{end}"
+        if t == "INS":
+            alt = rng.choice((seq, seq[:49], seq[:50], "<INS>", seq + "ACGT"))
+            return [c, str(pos), "id", "N", alt, ".", "PASS", f"SVTYPE=INS;END={pos};SVLEN={len(alt)}"], f"{c}:INS-{pos}-"
+        if t == "BND":
+            c2, p2 = rng.choice(("1", "3")), rng.choice((77, 9000))
+            alt = rng.choice((f"N[{c2}:{p2}[", f"N]{c2}:{p2}]", f"[{c2}:{p2}[N", f"]{c2}:{p2}]N", "<BND>", f"N[{p2}["))
+            key = {"N[": f"{c}:BND-{pos}[{c2}:{p2}[", "N]": f"{c}:BND-{pos}]{c2}:{p2}]", "[" + c2: f"{c}:BND-[{c2}:{p2}[{pos}", "]" + c2: f"{c}:BND-]{c2}:{p2}]{pos}"}.get(alt[:2], "wrong_format")
+            return [c, str(pos), "id", "N", alt, ".", "PASS", "SVTYPE=BND"], key
+        return [c, str(pos), "id", "N", "<DUP>", ".", "PASS", f"SVTYPE=DUP;END={pos + 400}"], "unsupported_type"
+
+    def mutate(cols):
+        cols = list(cols)
+        for _ in range(rng.choice((0, 1, 1, 2))):
+            op = rng.randrange(12)
+            f = cols[7].split(";")
+            if op == 0:
+                rng.shuffle(f); cols[7] = ";".join(f)
+            elif op == 1 and len(f) > 1:
+                del f[rng.randrange(len(f))]; cols[7] = ";".join(f)
+            elif op == 2:
+                f.insert(rng.randrange(len(f) + 1), rng.choice(("X=1", "SVTYPE=DEL", "END=1", "MATEID=a;b", "SVTYPE", "XEND=5", "END=abc", "CIEND=0,1"))); cols[7] = ";".join(f)
+            elif op == 3:
+                cols[7] = cols[7].replace("END=", rng.choice(("END=-", "end=", "END= ", "END=0")), 1)
+            elif op == 4:
+                cols[1] = rng.choice(("0", "x", "", "1e3", " 7", "007"))
+            elif op == 5:
+                cols[4] = rng.choice(("<DEL>", "N", "", ".", "A[", "[[", "]1:5]", "N[1:5", "[1:5[N]", "<INS>" * 12))
+            elif op == 6:
+                cols = cols + rng.choice((["GT", "0/1"], ["GT:DP", "0/1:3", "1/1:4"], ["GT"], []))
+            elif op == 7 and len(cols) > 8:
+                cols = cols[:8]
+            elif op == 8:
+                cols[7] = rng.choice(("", ".", "SVTYPE=", ";", "SVTYPE=DEL", "END=5;SVTYPE=INV;", "SVTYPE=INS;SVTYPE=DEL;END=9"))
+            elif op == 9:
+                cols[0] = rng.choice(("", "1", "chr 1", "1:2"))
+            elif op == 10:
+                cols[rng.randrange(len(cols))] = ""
+            else:
+                cols[7] = cols[7] + rng.choice((";", ";;", ";END=77", ";SVTYPE=BND"))
+        return cols
+
+    cases = []
+    tdir = tempfile.mkdtemp()
+    for i in range(260):
+        rows, D = [], {}
+        ins_n = {}
+        for _ in range(rng.choice((1, 2, 3, 5))):
+            cols, key = base_row()
+            if key.endswith("-") and key.count(":INS-"):
+                ins_n[cols[1]] = ins_n.get(cols[1], 0) + 1
+                key += str(ins_n[cols[1]])
+            if rng.random() < 0.8:
+                D[key] = [["x\n"] * rng.choice((0, 1, 3, 9, 40)), ["y\n"] * rng.choice((0, 2, 7, 40))]
+            if rng.random() < 0.6:
+                cols = mutate(cols)
+            rows.append("\t".join(cols) + "\n")
+        if rng.random() < 0.1:
+            rows[-1] = rows[-1].rstrip("\n")                       # no final newline
+        vcf = "".join(hdr + rows)
+        with open(f"{tdir}/c.vcf", "w") as fh:
+            fh.write(vcf)
+        with open(f"{tdir}/c.json", "w") as fh:
+            fh.write(json.dumps(D, sort_keys=True, indent=4))
+        ms = rng.choice((3, 3, 1, 0))
+        if os.path.exists(f"{tdir}/o.vcf"):
+            os.remove(f"{tdir}/o.vcf")
+        cmd = [sys.executable, f"{REF}/predict-genotype.py", "-d", f"{tdir}/c.json", "-v", f"{tdir}/c.vcf", "-o", f"{tdir}/o.vcf", "--minsupport", str(ms)]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        case = {"vcf": vcf, "counts": {k: [len(v[0]), len(v[1])] for k, v in D.items()}, "minsupport": ms, "rc": p.returncode}
+        if p.returncode == 0:
+            case["out"] = open(f"{tdir}/o.vcf").read()
+            case["stdout"] = p.stdout
+        else:
+            assert p.returncode == 1
+            case["error"] = p.stderr.strip().splitlines()[-1].split(":")[0]
+        cases.append(case)
+    with open(f"{out}/cases.json", "w") as fh:
+        json.dump(cases, fh, indent=0)
+    from collections import Counter
+    print("vcffuzz:", len(cases), "cases,", Counter(c.get("error", "ok") for c in cases))
+
+
 # ----------------------------------------------------------------------------------------------
 # G6 medium synthetic (needs tools/svjg_synth built)
 # ----------------------------------------------------------------------------------------------
@@ -969,7 +1074,7 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv"]
+    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz"]
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))

@@ -341,6 +341,31 @@ def test_vcf_cases(golden, tmp_path, tag, ms, err):
     assert p.stdout == open(f"{v}/ref_{tag}.stdout").read()
 
 
+def test_vcf_fuzz(golden, tmp_path, capsys):
+    """golden/vcffuzz: 260 small VCFs of mutated rows (INFO fields shuffled / dropped / doubled, edited END / POS / ALT / SVTYPE, 8..11
+    columns, blank columns, no final newline) with what the reference's predict-genotype.py wrote or died with: svjg.genotype.run (what
+    the drop-in script calls) writes the same file and stdout line, or raises the same exception class."""
+    from svjg import genotype
+    cases = json.load(open(f"{golden}/vcffuzz/cases.json"))
+    n_ok = 0
+    for i, c in enumerate(cases):
+        D = {k: [["x\n"] * a, ["y\n"] * b] for k, (a, b) in c["counts"].items()}
+        open(tmp_path / "c.json", "w").write(json.dumps(D, sort_keys=True, indent=4))
+        open(tmp_path / "c.vcf", "w").write(c["vcf"])
+        out = str(tmp_path / "o.vcf")
+        if c["rc"] == 0:
+            capsys.readouterr()
+            genotype.run(str(tmp_path / "c.json"), str(tmp_path / "c.vcf"), out, c["minsupport"])
+            assert capsys.readouterr().out == c["stdout"], i
+            assert open(out).read() == c["out"], i
+            n_ok += 1
+        else:
+            with pytest.raises(Exception) as ei:
+                genotype.run(str(tmp_path / "c.json"), str(tmp_path / "c.vcf"), out, c["minsupport"])
+            assert type(ei.value).__name__ == c["error"], i
+    assert n_ok > 150
+
+
 def test_error_order_when_the_gaf_is_not_utf8(ctx, golden, tmp_path):
     """golden/utf8order through the drop-in filter: the exception class is the reference's (UnicodeDecodeError of the text-mode read
     against the error of a malformed line, whichever the reference meets first)."""

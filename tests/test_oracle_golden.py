@@ -200,3 +200,22 @@ def test_realshape_lines(golden):
     assert {sv: [int(counts[i, 0]), int(counts[i, 1])] for i, sv in enumerate(orc.sv_ids) if counts[i].sum()} == \
         {k: [len(v[0]), len(v[1])] for k, v in ref.items()}
     assert n_lines == len(_read_lines(f"{r}/r.gaf"))
+
+
+def test_py_vcf_fuzz(golden):
+    """golden/vcffuzz: 260 small VCFs of mutated rows through the reference's predict-genotype.py — the Python oracle writes the same
+    text / stdout or dies with the same exception class."""
+    cases = json.load(open(f"{golden}/vcffuzz/cases.json"))
+    n_ok = 0
+    for c in cases:
+        D = {k: [["x\n"] * a, ["y\n"] * b] for k, (a, b) in c["counts"].items()}
+        lines = c["vcf"].splitlines(keepends=True)
+        if c["rc"] == 0:
+            text, n = O.genotype_vcf(lines, D, min_support=c["minsupport"])
+            assert text == c["out"] and f"Genotyped svs: {n}\n" == c["stdout"]
+            n_ok += 1
+        else:
+            with pytest.raises(Exception) as ei:
+                O.genotype_vcf(lines, D, min_support=c["minsupport"])
+            assert type(ei.value).__name__ == c["error"]
+    assert n_ok > 150
