@@ -799,6 +799,42 @@ def make_vcffuzz():
     print("vcffuzz:", len(cases), "cases,", Counter(c.get("error", "ok") for c in cases))
 
 
+def make_graphfuzz():
+    """golden/graphfuzz/cases.json: tests/graph_fuzz.py's random graphs and walks (seeds 9000..9039, 500 lines each) through the
+    reference's filter-alignments.py — per case the sha256 of the inputs (the generator is deterministic; the tests regenerate them),
+    the per-SV list lengths and the sha256 of the JSON the reference wrote."""
+    import hashlib
+    sys.path.insert(0, os.path.dirname(HERE))
+    import graph_fuzz
+    out = f"{HERE}/graphfuzz"
+    os.makedirs(out, exist_ok=True)
+    tdir = tempfile.mkdtemp()
+    cases = []
+    for seed in range(9000, 9040):
+        edges, alt, lines = graph_fuzz.make_case(seed, 500)
+        with open(f"{tdir}/g_svs_edges.json", "w") as fh:
+            fh.write(json.dumps(edges, indent=4))
+        with open(f"{tdir}/g.gfa", "w") as fh:
+            fh.write("H\tVN:Z:1.0\n")
+            for n in sorted({x for k in edges for x in (k.split("@")[0], k.split("@")[2])} | set(alt)):
+                fh.write(f"S\t{n}\t{'ACGT' * (alt[n] // 4) + 'A' * (alt[n] % 4) if n in alt else '*'}\n")
+        with open(f"{tdir}/g.gaf", "w") as fh:
+            fh.write("".join(lines))
+        js = f"{tdir}/g_informative_aln.json"
+        if os.path.exists(js):
+            os.remove(js)
+        rc, err = run_ref_filter(f"{tdir}/g.gaf", f"{tdir}/g.gfa", f"{tdir}/g")
+        assert rc == 0, err
+        text = open(js).read()
+        d = json.loads(text)
+        h_in = hashlib.sha256((json.dumps(edges, sort_keys=True) + json.dumps(alt, sort_keys=True) + "".join(lines)).encode()).hexdigest()
+        cases.append({"seed": seed, "n_lines": 500, "inputs_sha256": h_in, "json_sha256": hashlib.sha256(text.encode()).hexdigest(),
+                      "counts": {k: [len(v[0]), len(v[1])] for k, v in d.items()}})
+    with open(f"{out}/cases.json", "w") as fh:
+        json.dump(cases, fh, indent=0, sort_keys=True)
+    print("graphfuzz:", len(cases), "cases,", sum(sum(map(sum, c["counts"].values())) for c in cases), "informative alignments in all")
+
+
 # ----------------------------------------------------------------------------------------------
 # G6 medium synthetic (needs tools/svjg_synth built)
 # ----------------------------------------------------------------------------------------------
@@ -1074,7 +1110,7 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz"]
+    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz"]
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))

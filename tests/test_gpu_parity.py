@@ -80,6 +80,26 @@ def test_random_graphs(ctx, seed, tmp_path):
             assert st["n_deferred"] < 0.45 * n, st
 
 
+def test_graphfuzz_through_the_reference(ctx, golden, tmp_path):
+    """golden/graphfuzz: 40 random graphs x 500 random walks whose _informative_aln.json the REFERENCE wrote (per-SV list lengths and
+    the file's sha256 are committed; the inputs are regenerated from their seeds): the HIP path counts the same and the JSON it writes
+    has the reference's sha256."""
+    import hashlib
+    from svjg import capi
+    from svjg.graph import Graph
+    from tests.test_oracle_golden import _graphfuzz_case
+    for c in json.load(open(f"{golden}/graphfuzz/cases.json")):
+        edges, alt, lines = _graphfuzz_case(c)
+        data = np.frombuffer("".join(lines).encode(), dtype=np.uint8)
+        g = Graph(edges, alt)
+        ctx.load_graph(g)
+        ctx.reset_counts()
+        ctx.classify(data, want_hits=True)
+        assert _counts_dict(g, ctx.counts()) == c["counts"], c["seed"]
+        capi.write_informative_json(str(tmp_path / "o.json"), data, ctx.hits(), g.sv_ids)
+        assert hashlib.sha256(open(tmp_path / "o.json", "rb").read()).hexdigest() == c["json_sha256"], c["seed"]
+
+
 UNICODE = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "unicode")) if f.endswith(".gaf"))
 
 

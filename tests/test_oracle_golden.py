@@ -219,3 +219,29 @@ def test_py_vcf_fuzz(golden):
                 O.genotype_vcf(lines, D, min_support=c["minsupport"])
             assert type(ei.value).__name__ == c["error"]
     assert n_ok > 150
+
+
+def _graphfuzz_case(c):
+    import hashlib
+    from tests import graph_fuzz
+    edges, alt, lines = graph_fuzz.make_case(c["seed"], c["n_lines"])
+    h = hashlib.sha256((json.dumps(edges, sort_keys=True) + json.dumps(alt, sort_keys=True) + "".join(lines)).encode()).hexdigest()
+    if h != c["inputs_sha256"]:
+        pytest.skip("this interpreter's random module does not reproduce the generator's stream")
+    return edges, alt, lines
+
+
+def test_graphfuzz_through_the_reference(golden):
+    """golden/graphfuzz: 40 random graphs (hazard-prone names, multi-SV links, links in both reading directions, hubs) with 500 random
+    walks each, through the reference's filter-alignments.py: both oracles count what it counted, the Python oracle's JSON text has its
+    sha256."""
+    import hashlib
+    from oracle import oracle_c as OC
+    for c in json.load(open(f"{golden}/graphfuzz/cases.json")):
+        edges, alt, lines = _graphfuzz_case(c)
+        D = O.classify(lines, edges, alt)
+        assert {k: list(v) for k, v in O.counts_of(D).items()} == c["counts"], c["seed"]
+        assert hashlib.sha256(O.dump_informative(D).encode()).hexdigest() == c["json_sha256"], c["seed"]
+        orc = OC.COracle(edges, alt)
+        want, _, n = orc.filter("".join(lines).encode(), want_hits=False)
+        assert {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()} == c["counts"] and n == c["n_lines"]
