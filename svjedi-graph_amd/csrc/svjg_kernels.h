@@ -31,7 +31,11 @@ constexpr uint32_t TEXT = NHALF * HALF;          // 8 KB staged in LDS per strip
 // is denser than that is first cut down to its first half and only then sent to the exact path as a whole.
 constexpr uint32_t MAXL = 64;                       // line starts per stripe = lines of one round (one line per lane in the line phase)
 #ifndef SVJG_CAP_O
+#ifdef SVJG_W16
+#define SVJG_CAP_O 208
+#else
 #define SVJG_CAP_O 216
+#endif
 #endif
 constexpr uint32_t CAP_O = SVJG_CAP_O;              // orientation marks ('<' '>') per stripe
 constexpr uint32_t KMAX = 64;                    // path nodes per alignment handled by the main kernel: one wave pass (longer paths: exact path)
@@ -40,6 +44,20 @@ static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none
 
 // LDS of one worker (bytes); the hardware hands LDS out in units of 1280 bytes
 constexpr uint32_t L_TEXT = 0;                                             // staged text + slack for the word reads behind a name / column
+#ifdef SVJG_W16
+// MEASUREMENT VARIANT (tools/mkvariant.sh w16 -DSVJG_W16): sixteen workers per CU.  No non-digit bitmap (the nine decimal columns are
+// NOT tested for digits: results are right only for well-formed text), the per-line records take the tab bitmap's place after the
+// line phase, the marks' list is 16 bits of position + 8 bits of line per mark, 208 marks per stripe.
+constexpr uint32_t L_TBM = L_TEXT + TEXT + 64;
+constexpr uint32_t L_NDBM = L_TBM;                                         // (no such bitmap)
+constexpr uint32_t L_RL = L_TBM;
+constexpr uint32_t L_OPL = L_TBM + TEXT / 8 + 16;                          // u16[CAP_O + 8] positions, then u8[CAP_O + 8] line + 1
+constexpr uint32_t L_LINE = L_OPL + (CAP_O + 8) * 3;
+constexpr uint32_t LDS_MAIN = L_LINE + (MAXL + 8) * 4;
+constexpr uint32_t LDS_GRANULE = 1280;
+static_assert(LDS_MAIN <= 8 * LDS_GRANULE, "sixteen workers per CU");
+static_assert(L_TBM % 16 == 0 && L_OPL % 16 == 0 && L_LINE % 4 == 0, "LDS alignment");
+#else
 constexpr uint32_t L_NDBM = L_TEXT + TEXT + 64;                            // u32[TEXT/32 + 4] one bit per byte: neither a digit nor a tab (line phase only)
 constexpr uint32_t L_RL = L_NDBM;                                          // uint4[LRW] per line, written at the END of the line phase (the bitmap is dead by then):
                                                                            //   need_l, need_r, first mark (rel.) | k << 16 | status << 24, tab behind the path
@@ -51,6 +69,7 @@ constexpr uint32_t LDS_GRANULE = 1280;
 static_assert(LRW * 16 <= TEXT / 8 + 16, "the per-line records fit the bitmap they replace");
 static_assert(LDS_MAIN <= 9 * LDS_GRANULE, "fourteen workers per CU");
 static_assert(L_NDBM % 16 == 0 && L_TBM % 16 == 0 && L_OPL % 16 == 0 && L_LINE % 16 == 0 && L_RL % 16 == 0, "LDS alignment");
+#endif
 
 // status words (device)
 struct DevStatus {
@@ -301,7 +320,9 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
         }
     }
     if (sp + SPAN > V) nl64 &= sp >= V ? 0ull : ((1ull << (V - sp)) - 1ull);   // ignore anything at or beyond the valid length
+#ifndef SVJG_W16
     *(uint2 *)(ndbm + slot * 2) = make_uint2((uint32_t)nd64, (uint32_t)(nd64 >> 32));
+#endif
     *(uint2 *)(tbm + slot * 2) = make_uint2((uint32_t)tab64, (uint32_t)(tab64 >> 32));
     NL = nl64; ORI = ori64;
 }
@@ -403,7 +424,16 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     uint8_t *text = lds + L_TEXT;
     uint32_t *ndbm = (uint32_t *)(lds + L_NDBM);
     uint32_t *tbm = (uint32_t *)(lds + L_TBM);
+#ifdef SVJG_W16
+    uint16_t *OPLP = (uint16_t *)(lds + L_OPL);
+    uint8_t *OPLL = lds + L_OPL + (CAP_O + 8) * 2;
+#define OPL_PUT(j, v) do { const uint32_t v_ = (v); OPLP[j] = (uint16_t)v_; OPLL[j] = (uint8_t)((v_ >> 16) + 1u); } while (0)
+#define OPL_POS(j) ((uint32_t)OPLP[j])
+#else
     uint32_t *OPL = (uint32_t *)(lds + L_OPL);
+#define OPL_PUT(j, v) OPL[j] = (v)
+#define OPL_POS(j) (OPL[j] & 0xFFFFu)
+#endif
     uint32_t *LINE = (uint32_t *)(lds + L_LINE);                        // start | marks in front << 16
     uint4 *RL = (uint4 *)(lds + L_RL);                                  // (the bitmap's bytes: see L_RL)
 
@@ -639,12 +669,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t v0 = sp + ((sb - 1u) << 16);
                 for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {
                     const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                    OPL[j] = v0 + b + (b > t1 ? 0x10000u : 0u);
+                    OPL_PUT(j, v0 + b + (b > t1 ? 0x10000u : 0u));
                 }
             } else {
                 for (unsigned long long m = ORI[h]; m; m &= m - 1, ++j) {
                     const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                    OPL[j] = (sp + b) | ((sb + (uint32_t)__popcll(NL[h] & ((1ull << b) - 1ull)) - 1u) << 16);
+                    OPL_PUT(j, (sp + b) | ((sb + (uint32_t)__popcll(NL[h] & ((1ull << b) - 1ull)) - 1u) << 16));
                 }
             }
         }
@@ -683,7 +713,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // between two marks that holds it is no node name, and the node pass sends the line to the exact path.
                     k = kall;
                     const bool kfit = k >= 1 && k <= KMAX;
-                    const uint32_t m_first = OPL[o0] & 0xFFFFu, m_last = OPL[kfit ? o0 + k - 1 : o0] & 0xFFFFu;
+                    const uint32_t m_first = OPL_POS(o0), m_last = OPL_POS(kfit ? o0 + k - 1 : o0);
                     uint32_t t5 = tab_near(tbm, m_last + 1);
                     if (t5 == TEXT) {                                     // (a name of 32..48 bytes: the tab is at most 49 bytes behind the mark)
                         const uint32_t far = tab_near(tbm, m_last + 33 < TEXT ? m_last + 33 : TEXT);
@@ -703,7 +733,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // once instead of one dependent round trip per nested test).
                     const uint32_t u0 = ok ? t0 : 0u, u3 = ok ? t3 : 1u, u4 = ok ? t4 : 0u, u5 = ok ? t5 : 0u, u6 = ok ? t6 : 2u, u7 = ok ? t7 : 4u;
                     const uint32_t u8 = ok ? t8 : 6u, u9 = ok ? t9 : 8u, u10 = ok ? t10 : 10u, u11 = ok ? t11 : 12u;
+#ifdef SVJG_W16
+                    const bool digits = true;                            // (measurement variant: not tested)
+#else
                     const bool digits = bits_clear(ndbm, u0 + 1, u3 - u0 - 1) & bits_clear(ndbm, u5 + 1, u11 - u5 - 1);
+#endif
                     const bool alen0 = field_is_zero(text, u9 + 1, u10 - u9 - 1);   // Alen == 0: ZeroDivisionError (no id:f: tag in this stripe): exact path decides
                     // path column (t4, t5): the first orientation mark of the line right after t4, the last one in front of t5
                     // check_bkpt_overlap (filter-alignments.py:258-273) for a link of this line reads
@@ -777,9 +811,16 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (!(q > s && q + 4u <= e && text[q - 1u] == 'i' && text[q + 2u] == 'f' && text[q + 3u] == ':')) verdict = 0u;   // (inside the stripped line, like `in line`)
                         else {
                             const uint32_t v0 = q + 4u;                  // value = text[v0, first tab or end of the stripped line)
+#ifdef SVJG_W16
+                            const uint32_t tw = 0u, nw = 0u;             // (measurement variant: every tag takes the exact path)
+#else
                             const uint32_t tw = tab_window(tbm, v0), nw = tab_window(ndbm, v0);
+#endif
                             uint32_t n = tw ? (uint32_t)__builtin_ctz(tw) : 32u;
                             if (e - v0 < n) n = e - v0;
+#ifdef SVJG_W16
+                            n = 0u;
+#endif
                             if (n >= 1u && n <= 31u) {
                                 const uint32_t nd = nw & ((1u << n) - 1u);
                                 if (nd == 0u) verdict = 1u;
@@ -814,7 +855,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const wmask act_m = low_bits64(n_pass);
                 const bool act = in_mask(act_m);
                 const uint32_t o = obase + p0 + (act ? lane : 0u);
+#ifdef SVJG_W16
+                uint2 op2;
+                { const uint32_t pp = *(const u32_any *)(OPLP + o); op2.x = (pp & 0xFFFFu) | (((uint32_t)OPLL[o] - 1u) << 16); op2.y = pp >> 16; }
+#else
                 const uint2 op2 = *(const uint2 *)(OPL + o);             // (8-byte aligned or not: two dwords)
+#endif
                 const uint32_t opv = op2.x & 0xFFFFu;
                 const uint32_t ln = ((op2.x >> 16) - lbase) & (LRW - 1u);
                 const uint4 rl = RL[ln];
