@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 auto emit = [&](uint32_t hv, uint32_t jj) {
                     // counts[slot] = ref | alt << 32 is, in memory, the pair of 32-bit counters [2 * slot + allele] = [hv]: a 32-bit atomic
                     // (the memory-side atomic units take ~14 % more of those per second than 64-bit ones: profiles/r01_ubench_atomics.txt)
-                    if (!DIAG(8u)) atomicAdd(&((unsigned int *)a.counts)[hv], 1u);
+                    if (!DIAG(8u)) atomicAdd(&((unsigned int *)a.counts)[DIAG(4u) ? (hv & 1023u) : DIAG(64u) ? ((hv & 63u) | ((blockIdx.x & 1023u) << 6)) : hv], 1u);   // (4 / 64, ablation builds: all updates into 4 KB / into 256 B per worker)
                     if (a.want_hits) {
                         if (rbase + jj < a.rec_cap) {
                             svjg_hitrec r; r.line_start = a.base_offset + c0 + (LINE[lbase + ln] & 0xFFFFu); r.slot = hv >> 1;
