@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--svs", type=int, default=0, help="override the number of SVs (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed end-to-end block (files -> JSON -> VCF through the drop-in scripts)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the untimed north_star block (BASELINE configs[3] split over the GPUs of the run)")
     args = ap.parse_args()
 
     # Two ways to N GPUs: under a launcher (torch.distributed.run: WORLD_SIZE ranks, one GPU each, RCCL communicator from a

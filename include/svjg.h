@@ -47,6 +47,10 @@ extern "C" {
  * own int() / float() (svjedi-graph_amd/svjg/filter.py: resolve_host_lines), resubmitting an ASCII spelling of the line if the
  * reference accepts it. */
 #define SVJG_EXC_ASK_HOST        5
+/* -O / --dover given (SVJG_GRAPH_DOVER_LIST): argparse hands the reference a LIST, and the first comparison with it — the left
+ * overlap of the first link that has a candidate SV, after the node lengths of that sum were looked up — dies with
+ * TypeError (filter-alignments.py:52-57, :88, :153 -> :269). */
+#define SVJG_EXC_TYPE_ERROR      6
 
 typedef struct svjg_ctx svjg_ctx;
 
@@ -100,6 +104,10 @@ typedef struct {
 } svjg_graph;
 
 #define SVJG_GRAPH_ALL_SLOW 1u     /* route every alignment through the exact string path (debug / odd names) */
+/* The reference was given -O: d_over is a list there, and the first link with a candidate SV whose left-overlap sum can be formed
+ * raises TypeError (SVJG_EXC_TYPE_ERROR).  Every line takes the exact path (the flag implies SVJG_GRAPH_ALL_SLOW); lines in front
+ * of that link are classified — and may raise — as usual, and a file without such a link is written as the reference writes it. */
+#define SVJG_GRAPH_DOVER_LIST 16u
 
 /* One informative (alignment, SV) pair: what filter-alignments.py:163-166 appends, run-length encoded —
  * n_ref / n_alt = how many times the line is appended to the ref / alt list of that SV. */

@@ -23,7 +23,7 @@ import math
 import re
 from decimal import Decimal, getcontext
 
-D_OVER = 100  # filter-alignments.py:56,88 (the -O flag cannot be used)
+D_OVER = 100  # filter-alignments.py:56,88 (-O N leaves the list ["N"] there: TypeError at the first comparison)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -105,18 +105,20 @@ def classify_line(line, edges, alt_len, d_over=D_OVER):
             for sv_id, allele in edges[key]:
                 il = names.index(ln)
                 ir = names.index(rn)
-                left = sum(_node_len(n, alt_len) for n in names[: il + 1]) - rec["Ts"]
-                right = sum(_node_len(n, alt_len) for n in names[ir:]) - (rec["Tlen"] - rec["Te"] - 1)
-                if left >= d_over and right >= d_over:
+                # (:269-271 — each side is summed and compared in one expression, left first: under -O, where d_over is the
+                #  list argparse made, the left comparison raises TypeError before the right sum is formed)
+                left_ok = sum(_node_len(n, alt_len) for n in names[: il + 1]) - rec["Ts"] >= d_over
+                right_ok = sum(_node_len(n, alt_len) for n in names[ir:]) - (rec["Tlen"] - rec["Te"] - 1) >= d_over
+                if left_ok and right_ok:
                     hits.append((sv_id, allele))
     return hits
 
 
-def classify(gaf_lines, edges, alt_len):
-    """filter-alignments.py:119-166 — sv_id -> [[ref texts], [alt texts]]."""
+def classify(gaf_lines, edges, alt_len, d_over=D_OVER):
+    """filter-alignments.py:119-166 — sv_id -> [[ref texts], [alt texts]].  d_over: 100, or what `-O N` leaves there: ["N"]."""
     out = {}
     for line in gaf_lines:
-        for sv_id, allele in classify_line(line, edges, alt_len):
+        for sv_id, allele in classify_line(line, edges, alt_len, d_over):
             out.setdefault(sv_id, [[], []])[allele].append(line.split("cg:Z:")[0])
     return out
 

@@ -2,6 +2,7 @@
 // One context = one MI355X, one HIP stream; kernels live in svjg_kernels.h.
 #include "svjg_kernels.h"
 #include "svjg_host_tables.h"
+#include "svjg_pass.h"
 #include <rccl/rccl.h>
 #include <errno.h>
 #include <math.h>
@@ -21,8 +22,7 @@ static thread_local std::string g_init_error;
 
 // The main kernel's tables (perfect hash of the node names, link table) are built on the host from the graph: 0.25 s at 100 k SVs,
 // 2.5 s at 500 k.  A process that gives several contexts the same graph (one per GPU: filter-alignments.py, bench.py --gpus N)
-// builds them once: the most recent build is kept, keyed by the graph's arrays (addresses, sizes and a checksum of their
-// contents); the contexts' loads may come from several threads at once (the first builds, the others wait for it).
+// builds them once: the most recent build is kept, keyed by the sizes and two digests of everything the build reads (graph_digest); the contexts' loads may come from several threads at once (the first builds, the others wait for it).
 #include <memory>
 #include <mutex>
 namespace {
@@ -33,17 +33,28 @@ struct TablesCache {
 } g_tables;
 
 uint64_t fold64(const void *p, size_t n, uint64_t h) {
-    const uint64_t *w = (const uint64_t *)p;
-    for (size_t i = 0; i < n / 8; ++i) { h = (h ^ w[i]) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    if (n & 7) { uint64_t w = 0; memcpy(&w, b + (n & ~(size_t)7), n & 7); h = (h ^ w ^ ((uint64_t)(n & 7) << 56)) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }   // (the last n % 8 bytes count too)
     return h;
 }
 
+// everything build_kernel_tables reads — node, edge and hit arrays, the chromosome names' BYTES (every node name is spelled from
+// them), chrom_off, chrom_node_lo, d_over, flags — under two seeds.  No addresses: a freed graph's arrays are handed out again.
+uint64_t graph_digest(const svjg_graph &g, uint64_t seed) {
+    uint64_t h = seed;
+    h = fold64(g.nodes, (size_t)(g.n_nodes + 1) * sizeof(svjg_node), h);
+    h = fold64(g.edges, (size_t)g.n_edges * sizeof(svjg_edge), h ^ g.n_edges);
+    h = fold64(g.hits, (size_t)g.n_hits * sizeof(uint32_t), h ^ g.n_hits);
+    h = fold64(g.chrom_off, (size_t)(g.n_chrom + 1) * sizeof(uint32_t), h ^ g.n_chrom);
+    h = fold64(g.chrom_node_lo, (size_t)(g.n_chrom + 1) * sizeof(uint32_t), h);
+    h = fold64(g.chrom_names, (size_t)g.chrom_off[g.n_chrom], h);
+    const uint64_t tail[3] = {g.d_over, g.flags, g.n_slots};
+    return fold64(tail, sizeof tail, h);
+}
+
 std::shared_ptr<const KernelTables> kernel_tables_for(const svjg_graph &g) {
-    uint64_t key[6] = {(uint64_t)(uintptr_t)g.nodes, g.n_nodes, (uint64_t)(uintptr_t)g.edges, g.n_edges, g.n_hits, 0};
-    key[5] = fold64(g.nodes, (size_t)(g.n_nodes + 1) * sizeof(svjg_node), 1);
-    key[5] = fold64(g.edges, (size_t)g.n_edges * sizeof(svjg_edge), key[5]);
-    key[5] = fold64(g.hits, (size_t)g.n_hits * sizeof(uint32_t), key[5]);
-    key[5] = fold64(g.chrom_off, (size_t)(g.n_chrom + 1) / 2 * 8, key[5] ^ g.n_chrom);
+    const uint64_t key[6] = {g.n_nodes, g.n_edges, g.n_hits, g.n_chrom, graph_digest(g, 1), graph_digest(g, 0xD6E8FEB86659FD93ull)};
     std::lock_guard<std::mutex> lk(g_tables.mu);              // (held while building: a second loader of the same graph waits, then reuses)
     if (!g_tables.kt || memcmp(key, g_tables.key, sizeof key) != 0) {
         g_tables.kt = std::make_shared<const KernelTables>(build_kernel_tables(g));
@@ -260,14 +271,16 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     c->gv.nodes = c->d_nodes; c->gv.n_nodes = (uint32_t)g->n_nodes; c->gv.edges = c->d_edges; c->gv.hits = c->d_hits;
     c->gv.chrom_names = c->d_cnames; c->gv.chrom_off = c->d_coff; c->gv.chrom_lo = c->d_clo; c->gv.chrom_hash = c->d_chash;
     c->gv.n_chrom = g->n_chrom; c->gv.hash_mask = (uint32_t)hash.size() - 1; c->gv.d_over = g->d_over;
+    c->gv.dover_list = (g->flags & SVJG_GRAPH_DOVER_LIST) ? 1u : 0u;
     c->gv.node_of_kid = c->d_nok; c->gv.name_tab = c->d_names; c->gv.name_ihits = c->d_ihits; c->gv.name_disp = c->d_disp; c->gv.name_slots = kt.name_slots; c->gv.name_buckets = kt.name_buckets;
     c->gv.name_complete = (kt.names_left_out == 0 && kt.names_skipped == 0) ? 1u : 0u;
     c->gv.link_tab = c->d_links; c->gv.link_mask = kt.link_mask; c->gv.link_seed = kt.link_seed;
     c->gflags = g->flags;
+    if (g->flags & SVJG_GRAPH_DOVER_LIST) c->gflags |= SVJG_GRAPH_ALL_SLOW;   // (the exact routine knows where the reference's TypeError sits)
     if (kt.links_left_out) c->gflags |= SVJG_GRAPH_ALL_SLOW;   // a link the main kernel could not find would be a silent miss
     c->n_slots = g->n_slots;
-    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)g->n_slots + 2) * 8));
-    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)g->n_slots + 2) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)g->n_slots + GUARD_WORDS) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)g->n_slots + GUARD_WORDS) * 8));
     c->have_graph = true; c->have_counts = true;
     undo.armed = false;
     return svjg_reset_counts(c);
@@ -278,8 +291,8 @@ extern "C" int svjg_alloc_counts(svjg_ctx *c, uint32_t n_slots) {
     HIPCHK(c, hipSetDevice(c->device));
     free_graph(c);
     c->n_slots = n_slots;
-    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)n_slots + 2) * 8));
-    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)n_slots + 2) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_counts, ((uint64_t)n_slots + GUARD_WORDS) * 8));
+    HIPCHK(c, hipMalloc((void **)&c->d_snap, ((uint64_t)n_slots + GUARD_WORDS) * 8));
     c->have_counts = true;
     return svjg_reset_counts(c);
 }
@@ -288,7 +301,7 @@ extern "C" int svjg_reset_counts(svjg_ctx *c) {
     if (!c || !c->have_counts) return SVJG_E_ARG;
     c->counts_in_slot = -1;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, ((uint64_t)c->n_slots + 2) * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, ((uint64_t)c->n_slots + GUARD_WORDS) * 8, c->stream));
     return reset_status(c, true);                             // (nothing to wait for: the next call on the stream comes behind both)
 }
 
@@ -401,7 +414,7 @@ static int fetch_slot_counts(svjg_ctx *c) {
     c->counts_in_slot = -1;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->run[k].copied) HIPCHK(c, hipStreamWaitEvent(c->stream, c->run[k].copied, 0));   // (the pass's all-reduce runs on the second stream)
-    HIPCHK(c, hipMemcpyAsync(c->d_counts, c->run[k].counts, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_counts, c->run[k].counts, ((uint64_t)c->n_slots + GUARD_WORDS) * 8, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
@@ -460,7 +473,7 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         if ((rc = ensure(c, (void **)&c->d_host, &c->host_cap, host_want, sizeof(uint64_t), true))) return rc;
         if (want_hits && (rc = ensure(c, (void **)&c->d_recs, &c->rec_cap, rec_want, sizeof(svjg_hitrec), true))) return rc;
         // snapshot so that an overflowed attempt can be rolled back
-        HIPCHK(c, hipMemcpyAsync(c->d_snap, c->d_counts, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_snap, c->d_counts, ((uint64_t)c->n_slots + GUARD_WORDS) * 8, hipMemcpyDeviceToDevice, c->stream));
         DevStatus before = c->hs();
         if ((rc = reset_status(c, false))) return rc;
         ClassifyArgs a{};
@@ -513,7 +526,7 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         if (c->hs().overflow & 1u) def_want = n / 24 + 64;
         if (c->hs().overflow & 2u) rec_want = before.n_recs + (c->hs().n_recs - before.n_recs) * 2 + n / 24 + 64;
         if (c->hs().overflow & 4u) host_want = before.n_host + n / 24 + 64;
-        HIPCHK(c, hipMemcpyAsync(c->d_counts, c->d_snap, ((uint64_t)c->n_slots + 2) * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_counts, c->d_snap, ((uint64_t)c->n_slots + GUARD_WORDS) * 8, hipMemcpyDeviceToDevice, c->stream));
         uint64_t keep_err = before.err;
         c->hs() = before; c->hs().err = keep_err;
     }
@@ -716,26 +729,28 @@ extern "C" int svjg_comm_init(svjg_ctx *c, const char *id128, int n_ranks, int r
     return 0;
 }
 
-// the two guard elements behind the count vector <- largest ref / alt field (k_counts_guard)
-static int launch_guard(svjg_ctx *c, unsigned long long *counts = nullptr, hipStream_t stream = nullptr) {
+// the guard elements behind the count vector (svjg_pass.h) <- largest ref / alt field, and — st given: a fused pass — whether this
+// rank's pass must be repeated (k_counts_guard)
+static int launch_guard(svjg_ctx *c, unsigned long long *counts = nullptr, hipStream_t stream = nullptr, const DevStatus *st = nullptr) {
     if (!counts) counts = c->d_counts;
     if (!stream) stream = c->stream;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(counts + c->n_slots, 0, 16, stream));
-    if (c->n_slots) {
+    HIPCHK(c, hipMemsetAsync(counts + c->n_slots, 0, GUARD_WORDS * 8, stream));
+    if (c->n_slots || st) {
         uint32_t grid = (c->n_slots + TPB - 1) / TPB;
         if (grid > 1024) grid = 1024;
-        hipLaunchKernelGGL(k_counts_guard, dim3(grid), dim3(TPB), 0, stream, counts, c->n_slots);
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(k_counts_guard, dim3(grid), dim3(TPB), 0, stream, counts, c->n_slots, st);
         HIPCHK(c, hipGetLastError());
     }
     return 0;
 }
 static int check_guard(svjg_ctx *c) {
-    unsigned long long g[2] = {0, 0};
+    unsigned long long g[GUARD_WORDS] = {0, 0, 0};
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(g, c->d_counts + c->n_slots, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(g, c->d_counts + c->n_slots, sizeof g, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (g[0] >= (1ull << 32) || g[1] >= (1ull << 32)) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
+    if (pass_counts_overflowed(g[GUARD_MAX_REF], g[GUARD_MAX_ALT])) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
     return 0;
 }
 
@@ -746,7 +761,7 @@ extern "C" int svjg_allreduce_counts(svjg_ctx *c) {
     if (!c->comm) { c->err = "svjg_comm_init has not been called"; return SVJG_E_ARG; }
     int rc = launch_guard(c);
     if (rc) return rc;
-    ncclResult_t r = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
+    ncclResult_t r = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + GUARD_WORDS, ncclUint64, ncclSum, c->comm, c->stream);
     if (r != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return SVJG_E_RCCL; }
     return check_guard(c);
 }
@@ -785,7 +800,7 @@ extern "C" int svjg_allreduce_counts_all(svjg_ctx *const *ctxs, int n) {
         for (int i = 0; i < n && r == ncclSuccess; ++i) {
             svjg_ctx *c = ctxs[i];
             if (hipSetDevice(c->device) != hipSuccess) { ctxs[0]->err = "hipSetDevice"; ncclGroupEnd(); return SVJG_E_HIP; }
-            r = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, c->stream);
+            r = ncclAllReduce(c->d_counts, c->d_counts, (size_t)c->n_slots + GUARD_WORDS, ncclUint64, ncclSum, c->comm, c->stream);
         }
         const ncclResult_t r2 = ncclGroupEnd();
         if (r == ncclSuccess) r = r2;
@@ -914,7 +929,7 @@ static RunLayout run_layout(uint64_t n) {
     RunLayout L; uint64_t o = 0;
     L.pl32 = o; o += n * 12; L.raw = o; o += n * 8; L.gt = o; o += n; L.flags = o; o += n; L.boundary = o; o += n; o = (o + 63) & ~63ull; L.h_tail = o;
     uint64_t d = 0;
-    L.maxn = d; d += 8; L.status = d; d += (sizeof(DevStatus) + 7) & ~7ull; L.guard = d; d += 16; L.tail_bytes = d;
+    L.maxn = d; d += 8; L.status = d; d += (sizeof(DevStatus) + 7) & ~7ull; L.guard = d; d += GUARD_WORDS * 8; L.tail_bytes = d;
     L.out_bytes = L.h_tail + L.tail_bytes;
     d = (d + 63) & ~63ull; L.pl64 = d; d += n * 24; L.total = d + 64;
     return L;
@@ -939,7 +954,7 @@ extern "C" int svjg_set_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t
             r.h_cap = L.out_bytes;
             HIPCHK(c, hipHostGetDevicePointer(&r.h_dev, r.h, 0));
         }
-        if ((rc = ensure(c, (void **)&r.counts, &r.counts_cap, (uint64_t)c->n_slots + 2, sizeof(unsigned long long), false))) return rc;
+        if ((rc = ensure(c, (void **)&r.counts, &r.counts_cap, (uint64_t)c->n_slots + GUARD_WORDS, sizeof(unsigned long long), false))) return rc;
         for (auto &e : r.ev) if (!e) HIPCHK(c, hipEventCreate(&e));
         if (!r.computed) HIPCHK(c, hipEventCreateWithFlags(&r.computed, hipEventDisableTiming));
         if (!r.copied) HIPCHK(c, hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
@@ -989,10 +1004,10 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
     r.base_offset = base_offset; r.min_support = min_support; r.err = err;
     uint8_t *base = (uint8_t *)r.d;
     DevStatus *d_st = (DevStatus *)(base + L.status);             // (the pass's own status block: its tail goes to the host in one small copy)
-    if (r.counts_cap < (uint64_t)c->n_slots + 2) { c->err = "svjg_set_rows must follow svjg_load_graph"; return SVJG_E_ARG; }
+    if (r.counts_cap < (uint64_t)c->n_slots + GUARD_WORDS) { c->err = "svjg_set_rows must follow svjg_load_graph"; return SVJG_E_ARG; }
     GenoArgs ga = run_geno_args(c, r, L, min_support, err, r.counts);
     {
-        const uint64_t words = (uint64_t)c->n_slots + 2;
+        const uint64_t words = (uint64_t)c->n_slots + GUARD_WORDS;
         uint32_t rg = (uint32_t)((words + TPB - 1) / TPB);
         if (rg > 1024) rg = 1024;
         hipLaunchKernelGGL(k_step_reset, dim3(rg), dim3(TPB), 0, c->stream, r.counts, words, d_st, ga.max_n);
@@ -1007,8 +1022,12 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         HIPCHK(c, hipEventRecord(r.ev[0], c->stream));
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
         HIPCHK(c, hipEventRecord(r.ev[1], c->stream));
-        // the exact path for up to wave_limit lines, their number read on the device (more: the pass is repeated step by step)
+        // the exact path, the number of deferred lines read on the device: one wave per line for up to wave_limit lines, one lane per
+        // line beyond it (each kernel works only when the number lies in its range: a few microseconds otherwise).  So whatever a shard
+        // defers is counted before the pass's all-reduce; only a LIST that overflowed makes the pass repeat (svjg_pass.h).
         hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)c->n_cu), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, 0ull, wave_limit);
+        const uint64_t lane_blocks = (uint64_t)c->n_cu * (160u * 1024u / (SLOW_LANE_LDS + 1024u));
+        hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)lane_blocks), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, wave_limit, ~0ull - 1);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(r.ev[2], c->stream));
     }
@@ -1023,11 +1042,11 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
     // and fills ITS count vector).
     static const bool allreduce_second = [] { const char *e = getenv("SVJG_ALLREDUCE_STREAM"); return e && !strcmp(e, "second"); }();
     auto reduce_on = [&](hipStream_t st) -> int {
-        int rc2 = launch_guard(c, r.counts, st);
+        int rc2 = launch_guard(c, r.counts, st, d_st);                  // (guard word 2: "this rank's lists overflowed")
         if (rc2) return rc2;
-        ncclResult_t nr = ncclAllReduce(r.counts, r.counts, (size_t)c->n_slots + 2, ncclUint64, ncclSum, c->comm, st);
+        ncclResult_t nr = ncclAllReduce(r.counts, r.counts, (size_t)c->n_slots + GUARD_WORDS, ncclUint64, ncclSum, c->comm, st);
         if (nr != ncclSuccess) { c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(nr); return SVJG_E_RCCL; }
-        HIPCHK(c, hipMemcpyAsync(base + L.guard, r.counts + c->n_slots, 16, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(base + L.guard, r.counts + c->n_slots, GUARD_WORDS * 8, hipMemcpyDeviceToDevice, st));
         return 0;
     };
     if (c->comm && !allreduce_second && (rc = reduce_on(c->stream))) return rc;
@@ -1076,26 +1095,27 @@ extern "C" int svjg_run_end(svjg_ctx *c, const uint8_t **gt, const int32_t **pl,
         if (c->hs().n_deferred) HIPCHK(c, hipEventElapsedTime(&c->ms_slow, r.ev[1], r.ev[2]));
     }
     if (n_rows) HIPCHK(c, hipEventElapsedTime(&c->ms_geno, r.ev[4], r.ev[5]));
-    const uint64_t wave_limit = 16 * (uint64_t)c->n_cu * 4;
     bool again = false;
     const unsigned long long *redo_counts = r.counts;             // (a repeated genotype pass reads the slot's vector, or d_counts after the step-by-step fallback)
-    if (c->hs().overflow || c->hs().n_deferred > wave_limit) {
-        // the list of deferred lines was too short, or holds more lines than one wave per line is good for: the pass again, step by
-        // step (classify_range sizes the list, picks the exact-path kernel and retries), behind whatever is enqueued already
+    const unsigned long long *gd = (const unsigned long long *)(tail + L.guard);   // (meaningful under a communicator: the sums over the ranks)
+    if (pass_repeats(c->comm != nullptr, c->hs().overflow, gd[GUARD_REPEAT])) {
+        // a list of this rank — or, under a communicator, of ANY rank (svjg_pass.h: the ranks decide together, so all of them issue the
+        // one more all-reduce below) — was too short: the pass again, step by step (classify_range sizes the lists, picks the exact-path
+        // kernel and retries), behind whatever is enqueued already.  The all-reduce is issued even when this rank's text turns out to be
+        // malformed: its peers are waiting in theirs.
         if ((rc = svjg_reset_counts(c))) return rc;
         rc = classify_range(c, 0, n, r.base_offset, 0);
+        if (rc && rc != SVJG_E_INPUT) return rc;
+        if (c->comm) { const std::string keep = c->err; const int rc2 = svjg_allreduce_counts(c); if (rc2 && !rc) return rc2; if (rc) c->err = keep; }
         if (rc) return rc;
-        if (c->comm && (rc = svjg_allreduce_counts(c))) return rc;
         again = true; redo_counts = c->d_counts;
     } else {
         c->total_deferred = c->hs().n_deferred;
         if (c->hs().err != ~0ull) return SVJG_E_INPUT;
-        if (c->hs().n_host) { c->err = "the text holds lines only the host can decide (non-ASCII digits in a decimal column: svjg_get_host_lines); classify it with svjg_classify"; return SVJG_E_ARG; }
-        if (c->comm) {
-            const unsigned long long *gd = (const unsigned long long *)(tail + L.guard);
-            if (gd[0] >= (1ull << 32) || gd[1] >= (1ull << 32)) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
-        }
+        if (c->comm && pass_counts_overflowed(gd[GUARD_MAX_REF], gd[GUARD_MAX_ALT])) { c->err = "more than 2^32 informative alignments for one SV"; return SVJG_E_OVERFLOW; }
     }
+    // (either way: lines the kernels set aside for the host are neither counted nor fatal — the caller has to know)
+    if (c->hs().n_host) { c->err = "the text holds lines only the host can decide (non-ASCII digits in a decimal column: svjg_get_host_lines); classify it with svjg_classify"; return SVJG_E_ARG; }
     if (n_rows) {
         for (int attempt = 0;; ++attempt) {
             if (!again) {

@@ -68,6 +68,7 @@ namespace svjg {
 constexpr uint32_t NAME_ENT_WORDS = 16, LINK_ENT_WORDS = 4;
 constexpr uint32_t LINK_NO_HIT = 0xFFFFFFFFu, LINK_MANY = 0x80000000u;
 constexpr uint32_t NAME_EMPTY = 0xFFFFFFFFu, NAME_MAX_ID = (1u << 24) - 2u;
+static_assert((uint64_t)NAME_MAX_ID + 1 < (1ull << (32 - NAME_ID_SHIFT)), "a record keeps id << NAME_ID_SHIFT in one word, all ones = empty");
 constexpr uint32_t REC_ROW_INLINE = 0x80000000u, REC_NO_LINK = 0xFFFFFFFFu, REC_MANY = 0x80000000u;
 inline bool name_ent_empty(const uint32_t *e) { return e[6] == NAME_EMPTY; }
 inline uint32_t name_ent_len(const uint32_t *e) { return (e[6] & NAME_LEN_MASK) + 1u; }
@@ -200,7 +201,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             uint32_t c = (uint32_t)(nd.key >> 48), pos = (uint32_t)(nd.key >> 16), kind = (uint32_t)(nd.key >> 15) & 1u, cnt = (uint32_t)nd.key & 0x7FFFu;
             std::string nm(g.chrom_names + g.chrom_off[c], g.chrom_off[c + 1] - g.chrom_off[c]);
             nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
-            if (nm.size() > 4 * NAME_WORDS || i > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path
+            if (nm.size() > 4 * NAME_WORDS || kid[i] > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path (the record holds the WALK-ORDER id in 24 bits)
             uint32_t d[NAME_WORDS];
             name_windows(nm.data(), 0, (uint32_t)nm.size(), d);
             uint32_t flags = ((nd.row & 0x80000000u) ? 1u : 0u) | ((kind && nd.aux == SVJG_LEN_UNKNOWN) ? 2u : 0u);
@@ -263,7 +264,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
                 for (uint32_t i = a; i < b; ++i) {
                     const svjg_edge &ed = g.edges[i];
                     const uint32_t nh = ed.meta >> 2;
-                    if (!nh || ed.right > NAME_MAX_ID) continue;
+                    if (!nh || kid[ed.right] > NAME_MAX_ID) continue;
                     bool alt = false;
                     for (uint32_t q = 0; q < nh; ++q) alt |= ((nh <= 2 ? (q ? ed.h1 : ed.h0) : g.hits[ed.h0 + q]) & 1u) != 0;
                     if ((int)alt == pass) rows.push_back(i);

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "svjg_line.h"
 #include "svjg_planes.h"
+#include "svjg_pass.h"
 
 namespace svjg {
 
@@ -1234,7 +1235,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
 // all-reduce): the largest ref field and the largest alt field go to the two extra elements behind the vector, which travel
 // through the same all-reduce; if the SUM over the ranks of these maxima stays below 2^32 no slot can have carried from one
 // half into the other (the host then mirrors the OverflowError of a Python-side sum).
-__global__ __launch_bounds__(TPB) void k_counts_guard(unsigned long long *counts, uint32_t n_slots) {
+__global__ __launch_bounds__(TPB) void k_counts_guard(unsigned long long *counts, uint32_t n_slots, const DevStatus *st) {
     uint32_t mr = 0, ma = 0;
     for (uint32_t i = blockIdx.x * TPB + threadIdx.x; i < n_slots; i += gridDim.x * TPB) {
         const unsigned long long c = counts[i];
@@ -1243,9 +1244,11 @@ __global__ __launch_bounds__(TPB) void k_counts_guard(unsigned long long *counts
     }
     for (int d = 32; d; d >>= 1) { const uint32_t y = __shfl_down(mr, d), z = __shfl_down(ma, d); mr = mr > y ? mr : y; ma = ma > z ? ma : z; }
     if ((threadIdx.x & 63) == 0) {
-        if (mr) atomicMax(&counts[n_slots], (unsigned long long)mr);
-        if (ma) atomicMax(&counts[n_slots + 1], (unsigned long long)ma);
+        if (mr) atomicMax(&counts[n_slots + GUARD_MAX_REF], (unsigned long long)mr);
+        if (ma) atomicMax(&counts[n_slots + GUARD_MAX_ALT], (unsigned long long)ma);
     }
+    // a fused pass under a communicator: "this rank must repeat the pass" travels through the pass's own all-reduce (svjg_pass.h)
+    if (st && blockIdx.x == 0 && threadIdx.x == 0) counts[n_slots + GUARD_REPEAT] = pass_repeat_word(st->overflow);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct GraphView {
     uint32_t n_chrom;
     uint32_t hash_mask;
     uint32_t d_over;
+    uint32_t dover_list;         // SVJG_GRAPH_DOVER_LIST: the comparison with d_over raises TypeError (filter-alignments.py -O)
     const uint32_t *name_ihits;  // hit lists of the records' inline links with more than one hit
     const uint32_t *name_tab;    // canonical node name -> node record (svjg_host_tables.h), 16 words (one 64-byte line) per slot
     const uint16_t *name_disp;   // perfect hash of the node names: displacement of every bucket
@@ -429,6 +430,7 @@ SVJG_HD int slow_wave_phase2(const GraphView &g, const SlowLine &ln, const NodeS
         while (ns.id[ir] != rid) ++ir;
         int64_t left = 0, right = 0;
         for (uint32_t j = 0; j <= il; ++j) { if (ns.rc[j]) { *order = (2ull << 32) | i; return ns.rc[j]; } left += ns.len[j]; }
+        if (g.dover_list) { *order = (2ull << 32) | i; return SVJG_EXC_TYPE_ERROR; }   // int >= list (:269), before the right sum is formed
         for (uint32_t j = ir; j < ln.k; ++j) { if (ns.rc[j]) { *order = (2ull << 32) | i; return ns.rc[j]; } right += ns.len[j]; }
         if (left - ln.Ts >= (int64_t)g.d_over && right - (ln.Tlen - ln.Te - 1) >= (int64_t)g.d_over)
             for (uint32_t j = 0; j < nh; ++j) { uint32_t hv = edge_hit(g, ed, j); emit(hv >> 1, hv & 1u); }
@@ -488,6 +490,7 @@ SVJG_HD int slow_line(const GraphView &g, P t, uint64_t s, uint64_t e, Emit &emi
         int64_t left = 0, right = 0, l1;
         pos = ps;
         for (uint32_t j = 0; j <= il; ++j) { next_node(t, pe, oriented, pos, nm); int rc = generic_node_len(g, t, nm, l1); if (rc) return rc; left += l1; }
+        if (g.dover_list) return SVJG_EXC_TYPE_ERROR;             // int >= list (:269), before the right sum is formed
         pos = ps;
         for (uint32_t j = 0; j < k; ++j) {
             next_node(t, pe, oriented, pos, nm);

@@ -22,11 +22,10 @@ def main():
     ap.add_argument("-o", "--outputDir", metavar="<outputDirectory>", type=str, required=False)
     ap.add_argument("-p", "--prefix", metavar="<prefix", type=str, required=False)
     args = ap.parse_args()
-    if args.dover != 100:
-        # the reference compares an int with the list argparse produced and dies with TypeError
-        raise TypeError("'>=' not supported between instances of 'int' and 'list'")
     from svjg import filter as flt
-    flt.run(args.gaf[0], args.gfa[0], args.prefix, args.outputDir)
+    # -O: argparse (nargs=1, no type) hands the reference a list of one string; it dies with TypeError where it first compares an
+    # overlap with it (filter-alignments.py:269) — at the first link with a candidate SV, not at start-up
+    flt.run(args.gaf[0], args.gfa[0], args.prefix, args.outputDir, dover_given=args.dover != 100)
 
 
 if __name__ == "__main__":

@@ -13,7 +13,9 @@ HOST_LIB_PATH = os.path.join(os.path.dirname(HERE), "csrc", "libsvjg_host.so")
 
 HITREC_DT = np.dtype([("line_start", "<u8"), ("slot", "<u4"), ("n_ref", "<u2"), ("n_alt", "<u2")])
 
-EXC_CLASS = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError}
+EXC_CLASS = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError, 6: TypeError}
+LINE_ERRORS = (ValueError, IndexError, KeyError, ZeroDivisionError, TypeError)      # what a GAF line can make the reference die with
+DOVER_TYPE_ERROR = "'>=' not supported between instances of 'int' and 'list'"       # filter-alignments.py:269 under -O (svjg.h: SVJG_EXC_TYPE_ERROR)
 
 
 class SvjgError(RuntimeError):
@@ -317,7 +319,7 @@ class Context:
         if rc == -10:
             cls, off = ctypes.c_int(0), ctypes.c_uint64(0)
             self.lib.svjg_input_error(self.h, ctypes.byref(cls), ctypes.byref(off))
-            e = EXC_CLASS.get(cls.value, ValueError)(f"malformed GAF line at byte offset {off.value}")
+            e = TypeError(DOVER_TYPE_ERROR) if cls.value == 6 else EXC_CLASS.get(cls.value, ValueError)(f"malformed GAF line at byte offset {off.value}")
             e.svjg_offset = off.value                           # (svjg/filter.py: reference_error)
             raise e
         if rc == -12:

@@ -135,10 +135,13 @@ def host_line(text):
         head, _, tail = out.rpartition("id:f:")
         v, sep, rest = tail.partition("\t")
         if not v.isascii():
-            if head.count("\t") < 12 and head.count("\t") == 5:
-                # (the tag's value is a piece of the path column: rewriting it would rename a node)
-                raise NotImplementedError("an id:f: value with non-ASCII digits inside the path column")
-            out = head + "id:f:" + _ascii_number(v) + sep + rest
+            if head.count("\t") == 5:
+                # The tag's value is a piece of the PATH column: rewriting it would rename a node.  float() has accepted it (above), and
+                # the reference looks at the LAST "id:f:" of the line only (:194): one more tag with an ASCII value behind the line's
+                # columns leaves every column as it is and gives the kernels a value they read.
+                out += "\tid:f:1"
+            else:
+                out = head + "id:f:" + _ascii_number(v) + sep + rest
     return out.encode("utf-8") + b"\n"
 
 
@@ -181,7 +184,7 @@ def resolve_host_lines(ctxs, data, want_hits, error=None):
         before = len(ctx.host_lines())
         try:
             ctx.classify(np.frombuffer(b"".join(b for _, b in accepted), dtype=np.uint8), base_offset=HOST_BASE, want_hits=want_hits)
-        except (ValueError, IndexError, KeyError, ZeroDivisionError) as ex:
+        except capi.LINE_ERRORS as ex:
             o = getattr(ex, "svjg_offset", None)
             if o is not None and o >= HOST_BASE:
                 ex.svjg_offset = int(orig[np.searchsorted(starts, np.uint64(o - HOST_BASE), side="right") - 1])
@@ -260,11 +263,11 @@ def classify_file(ctx, graph, gaf_path, want_hits=True):
         for a, b in zip(cuts[:-1], cuts[1:]):
             if b > a:
                 ctx.classify(data[a:b], base_offset=a, want_hits=want_hits)
-    except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+    except capi.LINE_ERRORS as e:
         err = e
     try:
         remap = resolve_host_lines([ctx], data, want_hits, err)
-    except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+    except capi.LINE_ERRORS as e:
         raise reference_error(data, e)
     if ctx.stats()["non_ascii"]:
         check_utf8(data)
@@ -301,11 +304,11 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
         # the first failing shard (file order) holds the first bad line
         first_bad = [(ranges[d][0][0], errs[i]) for i, d in enumerate(distinct) if errs[i] is not None]
         err = min(first_bad, key=lambda x: x[0])[1] if first_bad else None
-        if err is not None and not isinstance(err, (ValueError, IndexError, KeyError, ZeroDivisionError)):
+        if err is not None and not isinstance(err, capi.LINE_ERRORS):
             raise err
         try:
             remap = resolve_host_lines(ctxs, data, want_hits, err)       # (lines with non-ASCII digits: Python's int() decides)
-        except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+        except capi.LINE_ERRORS as e:
             raise reference_error(data, e)
         capi.release_host_tables()                 # (every context has the graph: the shared host copy of the kernels' tables can go)
         _stamp(t, f"tables -> device, upload + classify on {len(distinct)} GPU(s)")
@@ -474,7 +477,7 @@ def classify_stream(graph, stream, want_hits=True, device=0, _t=None):
                     cut = buf.rfind(b"\n", done) + 1          # (a lone \r ends a line too, but never needs to end a chunk)
                     flush(cut)
             flush(len(buf))
-        except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+        except capi.LINE_ERRORS as e:
             # the reference would have met this line only after reading everything in front of it; read on so that a
             # non-UTF-8 byte before it still wins (reference_error), then report
             for b in iter(lambda: stream.read(STREAM_BLOCK), b""):
@@ -483,7 +486,7 @@ def classify_stream(graph, stream, want_hits=True, device=0, _t=None):
         data = np.frombuffer(bytes(buf), dtype=np.uint8) if err is not None else np.frombuffer(buf, dtype=np.uint8)
         try:
             remap = resolve_host_lines([ctx], data, want_hits, err)
-        except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+        except capi.LINE_ERRORS as e:
             raise reference_error(data, e)
         _stamp(t, "stream -> device, classified while it arrived")
         if ctx.stats()["non_ascii"]:
@@ -494,11 +497,15 @@ def classify_stream(graph, stream, want_hits=True, device=0, _t=None):
         ctx.close()
 
 
-def run(gaf_path, gfa_path, prefix, output_dir=None, device=None):
-    """filter-alignments.py main()."""
+def run(gaf_path, gfa_path, prefix, output_dir=None, device=None, dover_given=False):
+    """filter-alignments.py main().  dover_given: -O was on the command line — the reference then holds a list where it expects a
+    number and dies with TypeError at the first link that has a candidate SV (:153 -> :269); a GAF without one is written as usual."""
     out_json, edges_json = output_names(prefix, output_dir)
     t = [time.perf_counter()]
     graph = Graph.from_files(edges_json, gfa_path)
+    if dover_given:
+        from .graph import GRAPH_DOVER_LIST
+        graph.flags |= GRAPH_DOVER_LIST
     _stamp(t, "edges JSON + GFA -> graph")
     stream = sys.stdin.buffer if gaf_path == "-" else None
     if stream is None:

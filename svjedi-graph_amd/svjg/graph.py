@@ -19,6 +19,7 @@ LEN_UNKNOWN = 0xFFFFFFFF
 NODE_HAZARD = 0x80000000
 SENTINEL_KEY = 0xFFFFFFFFFFFFFFFF
 GRAPH_ALL_SLOW = 1
+GRAPH_DOVER_LIST = 16         # svjg.h: the reference was given -O (d_over is a list there: TypeError at the first candidate link)
 
 
 class GraphFormatError(ValueError):

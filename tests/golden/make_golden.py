@@ -54,9 +54,9 @@ ref_filter = _load("ref_filter", f"{REF}/filter-alignments.py")
 ref_geno = _load("ref_geno", f"{REF}/predict-genotype.py")
 
 
-def run_ref_filter(gaf, gfa, prefix):
+def run_ref_filter(gaf, gfa, prefix, extra=()):
     """-> (returncode, last stderr line)"""
-    p = subprocess.run([sys.executable, f"{REF}/filter-alignments.py", "-a", gaf, "-g", gfa, "-p", prefix],
+    p = subprocess.run([sys.executable, f"{REF}/filter-alignments.py", "-a", gaf, "-g", gfa, "-p", prefix, *extra],
                        capture_output=True, text=True)
     err = p.stderr.strip().splitlines()[-1] if p.stderr.strip() else ""
     return p.returncode, err
@@ -490,6 +490,10 @@ def make_unicode():
     cases["err_unicode_zero_alen"] = ["r3\t500\t0\t500\t+\t>1:1-1000>1:1001-1500\t1500\t0\t1500\t0\t" + arabic("0") + "\t60\t" + tags + "\n"]
     cases["err_unicode_before_ascii_error"] = [cols(alt, lambda x: x + "\u0663x", (7,)), plain.replace("\t60\t", "\t\t")]
     cases["err_id_tag_value"] = [alt.rstrip("\n") + "\tid:f:" + arabic("0.5") + "\u00e9\n"]
+    # (r04) an id:f: "tag" INSIDE the path column whose value is written with non-ASCII digits: float() takes it, Alen == 0 raises nothing,
+    # the piece of path is a node name the graph does not have; and the same node inside an overlap sum (get_node_len dies on it)
+    cases["id_tag_in_path_column"] = [plain, "r3\t500\t0\t500\t+\t>1:1-1000>1:1001-1500id:f:" + arabic("5") + "\t1500\t0\t1500\t0\t0\t60\t" + tags + "\n", alt]
+    cases["err_id_tag_in_path_column_node_in_sum"] = [plain, "r3\t500\t0\t500\t+\t>1:1-1000>1:1001-1500>1:1501-3000id:f:" + wide("7.5") + "\t3000\t0\t3000\t500\t500\t60\t" + tags + "\n"]
     manifest = {}
     tdir = tempfile.mkdtemp()
     shutil.copy(f"{q}/q_svs_edges.json", f"{tdir}/q_svs_edges.json")
@@ -510,6 +514,60 @@ def make_unicode():
     with open(f"{out}/manifest.json", "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
     print("unicode:", {k: (v["rc"], v.get("error", "")) for k, v in manifest.items()})
+
+
+def make_dover():
+    """golden/dover (r04): the quirks graph through the reference WITH -O 50.  argparse leaves a list in d_over, so the reference
+    dies with TypeError where it first compares an overlap with it — the first link that has a candidate SV, once the node lengths
+    of its left sum are there — and not before: lines in front of it are classified (and may die) as usual, a GAF without such a link
+    is written as `{}`."""
+    q = f"{HERE}/quirks"
+    out = f"{HERE}/dover"
+    os.makedirs(out, exist_ok=True)
+    L = {}
+    for line in open(f"{q}/q.gfa"):
+        c = line.rstrip("\n").split("\t")
+        if c[0] == "S":
+            L[c[1]] = len(c[2]) if "." in c[1].split(":")[-1] else int(c[1].split(":")[-1].split("-")[1]) - int(c[1].split(":")[-1].split("-")[0]) + 1
+    tags = "tp:A:P\tcm:i:9\ts1:i:90\ts2:i:0\tdv:f:0.0200"
+
+    def g(name, nodes_, ori, **kw):
+        return gaf_line(name, nodes_, list(ori), L, extra=kw.pop("extra", tags), **kw)
+    plain = g("r0", ["1:1-1000", "1:1001-1500", "1:1501-3000"], ">>>")
+    alt = g("r1", ["1:1-1000", "1:1501-3000"], ">>")
+    single = g("s0", ["1:1-1000"], ">")
+    nolink = g("n0", ["chrA:901-2000", "1:1-1000"], ">>")                       # two nodes, no such link in the table
+    unknown = g("u0", ["1:1-1000", "1:1001-1500"], ">>").replace("1:1001-1500", "1:1001-1400")   # a name the graph does not have
+    nonint = plain.replace("\t60\t", "\tx\t")
+    cases = {}
+    cases["dover_flag_hit"] = [plain, alt]
+    cases["dover_flag_nohit"] = [single, nolink, unknown, single]
+    cases["dover_flag_empty"] = []
+    cases["dover_flag_error_in_front_of_the_hit"] = [nolink, nonint, plain]
+    cases["dover_flag_hit_in_front_of_the_error"] = [nolink, alt, nonint]
+    cases["dover_flag_keyerror_in_the_left_sum"] = [g("r0", ["1:1-1000", "1:1001-1500"], ">>").replace(">1:1-1000", ">1:7.1>1:1-1000").replace("\t1500\t0\t1500\t", "\t1600\t0\t1600\t")]
+    cases["dover_flag_right_sum_not_reached"] = ["r0\t500\t0\t500\t+\t>1:1-1000>1:1001-1500>1:abc\t1500\t0\t1500\t500\t500\t60\t" + tags + "\n"]
+    cases["dover_flag_hit_behind_many_lines"] = [single, nolink, unknown] * 40 + [g("r9", ["1:1501-3000", "1:1-1000"], "<<")] + [plain] * 3
+    manifest = {}
+    tdir = tempfile.mkdtemp()
+    shutil.copy(f"{q}/q_svs_edges.json", f"{tdir}/q_svs_edges.json")
+    for name, lines in cases.items():
+        gaf = f"{out}/{name}.gaf"
+        with open(gaf, "w", encoding="utf-8") as fh:
+            fh.write("".join(lines))
+        js = f"{tdir}/q_informative_aln.json"
+        if os.path.exists(js):
+            os.remove(js)
+        rc, err = run_ref_filter(gaf, f"{q}/q.gfa", f"{tdir}/q", extra=("-O", "50"))
+        if rc == 0:
+            shutil.copy(js, f"{out}/{name}.ref.json")
+            manifest[name] = {"rc": 0, "n_lines": len(lines)}
+        else:
+            assert rc == 1
+            manifest[name] = {"rc": 1, "error": err.split(":")[0], "message": err, "n_lines": len(lines)}
+    with open(f"{out}/manifest.json", "w") as fh:
+        json.dump(manifest, fh, indent=1, sort_keys=True)
+    print("dover:", {k: (v["rc"], v.get("error", "")) for k, v in manifest.items()})
 
 
 def make_nosv():
@@ -1110,7 +1168,7 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz"]
+    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz", "dover"]
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))

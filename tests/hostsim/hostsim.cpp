@@ -7,6 +7,7 @@
 #include "../../svjedi-graph_amd/csrc/svjg_line.h"
 #include "../../svjedi-graph_amd/csrc/svjg_host_tables.h"
 #include "../../svjedi-graph_amd/csrc/svjg_planes.h"
+#include "../../svjedi-graph_amd/csrc/svjg_pass.h"
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,7 @@ static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &has
     v.nodes = g->nodes; v.n_nodes = (uint32_t)g->n_nodes; v.edges = g->edges; v.hits = g->hits;
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
+    v.dover_list = (g->flags & SVJG_GRAPH_DOVER_LIST) ? 1u : 0u;
     v.node_of_kid = nullptr; v.name_tab = nullptr; v.name_ihits = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
     if (kt) {                                                             // the exact path resolves names through the node-name table
         v.node_of_kid = kt->node_of_kid.data(); v.name_tab = kt->names.data(); v.name_ihits = kt->ihits.data(); v.name_disp = kt->disp.data(); v.name_slots = kt->name_slots; v.name_buckets = kt->name_buckets;
@@ -181,3 +183,9 @@ extern "C" void hostsim_span_classes(const uint8_t *text, uint64_t n_spans, uint
         o[6] = lo.colon | ((uint64_t)hi.colon << 32); o[7] = lo.high | ((uint64_t)hi.high << 32);
     }
 }
+
+// the fused pass's decisions (svjg_pass.h), as libsvjg_hip.so takes them
+extern "C" uint64_t hostsim_pass_repeat_word(uint32_t overflow_bits) { return pass_repeat_word(overflow_bits); }
+extern "C" int hostsim_pass_repeats(int has_comm, uint32_t own_overflow_bits, uint64_t guard_repeat_sum) { return pass_repeats(has_comm != 0, own_overflow_bits, guard_repeat_sum) ? 1 : 0; }
+extern "C" int hostsim_pass_counts_overflowed(uint64_t a, uint64_t b) { return pass_counts_overflowed(a, b) ? 1 : 0; }
+extern "C" uint32_t hostsim_guard_words(void) { return GUARD_WORDS; }

@@ -11,7 +11,7 @@ class HostLine(Exception):
     """the exact routine's "the host decides" (svjg.h: SVJG_EXC_ASK_HOST): a decimal column with non-ASCII bytes"""
 
 
-EXC = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError, 5: HostLine}
+EXC = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError, 5: HostLine, 6: TypeError}
 
 
 def build():
@@ -19,6 +19,7 @@ def build():
            os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_line.h"),
            os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_host_tables.h"),
            os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_planes.h"),
+           os.path.join(HERE, "..", "..", "svjedi-graph_amd", "csrc", "svjg_pass.h"),
            os.path.join(HERE, "..", "..", "include", "svjg.h")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in src):
         subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-shared", "-fPIC", "-o", SO, src[0]], check=True)
@@ -82,3 +83,18 @@ def span_classes(text):
     lib.hostsim_span_classes.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
     lib.hostsim_span_classes(buf.ctypes.data, buf.size // 64, out.ctypes.data)
     return out
+
+
+def pass_logic():
+    """the fused pass's host decisions (svjedi-graph_amd/csrc/svjg_pass.h) -> (repeat_word(overflow), repeats(has_comm, overflow, guard_sum),
+    counts_overflowed(max_ref_sum, max_alt_sum), number of guard words)"""
+    lib = ctypes.CDLL(build())
+    lib.hostsim_pass_repeat_word.restype = ctypes.c_uint64
+    lib.hostsim_pass_repeat_word.argtypes = [ctypes.c_uint32]
+    lib.hostsim_pass_repeats.restype = ctypes.c_int
+    lib.hostsim_pass_repeats.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64]
+    lib.hostsim_pass_counts_overflowed.restype = ctypes.c_int
+    lib.hostsim_pass_counts_overflowed.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+    lib.hostsim_guard_words.restype = ctypes.c_uint32
+    return (lambda o: int(lib.hostsim_pass_repeat_word(o)), lambda c, o, s: bool(lib.hostsim_pass_repeats(int(c), o, s)),
+            lambda a, b: bool(lib.hostsim_pass_counts_overflowed(a, b)), int(lib.hostsim_guard_words()))

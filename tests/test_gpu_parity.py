@@ -129,6 +129,34 @@ def test_unicode_digit_lines(ctx, golden, name, all_slow, tmp_path):
         assert type(ei.value).__name__ == man["error"]
 
 
+DOVER = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "dover")) if f.endswith(".gaf"))
+
+
+@pytest.mark.parametrize("name", DOVER)
+def test_dover_flag_through_the_drop_in_script(golden, name, tmp_path):
+    """golden/dover: filter-alignments.py -O 50, the drop-in against what the reference did with the same command line: exit code 1
+    and the reference's exception (TypeError at the first link with a candidate SV; an earlier malformed line or a KeyError of the
+    left sum first), or exit code 0 and the `{}` the reference wrote when no link has a candidate."""
+    import shutil
+    import subprocess
+    import sys
+    q, d = f"{golden}/quirks", f"{golden}/dover"
+    man = json.load(open(f"{d}/manifest.json"))[name]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copy(f"{q}/q_svs_edges.json", tmp_path / "q_svs_edges.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "svjedi-graph_amd", "filter-alignments.py"), "-a", f"{d}/{name}.gaf", "-g", f"{q}/q.gfa",
+                        "-p", str(tmp_path / "q"), "-O", "50"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == man["rc"], r.stderr[-800:]
+    if man["rc"] == 0:
+        assert open(tmp_path / "q_informative_aln.json").read() == open(f"{d}/{name}.ref.json").read() == "{}"
+    else:
+        last = r.stderr.strip().splitlines()[-1]
+        assert last.split(":")[0] == man["error"], r.stderr[-800:]
+        if man["error"] == "TypeError":
+            assert last == man["message"]
+        assert not os.path.exists(tmp_path / "q_informative_aln.json")
+
+
 def test_unicode_digit_lines_sharded_and_streamed(golden, tmp_path, monkeypatch):
     """the same through the two other ways into the filter: byte ranges on two contexts of one GPU, and a pipe"""
     import io
@@ -1242,6 +1270,41 @@ def test_run_resident_is_the_three_calls(tmp_path):
         c.upload(bad)
         with pytest.raises(ValueError):
             c.run_resident(3, 0.00005)
+    finally:
+        c.close()
+
+
+def test_fused_pass_with_many_deferred_lines_under_a_communicator(tmp_path):
+    """The fused pass (svjg_run_begin / svjg_run_end) behind a one-rank RCCL communicator when a shard defers more lines than one
+    wave per line is good for (16 384): the lane-per-line kernel is enqueued in the pass itself and reads the number on the device,
+    so the pass's own all-reduce already sums complete counts — no repeat, ONE collective per pass —; and when the list of
+    deferred lines overflows, the guard word that travels through the all-reduce makes the rank(s) repeat the pass with one more
+    collective (svjg_pass.h).  Both equal the step-by-step calls; with two passes in flight too."""
+    from svjg import capi, genotype, shard
+    pre, gaf, g, orc = _synth_case(tmp_path, 40000, 1500, 3, "mixed", 35)
+    rows = genotype.VcfRows(pre + ".vcf", g.slot_of)
+    tagged = bytes(gaf).replace(b"\tdv:f:", b"\tid:f:5e-1\tdv:f:")          # every line: an exponent the main kernel leaves to the exact path
+    mid = np.frombuffer(tagged, dtype=np.uint8)                               # 40 k deferred lines: above the wave limit, inside the list
+    many = np.frombuffer(tagged * 4, dtype=np.uint8)                          # 160 k: the list (n / 4096 + 65 536 entries) overflows
+    c = capi.Context(0)
+    try:
+        c.load_graph(g)
+        c.set_rows(rows.sv_type, rows.slot, rows.ok)
+        shard.RcclGroup(c, 1, 0, lambda uid: uid)
+        for text, n_def in ((mid, 40000), (many, 160000), (gaf, None)):
+            want = _step_by_step(c, text, rows)
+            assert n_def is None or want[1]["n_deferred"] == n_def
+            for _ in range(2):
+                gt, pl, raw, flags = (np.array(x) for x in c.run_resident(3, 0.00005))
+                assert np.array_equal(c.counts(), want[0]) and want[0].sum() > 0
+                st = c.stats()
+                assert st["n_lines"] == want[1]["n_lines"] and st["n_deferred"] == want[1]["n_deferred"]
+                assert np.array_equal(gt, want[2]) and np.array_equal(pl, want[3]) and np.array_equal(raw, want[4]) and np.array_equal(flags & 1, want[5])
+            c.run_begin(3, 0.00005); c.run_begin(3, 0.00005)                   # two in flight: both repeat (or neither), in order
+            for _ in range(2):
+                got = [np.array(x) for x in c.run_end()]
+                assert np.array_equal(got[0], want[2]) and np.array_equal(got[1], want[3]) and np.array_equal(got[2], want[4])
+            assert np.array_equal(c.counts(), want[0])
     finally:
         c.close()
 

@@ -37,6 +37,29 @@ def test_quirks(golden, name, tables, wave):
         assert type(ei.value).__name__ == man["error"]
 
 
+DOVER = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "dover")) if f.endswith(".gaf"))
+
+
+@pytest.mark.parametrize("wave", [0, 1, 2], ids=["one_lane", "wave_lanes", "wave_two_phase"])
+@pytest.mark.parametrize("name", DOVER)
+def test_dover_flag(golden, name, wave):
+    """golden/dover (the reference run with -O): the exact routine under SVJG_GRAPH_DOVER_LIST raises TypeError where the reference
+    does — after the left sum's node lengths, before the right sum — in all three of its forms"""
+    from svjg.graph import GRAPH_DOVER_LIST
+    q, d = f"{golden}/quirks", f"{golden}/dover"
+    man = json.load(open(f"{d}/manifest.json"))[name]
+    g = Graph.from_files(f"{q}/q_svs_edges.json", f"{q}/q.gfa")
+    g.flags |= GRAPH_DOVER_LIST
+    raw = open(f"{d}/{name}.gaf", "rb").read()
+    if man["rc"] == 0:
+        counts, n_lines = sim.classify(g, raw, True, wave)
+        assert counts.sum() == 0 and n_lines == man["n_lines"]
+    else:
+        with pytest.raises(Exception) as ei:
+            sim.classify(g, raw, True, wave)
+        assert type(ei.value).__name__ == man["error"]
+
+
 @pytest.mark.parametrize("tables,wave", [(True, 0), (True, 2)], ids=["name_table", "wave_two_phase"])
 def test_realshape_lines(golden, tables, wave):
     """the exact per-line routine on the lines shaped like real minigraph output (paths of up to 300 nodes, kilobyte tags)"""

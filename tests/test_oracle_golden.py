@@ -52,17 +52,40 @@ def test_py_filter_unicode_digits(golden, name):
     if man["rc"] == 0:
         D = O.classify(lines, edges, alt)
         assert O.dump_informative(D) == open(f"{u}/{name}.ref.json").read()
-        ascii_lines = [flt.host_line(x).decode("ascii") for x in lines]
+        ascii_lines = [flt.host_line(x).decode("utf-8") for x in lines]   # (ASCII but for a tag value inside the path column, which stays as it is)
         D2 = O.classify(ascii_lines, edges, alt)
         assert {k: [len(v[0]), len(v[1])] for k, v in D2.items()} == {k: [len(v[0]), len(v[1])] for k, v in D.items()}
     else:
         with pytest.raises(Exception) as ei:
             O.classify(lines, edges, alt)
         assert type(ei.value).__name__ == man["error"]
-        with pytest.raises(Exception) as ei:
-            for x in lines:
-                flt.host_line(x)
+        with pytest.raises(Exception) as ei:                                # (from the host's own int() / float(), or from what the rewritten lines classify to)
+            O.classify([flt.host_line(x).decode("utf-8") for x in lines], edges, alt)
         assert type(ei.value).__name__ == man["error"]
+
+
+DOVER = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "dover")) if f.endswith(".gaf"))
+
+
+@pytest.mark.parametrize("name", DOVER)
+def test_py_filter_with_the_dover_flag(golden, name):
+    """golden/dover: the reference run WITH -O 50 (d_over is then the list ["50"], filter-alignments.py:52-57, :88): TypeError at the
+    first link with a candidate SV whose left sum can be formed (:153 -> :269), whatever comes first in the file otherwise, `{}` when
+    there is no such link."""
+    q, d = f"{golden}/quirks", f"{golden}/dover"
+    man = json.load(open(f"{d}/manifest.json"))[name]
+    edges = O.load_edges(f"{q}/q_svs_edges.json")
+    alt = O.load_alt_node_len(f"{q}/q.gfa")
+    lines = _read_lines(f"{d}/{name}.gaf")
+    if man["rc"] == 0:
+        assert O.dump_informative(O.classify(lines, edges, alt, d_over=["50"])) == open(f"{d}/{name}.ref.json").read() == "{}"
+    else:
+        with pytest.raises(Exception) as ei:
+            O.classify(lines, edges, alt, d_over=["50"])
+        assert type(ei.value).__name__ == man["error"]
+        if man["error"] == "TypeError":
+            from svjg import capi
+            assert man["message"] == "TypeError: " + capi.DOVER_TYPE_ERROR and str(ei.value) == capi.DOVER_TYPE_ERROR
 
 
 def test_py_testdir_end_to_end(golden):
