@@ -28,7 +28,10 @@ for p in (ROOT, os.path.join(ROOT, "svjedi-graph_amd"), os.path.join(ROOT, "tool
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what a copy achieves is measured in the run (roofline.measured_copy_gbs)
+MIN_SUSTAINED_S = 0.25       # the `sustained` block repeats the timed passes until they span this long (a sampler outside the process can then see them)
+# the north_star workload (BASELINE.json configs[3]): split over the GPUs of the run, untimed for `value`
+NORTH_STAR = {"aln": 100_000_000, "svs": 500_000, "chroms": 24, "mix": "mixed", "seed": 20260515 + 3, "piece": 12_500_000}
 
 WORKLOADS = {
     # name: (alignments per rank, n_sv, n_chrom, mix, seed, description)
@@ -114,9 +117,11 @@ def timed_steps(ctxs, steps, warmup, min_support=3, err=0.00005, outer_barrier=N
     except threading.BrokenBarrierError:
         dt = None
     for x in th:
-        x.join()
+        x.join(60)                                               # (a peer of a failed worker may sit in an all-reduce that never completes)
     if errors:
         raise errors[0]
+    if dt is None or any(x.is_alive() for x in th):
+        raise RuntimeError("a worker thread did not finish its passes")
     return dt, ms, outs[0]
 
 
@@ -131,6 +136,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed end-to-end block (files -> JSON -> VCF through the drop-in scripts)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the untimed north_star block (BASELINE configs[3] split over the GPUs of the run)")
+    ap.add_argument("--no-long-read", action="store_true", help="skip the untimed long_read block (long-read shaped lines: paths long-tailed to 200 nodes, cg:Z: strings)")
+    ap.add_argument("--north-star-aln", type=int, default=NORTH_STAR["aln"], help="alignments of the north_star block (tests)")
+    ap.add_argument("--north-star-svs", type=int, default=NORTH_STAR["svs"], help="SVs of the north_star block (tests)")
     args = ap.parse_args()
 
     # Two ways to N GPUs: under a launcher (torch.distributed.run: WORLD_SIZE ranks, one GPU each, RCCL communicator from a
@@ -193,6 +201,7 @@ def main():
         t_h2d = max(t_h2d, time.time() - t1)
         del text
     rccl = None
+    rccl_log = rccl_debug_capture(tmp) if n_total_ranks > 1 else None     # (NCCL_DEBUG must be in the environment before the communicator exists)
     if world > 1:
         import dist_boot
         getattr(capi, "RcclGroup", shard.RcclGroup)(ctxs[0], world, rank, dist_boot.torch_exchange)
@@ -201,12 +210,34 @@ def main():
         capi.comm_init_all(ctxs)
         rccl = {"ranks": n_local, "init": "ncclCommInitAll, one process, one thread per GPU"}
 
-    dt, kms, out = timed_steps(ctxs, args.steps, args.warmup, outer_barrier=(dist.barrier if dist is not None else None))
-    if dist is not None:
+    outer = dist.barrier if dist is not None else None
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
+        tt = torch.tensor([v], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+        return float(tt[0])
+
+    dt, kms, out = timed_steps(ctxs, args.steps, args.warmup, outer_barrier=outer)
+    dt = max_over_ranks(dt)
+    out = tuple(np.array(x) for x in out)                     # (views of the library's pinned result block: copied before anything else runs)
+    # the same passes again, as many as span MIN_SUSTAINED_S (every rank computes the same number from the timed figure all of them hold)
+    n_sus = max(args.steps, int(MIN_SUSTAINED_S / max(dt / args.steps, 1e-6)) + 1)
+    dt_sus, kms_sus, _ = timed_steps(ctxs, n_sus, 0, outer_barrier=outer)
+    dt_sus = max_over_ranks(dt_sus)
+    # N > 1: the all-reduce of a pass on the compute stream (above, `value`) and on the second stream, both measured
+    second = None
+    if n_total_ranks > 1 and hasattr(ctxs[0], "allreduce_on_second_stream"):
+        for c in ctxs:
+            c.allreduce_on_second_stream(True)
+        dt2, kms2, _ = timed_steps(ctxs, max(args.steps, n_sus // 4), args.warmup, outer_barrier=outer)
+        dt2 = max_over_ranks(dt2)
+        for c in ctxs:
+            c.allreduce_on_second_stream(False)
+        second = {"steps": max(args.steps, n_sus // 4), "ms_per_step": dt2 / max(args.steps, n_sus // 4) * 1e3,
+                  "classify_main_ms": float(np.mean([m[0] for per in kms2 for m in per]))}
     main_ms = [m[0] for per in kms for m in per]
     slow_ms = [m[1] for per in kms for m in per]
     geno_ms = [m[2] for per in kms for m in per]
@@ -214,7 +245,19 @@ def main():
     ctx = ctxs[0]
     st = ctx.stats()
     counts = ctx.counts()
-    gt, pl, raw, done = (np.array(x) for x in out)            # (views of the library's pinned result block: copied before anything else runs)
+    gt, pl, raw, done = out
+    copy_gbs = None
+    if rank == 0 and hasattr(ctx, "copy_rate"):
+        try:
+            copy_gbs = ctx.copy_rate(1 << 31)                    # 2 GB read + 2 GB written, in this process, on this GPU
+        except Exception as e:                                   # noqa: BLE001 (a measurement beside the point of the run)
+            sys.stderr.write(f"[bench] copy rate not measured: {e}\n")
+    ns = None
+    if not args.no_north_star:
+        ns = north_star_block(capi, synth, genotype, Graph, ctxs, rank, world, n_local, dist, args, tmp)
+    lr = None
+    if not args.no_long_read and n_total_ranks == 1 and not os.environ.get("SVJG_BENCH_CAPI"):
+        lr = long_read_block(capi, synth, Graph, ctx, tmp, check=not args.no_cpu_baseline)
 
     if rank == 0:
         total_aln = n_aln * n_total_ranks
@@ -244,8 +287,21 @@ def main():
                          "kernel": "k_classify_main", "algorithmic_bytes_per_launch": gaf_bytes_0},
             "setup_s": {"generate_and_tables": round(t_setup, 1), "h2d_upload": round(t_h2d, 3),
                         "pcie_inclusive_alignments_per_s": n_aln / (t_h2d + ms_per_step * 1e-3)},
+            # the timed passes again, repeated until they span >= MIN_SUSTAINED_S: per-step mean over all of them
+            "sustained": {"steps": n_sus, "seconds": dt_sus, "ms_per_step": dt_sus / n_sus * 1e3, "alignments_per_s": total_aln * n_sus / dt_sus,
+                          "classify_main_ms": float(np.mean([m[0] for per in kms_sus for m in per]))},
         }
+        if copy_gbs:
+            res["roofline"]["measured_copy_gbs"] = copy_gbs      # bytes read + written per second by a plain copy kernel in this process
+            res["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+        if ns is not None:
+            res["north_star"] = ns
+        if lr is not None:
+            res["long_read"] = lr
         if rccl:
+            rccl["allreduce_stream"] = {"compute": {"ms_per_step": ms_per_step, "classify_main_ms": k_main}, "second": second,
+                                        "value_is": "compute (the all-reduce between this pass's kernels and the next pass's)"}
+            rccl.update(rccl_debug_summary(rccl_log))
             res["rccl"] = rccl
         # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (profiles/<round>/traffic.json,
         # the newest round that has one)
@@ -280,6 +336,144 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rccl_debug_capture(tmp):
+    """RCCL's own account of what it set up (record algorithm / protocol / channels): NCCL_DEBUG=INFO into a file of this
+    process, parsed once after the passes.  Leaves a caller's own NCCL_DEBUG settings alone."""
+    if os.environ.get("NCCL_DEBUG"):
+        return os.environ.get("NCCL_DEBUG_FILE")
+    path = os.path.join(tmp, "rccl.%h.%p.log")
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING,GRAPH")
+    os.environ["NCCL_DEBUG_FILE"] = path
+    return path
+
+
+def rccl_debug_summary(path):
+    """-> what the log says about rings / trees, channels, transports and the all-reduce's algorithm and protocol (best effort: the wording
+    differs between RCCL versions; the matching lines themselves are kept, a few of each kind)"""
+    import glob
+    import re
+    out = {}
+    try:
+        files = glob.glob(re.sub(r"%[hp]", "*", path)) if path else []
+        lines = []
+        for f in files[:1]:
+            lines = open(f, errors="replace").read().splitlines()
+        if not lines:
+            return {"debug_info": {"note": "no RCCL log (NCCL_DEBUG_FILE not written)"}}
+        def grab(pat, n=3):
+            return [re.sub(r"^.*?NCCL INFO ", "", l)[:200] for l in lines if re.search(pat, l)][:n]
+        ch = [int(m.group(1)) for l in lines for m in [re.search(r"(\d+) coll channels", l)] if m]
+        out["coll_channels"] = ch[0] if ch else None
+        out["channels"] = grab(r"Channel \d+/\d+ *:", 2)
+        out["rings_trees"] = grab(r"\bRing \d+ *:|\bTrees? \[|Connected all (rings|trees)", 4)
+        out["transport"] = sorted({m.group(1) for l in lines for m in [re.search(r"via (P2P/[A-Za-z/]+|SHM[/A-Za-z]*|NET/[A-Za-z0-9]+)", l)] if m})
+        algo = [m.groups() for l in lines for m in [re.search(r"[Aa]lgo(?:rithm)? *[:=]? *(\w+).*?[Pp]roto(?:col)? *[:=]? *(\w+)", l)] if m]
+        out["algo_proto"] = sorted({f"{a}/{p}" for a, p in algo})[:6] or None
+        out["allreduce_lines"] = grab(r"AllReduce", 3)
+        out["log_lines"] = len(lines)
+    except (OSError, ValueError) as e:
+        out["debug"] = str(e)
+    return {"debug_info": out}
+
+
+def long_read_block(capi, synth, Graph, ctx, tmp, check=True):
+    """Untimed for `value`: what the headline workload says nothing about — long-read shaped text (tools/svjg_synth.c: svjg_synth_gaf_long;
+    the hand-made originals are tests/golden/realshape): sequencer read names, UCSC contig names of up to 23 bytes, paths long-tailed to 200
+    nodes (3 % beyond one node pass of 64), cg:Z: strings on a third of the lines; 1 M lines x 20 k mixed SVs on 8 contigs.  Classification
+    only (main kernel + exact path), kernel time by HIP events: lines per second, how many lines took the exact path and why."""
+    n_lines, n_sv, seed = 1_000_000, 20_000, 20260515 + 9
+    pre = os.path.join(tmp, "long_read")
+    inf = synth.generate(pre, 0, n_sv, 8, "mixed", seed, write_gaf=False, chrom_style="ucsc")
+    gaf = synth.gaf_bytes(inf["tables"], seed, 0, n_lines, threads=min(16, os.cpu_count() or 8), shape="long")
+    graph = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    ctx.load_graph(graph)
+    ctx.upload(gaf)
+    ms = []
+    for i in range(7):
+        ctx.reset_counts()
+        ctx.classify_resident()
+        if i >= 2:
+            ms.append(ctx.kernel_ms()[:2])
+    main_ms, slow_ms = float(np.mean([m[0] for m in ms])), float(np.mean([m[1] for m in ms]))
+    st, cause = ctx.stats(), ctx.defer_causes()
+    marks = int(((gaf == ord("<")) | (gaf == ord(">"))).sum())
+    out = {"workload": f"{n_lines} long-read shaped GAF lines x {n_sv} mixed SVs on 8 UCSC-named contigs; classification only, untimed for `value`",
+           "lines": n_lines, "gaf_bytes": int(gaf.size), "bytes_per_line": round(gaf.size / n_lines, 1), "path_nodes_per_line": round(marks / n_lines, 2),
+           "kernel_ms": {"classify_main": main_ms, "classify_exact_path": slow_ms},
+           "lines_per_s": n_lines / ((main_ms + slow_ms) * 1e-3), "gb_per_s": gaf.size / ((main_ms + slow_ms) * 1e-3) / 1e9,
+           "deferred_lines": int(st["n_deferred"]), "deferred_fraction": st["n_deferred"] / n_lines, "deferred_by_cause": {k: int(v) for k, v in cause.items() if v}}
+    if check:                                                    # the C oracle on the first 100 k lines (the checker, not the thing measured)
+        from oracle import oracle_c, oracle_py
+        nl = np.flatnonzero(gaf[: 400_000_000] == 10)
+        sample = gaf[: int(nl[min(100_000, nl.size) - 1]) + 1]
+        orc = oracle_c.COracle(oracle_py.load_edges(pre + "_svs_edges.json"), oracle_py.load_alt_node_len(pre + ".gfa"))
+        want, _, _ = orc.filter(sample, want_hits=False)
+        ctx.reset_counts()
+        ctx.classify(sample)
+        g = ctx.counts()
+        exp = {sv: (int(want[i, 0]), int(want[i, 1])) for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
+        got = {graph.sv_ids[i]: (int(g[i, 0]), int(g[i, 1])) for i in range(graph.n_slots) if g[i].sum()}
+        out["parity_on_sample"] = "bit-exact" if exp == got else "MISMATCH"
+    return out
+
+
+def north_star_block(capi, synth, genotype, Graph, ctxs, rank, world, n_local, dist, args, tmp):
+    """Untimed for `value`: BASELINE.json configs[3] — the north_star workload, 100 M alignments x 500 k SVs — split over the GPUs of
+    this run (one GPU: all of it resident, 21.6 GB of text), every rank's share generated and uploaded in pieces; then whole passes
+    (zero, classify, all-reduce, genotype all 500 k rows) as in the timed loop: alignments per second over all ranks, kernel times, the
+    digest of the summed count vector (equal on every rank behind the all-reduce).  Reuses the run's contexts."""
+    import hashlib
+    t0 = time.time()
+    total, n_sv = int(args.north_star_aln), int(args.north_star_svs)
+    n_ranks = world * n_local
+    per = total // n_ranks
+    pre = os.path.join(tmp, "north_star")
+    inf = synth.generate(pre, 0, n_sv, min(NORTH_STAR["chroms"], max(1, n_sv // 50)), NORTH_STAR["mix"], NORTH_STAR["seed"], write_gaf=False)
+    graph = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    rows = genotype.VcfRows(pre + ".vcf", graph.slot_of)
+    thr = min(16, os.cpu_count() or 8)
+    nbytes = []
+    for i, c in enumerate(ctxs):
+        g = rank * n_local + i
+        lo, hi = g * per, (total if g == n_ranks - 1 else (g + 1) * per)
+        c.load_graph(graph)
+        c.set_rows(rows.sv_type, rows.slot, rows.ok)
+        pieces = (synth.gaf_bytes(inf["tables"], NORTH_STAR["seed"], a, min(NORTH_STAR["piece"], hi - a), threads=thr)
+                  for a in range(lo, hi, NORTH_STAR["piece"]))
+        if hasattr(c, "upload_parts"):
+            nbytes.append(c.upload_parts(pieces, (hi - lo) * 320 + (1 << 20)))
+        else:                                                    # (a stand-in for the library: tests)
+            whole = np.concatenate(list(pieces))
+            c.upload(whole)
+            nbytes.append(int(whole.size))
+    t_setup = time.time() - t0
+    outer = dist.barrier if dist is not None else None
+    steps = 3
+    dt, kms, out = timed_steps(ctxs, steps, 1, outer_barrier=outer)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    digests = [hashlib.sha256(np.ascontiguousarray(c.counts()).tobytes()).hexdigest()[:16] for c in ctxs]
+    stats = [c.stats() for c in ctxs]
+    if dist is not None:
+        box = [None] * world
+        dist.all_gather_object(box, digests)
+        digests = [d for b in box for d in b]
+    main_ms = float(np.mean([m[0] for per_ctx in kms for m in per_ctx]))
+    flags = np.array(out[3])
+    return {"workload": f"configs[3]: {total} GAF alignments x {n_sv} mixed SVs over {n_ranks} GPU(s), text resident in HBM; untimed for `value`",
+            "alignments": total, "n_gpus": n_ranks, "alignments_per_gpu": per, "gaf_bytes_per_gpu": nbytes[0], "count_slots": graph.n_slots,
+            "passes": steps, "ms_per_pass": dt / steps * 1e3, "alignments_per_s": total * steps / dt,
+            "kernel_ms": {"classify_main": main_ms, "classify_exact_path": float(np.mean([m[1] for per_ctx in kms for m in per_ctx])),
+                          "genotype": float(np.mean([m[2] for per_ctx in kms for m in per_ctx]))},
+            "roofline_frac": nbytes[0] / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if main_ms > 0 else None,
+            "deferred_lines_per_pass": int(stats[0]["n_deferred"]), "genotyped_rows": int((flags & 1).sum()),
+            "counts_digest": digests[0], "digest_equal_across_ranks": len(set(digests)) == 1, "setup_s": round(t_setup, 1)}
 
 
 def end_to_end(workload, pre, gaf):

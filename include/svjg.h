@@ -148,6 +148,11 @@ void svjg_release_host_tables(void);
  * that go to HBM while the next pieces are read; svjg_classify_file uses `offset` as base_offset. */
 int svjg_gaf_upload(svjg_ctx *ctx, const char *gaf, uint64_t n_bytes);
 int svjg_gaf_upload_file(svjg_ctx *ctx, const char *path, uint64_t offset, uint64_t n_bytes);
+/* The resident text in pieces (a text larger than the caller wants to hold on the host: the 21.6 GB of BASELINE configs[3] on one
+ * GPU): piece [offset, offset + n_bytes) of a text of at most capacity_bytes; the call with offset 0 sizes the buffer, the one
+ * with last != 0 ends the text at offset + n_bytes and makes it resident.  Pieces go in ascending order and may be cut anywhere
+ * (the text as a whole ends at a line end or without a terminator, like a file: filter-alignments.py:123-126). */
+int svjg_gaf_upload_part(svjg_ctx *ctx, const char *gaf, uint64_t n_bytes, uint64_t offset, uint64_t capacity_bytes, int last);
 int svjg_classify_resident(svjg_ctx *ctx, uint64_t base_offset, int want_hits);
 int svjg_classify(svjg_ctx *ctx, const char *gaf, uint64_t n_bytes, uint64_t base_offset, int want_hits);
 int svjg_classify_file(svjg_ctx *ctx, const char *path, uint64_t offset, uint64_t n_bytes, int want_hits);
@@ -183,6 +188,9 @@ int svjg_allreduce_counts(svjg_ctx *ctx);
  * communicators from ncclCommInitAll, the same all-reduce issued for every context; n == 1 is allowed (no collective).
  * Both all-reduce forms fail with SVJG_E_OVERFLOW when a per-SV count cannot be represented (>= 2^32). */
 int svjg_comm_init_all(svjg_ctx *const *ctxs, int n);
+/* Where the fused pass (svjg_run_begin) enqueues its all-reduce: 0 (default) on the compute stream, between this pass's kernels and
+ * the next pass's; 1 on the second stream, in front of the pass's genotype kernel (bench.py measures both on a multi-GPU box). */
+int svjg_comm_set_stream(svjg_ctx *ctx, int second_stream);
 int svjg_allreduce_counts_all(svjg_ctx *const *ctxs, int n);
 
 /* ---- genotypes (predict-genotype.py:216-227 gate, :281-325 likelihood) -----------------------------
@@ -270,6 +278,9 @@ void svjg_vcf_free(svjg_vcf *v);
 /* ---- measurement hooks (bench.py): HIP-event time of the kernels of the last classify / genotype ---- */
 int svjg_last_kernel_ms(svjg_ctx *ctx, float *classify_main_ms, float *classify_slow_ms, float *genotype_ms);
 int svjg_sync(svjg_ctx *ctx);
+/* what a plain device-to-device copy of n_bytes reaches on this GPU right now (16 B per lane, grid-stride; best of three):
+ * bytes read + bytes written per second, in GB/s — the measured ceiling bench.py reports beside the 8 TB/s of the data sheet */
+int svjg_copy_rate(svjg_ctx *ctx, uint64_t n_bytes, double *gb_per_s);
 
 #ifdef __cplusplus
 }

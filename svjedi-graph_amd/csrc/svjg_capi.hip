@@ -125,6 +125,8 @@ struct svjg_ctx {
     float ms_main = 0, ms_slow = 0, ms_geno = 0;
     // rccl
     ncclComm_t comm = nullptr;
+    bool allreduce_second = false;       // svjg_comm_set_stream
+    uint64_t part_total = 0, part_need = 0, part_next = 0;   // svjg_gaf_upload_part
 };
 
 #define HIPCHK(ctx, call)                                                                         \
@@ -375,6 +377,22 @@ extern "C" int svjg_gaf_upload(svjg_ctx *c, const char *gaf, uint64_t n) {
     c->have_gaf = false;
     if (n) HIPCHK(c, hipMemcpyAsync(c->d_gaf, gaf, n, hipMemcpyHostToDevice, c->stream));   // (the runtime stages pageable memory itself: 47 GB/s measured)
     return gaf_finish(c, n, need);
+}
+
+extern "C" int svjg_gaf_upload_part(svjg_ctx *c, const char *gaf, uint64_t n, uint64_t offset, uint64_t capacity, int last) {
+    if (!c || (n && !gaf) || offset + n > capacity) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (offset == 0) {
+        int rc = gaf_reserve(c, capacity, &c->part_need);
+        if (rc) return rc;
+        c->have_gaf = false; c->part_total = capacity; c->part_next = 0;
+    }
+    if (capacity != c->part_total || offset != c->part_next || c->have_gaf) { c->err = "svjg_gaf_upload_part: pieces go in ascending order, the first at offset 0"; return SVJG_E_ARG; }
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_gaf + offset, gaf, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));               // (the caller's buffer may go away)
+    c->part_next = offset + n;
+    if (last) return gaf_finish(c, c->part_next, c->part_need);   // (zero padding from the text's end to the end of the buffer)
+    return 0;
 }
 
 extern "C" int svjg_gaf_upload_file(svjg_ctx *c, const char *path, uint64_t offset, uint64_t n) {
@@ -729,6 +747,13 @@ extern "C" int svjg_comm_init(svjg_ctx *c, const char *id128, int n_ranks, int r
     return 0;
 }
 
+extern "C" int svjg_comm_set_stream(svjg_ctx *c, int second_stream) {
+    if (!c) return SVJG_E_ARG;
+    if (c->run_inflight) { c->err = "svjg_comm_set_stream with a pass in flight"; return SVJG_E_ARG; }
+    c->allreduce_second = second_stream != 0;
+    return 0;
+}
+
 // the guard elements behind the count vector (svjg_pass.h) <- largest ref / alt field, and — st given: a fused pass — whether this
 // rank's pass must be repeated (k_counts_guard)
 static int launch_guard(svjg_ctx *c, unsigned long long *counts = nullptr, hipStream_t stream = nullptr, const DevStatus *st = nullptr) {
@@ -1040,7 +1065,8 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
     // fits beside the classify workers; the kernel writes its results straight into the pinned host block — they cross PCIe as they
     // are produced —, which takes ~45 us for 100 k rows.  Meanwhile the compute stream already runs the next pass (that one zeroes
     // and fills ITS count vector).
-    static const bool allreduce_second = [] { const char *e = getenv("SVJG_ALLREDUCE_STREAM"); return e && !strcmp(e, "second"); }();
+    static const bool env_second = [] { const char *e = getenv("SVJG_ALLREDUCE_STREAM"); return e && !strcmp(e, "second"); }();
+    const bool allreduce_second = env_second || c->allreduce_second;
     auto reduce_on = [&](hipStream_t st) -> int {
         int rc2 = launch_guard(c, r.counts, st, d_st);                  // (guard word 2: "this rank's lists overflowed")
         if (rc2) return rc2;
@@ -1163,6 +1189,30 @@ extern "C" int svjg_last_kernel_ms(svjg_ctx *c, float *m, float *s, float *g) {
     if (m) *m = c->ms_main;
     if (s) *s = c->ms_slow;
     if (g) *g = c->ms_geno;
+    return 0;
+}
+
+extern "C" int svjg_copy_rate(svjg_ctx *c, uint64_t n_bytes, double *gb_per_s) {
+    if (!c || !gb_per_s || n_bytes < 65536) return SVJG_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    n_bytes &= ~15ull;
+    uint4 *src = nullptr, *dst = nullptr;
+    if (hipMalloc((void **)&src, n_bytes) != hipSuccess || hipMalloc((void **)&dst, n_bytes) != hipSuccess) { hipFree(src); c->err = "svjg_copy_rate: no memory for the two buffers"; return SVJG_E_NOMEM; }
+    struct Free { uint4 *a, *b; ~Free() { hipFree(a); hipFree(b); } } fr{src, dst};
+    HIPCHK(c, hipMemsetAsync(src, 0x5A, n_bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(dst, 0, n_bytes, c->stream));
+    float best = 0;
+    for (int i = 0; i < 4; ++i) {                              // (the first run warms up)
+        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        hipLaunchKernelGGL(k_copy16, dim3((uint32_t)c->n_cu * 8), dim3(TPB), 0, c->stream, dst, src, n_bytes / 16);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+        if (i && (best == 0 || ms < best)) best = ms;
+    }
+    *gb_per_s = best > 0 ? 2.0 * (double)n_bytes / (best * 1e-3) / 1e9 : 0.0;
     return 0;
 }
 

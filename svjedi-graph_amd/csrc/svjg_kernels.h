@@ -39,7 +39,13 @@ constexpr uint32_t MAXL = 64;                       // line starts per stripe = 
 #endif
 #endif
 constexpr uint32_t CAP_O = SVJG_CAP_O;              // orientation marks ('<' '>') per stripe
-constexpr uint32_t KMAX = 64;                    // path nodes per alignment handled by the main kernel: one wave pass (longer paths: exact path)
+constexpr uint32_t KMAX = 64;                    // path nodes of one node pass (one wave, one node per lane)
+// A line of more than KMAX nodes — up to KLONG, what the stripe's list of marks and the 8-bit node count of a line's record hold — is
+// walked in sub-passes of 64 nodes that overlap by one (the step into the next sub-pass's first node is that sub-pass's own), twice:
+// once to learn the path's total length (the right-hand overlap test needs it, filter-alignments.py:271) and that its ids rise or
+// fall all the way or, where they turn, that no name comes twice (then list.index is the position itself), once to count.  A long
+// line that does come back to a node takes the exact path.
+constexpr uint32_t KLONG = CAP_O < 255u ? CAP_O : 255u;
 constexpr uint32_t LRW = MAXL;                   // lines per round
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // The path column ends at the first tab behind the line's LAST orientation mark (a node name has at most 48 bytes).  Should a tab sit in front of that mark (marks in later columns), the piece of text
                     // between two marks that holds it is no node name, and the node pass sends the line to the exact path.
                     k = kall;
-                    const bool kfit = k >= 1 && k <= KMAX;
+                    const bool kfit = k >= 1 && k <= KLONG;
                     const uint32_t m_first = OPL_POS(o0), m_last = OPL_POS(kfit ? o0 + k - 1 : o0);
                     uint32_t t5 = tab_near(tbm, m_last + 1);
                     if (t5 == TEXT) {                                     // (a name of 32..48 bytes: the tab is at most 49 bytes behind the mark)
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (fa | fb | n_int) id_span = fa | (fb << 1) | ((n_int < 3u ? n_int : 3u) << 2) | (isp << 4) | (ok_cols ? 1u << 11 : 0u);
                         id_end = e | (lend << 16);
                     }
-                    if (!ok && status == ST_DEFER && kall > KMAX) status = ST_DEFER + DC_LONG_PATH;
+                    if (!ok && status == ST_DEFER && kall > KLONG) status = ST_DEFER + DC_LONG_PATH;
                     else if (!ok && status == ST_DEFER && t5 == TEXT && t4 < TEXT && kfit) status = ST_DEFER + DC_NAME;   // (no tab within 49 bytes of the last mark: a name beyond 48 bytes)
                     if (ok_cols) {
                         if (ok) status = k >= 2 ? ST_OK : ST_NOHIT;
@@ -841,15 +847,33 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             // ---- node passes: up to 64 consecutive marks that cover whole lines; one mark (path node) per lane ----------------
             const wmask ok_lines = m_eq(status, ST_OK);                  // (lanes beyond cnt: ST_NONE)
             const uint32_t relend = rel + kall;
-            for (uint32_t i0 = 0; i0 < cnt;) {
-                const uint32_t p0 = rdlane(rel, i0);
-                const wmask nofit = m_gt(relend - p0, 64u) & low_bits64(cnt) & ~low_bits64(i0);
-                uint32_t i1 = nofit ? (uint32_t)__builtin_ctzll(nofit) : cnt;
-                if (i1 == i0) { ++i0; continue; }                        // a line with more than 64 marks (> KMAX): already deferred
-                const uint32_t n_pass = rdlane(relend, i1 - 1) - p0;
-                const wmask okl = ok_lines & low_bits64(i1) & ~low_bits64(i0);
-                i0 = i1;
-                if (!okl) continue;                                      // no line of the pass has a path to look at
+            // a line of more than 64 nodes (wave-uniform state; the line is lane i0's): lsub = 0: none, else sub-pass number + 1 | sweep << 8 |
+            // "the line's last sub-pass" << 16; lS = length of the path in front of the sub-pass's first node (behind its last one once the
+            // sub-pass has its lengths), lTOT = the path's total length (after sweep 0), lD0 = which way its ids run (3: they turn)
+            uint32_t lsub = 0, lS = 0, lTOT = 0, lD0 = 0;
+            for (uint32_t i0 = 0;;) {
+                uint32_t p0, n_pass;
+                wmask okl;
+                if (!RARELY(lsub)) {
+                    if (i0 >= cnt) break;
+                    p0 = rdlane(rel, i0);
+                    const wmask nofit = m_gt(relend - p0, 64u) & low_bits64(cnt) & ~low_bits64(i0);
+                    const uint32_t i1 = nofit ? (uint32_t)__builtin_ctzll(nofit) : cnt;
+                    if (RARELY(i1 == i0)) {                              // a line with more than 64 marks: sub-passes, if its columns were fine
+                        if ((ok_lines >> i0) & 1ull) { lsub = 1u; lS = 0; } else ++i0;
+                        continue;
+                    }
+                    n_pass = rdlane(relend, i1 - 1) - p0;
+                    okl = ok_lines & low_bits64(i1) & ~low_bits64(i0);
+                    i0 = i1;
+                    if (!okl) continue;                                  // no line of the pass has a path to look at
+                } else {
+                    const uint32_t t63 = ((lsub & 0xFFu) - 1u) * 63u, K = rdlane(kall, i0);
+                    p0 = rdlane(rel, i0) + t63;
+                    n_pass = K - t63 < 64u ? K - t63 : 64u;
+                    lsub = (lsub & 0xFFFFu) | (K - t63 <= 64u ? 0x10000u : 0u);
+                    okl = 1ull << i0;
+                }
                 __builtin_amdgcn_s_setprio(P_LOAD);
                 // -- the node of this lane: line, index in the line, name.  Every lane runs the same straight code on indices that
                 //    are safe to read (a lane beyond the pass looks at the pass's first mark); `live` says whose results count --
@@ -920,26 +944,51 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t gsum = wave_incl_scan(lbp);               // every lbp < 2^25: no overflow over 64 lanes
                 const uint32_t gfirst = (uint32_t)__shfl((int)(gsum - lbp), (int)lnb);
                 const uint32_t glast = (uint32_t)__shfl((int)gsum, (int)(lane + (lk ? lk - 1 - j : 0u)));
-                const uint32_t pre = gsum - gfirst, tot = glast - gfirst;
+                uint32_t pre = gsum - gfirst, tot = glast - gfirst;
                 // -- first occurrence of every name in its line (the reference's list.index / str.split quirks): every lane looks at
                 //    the lanes below it, one DPP wave shift per distance (no LDS round trips), as far as the longest line of the pass
                 //    reaches.  key = id | line << 26: lanes of other lines never compare equal --
                 // A line whose node ids rise all the way, or fall all the way, cannot come back to a node (the ids follow the genome): only
                 // when some line of the pass does neither do the lanes of THOSE lines search, as far as the longest of them reaches.
-                const wmask step_m = m_lt(j + 1u, lk);                   // lanes with a step to the next node of their line (a dead lane: lk = 0)
+                const wmask step_m = m_lt(j + 1u, lk) & low_bits64(n_pass - 1u);   // lanes with a step to the next node of their line inside the pass (a dead lane: lk = 0)
                 const uint32_t nxv = lane_above((id << 1) | oribit);
                 const uint32_t idl = id, idr = nxv >> 1;
                 uint32_t f = lane;
+                const uint32_t dir = idr > id ? 1u : idr < id ? 2u : 0u;
+                bool l_dup = false;
+                if (RARELY(lsub)) {
+                    // -- a sub-pass of a long line: the path's length in front of it and its total come from the sub-passes before;
+                    //    sweep 0 only measures (total length, no name twice, every name known), sweep 1 counts --
+                    pre = gsum + lS; tot = lTOT;
+                    lS += rdlane(gsum, (lsub & 0x10000u) ? n_pass - 1u : n_pass - 2u);   // (the last node of a sub-pass that is not the last is the next one's first)
+                    if (!(lsub & 0x100u)) {
+                        // Does a name come twice?  While the ids rise (or fall) all the way, no.  Once they turn, every node is held against
+                        // the nodes of the sub-passes before it (their ids wait where the tab bitmap was: the line phase is over) and, further
+                        // down, against those of its own sub-pass (the search every pass has for lines whose ids turn).
+                        const uint32_t t63 = ((lsub & 0xFFu) - 1u) * 63u;
+                        uint32_t *IDS = tbm;
+                        if (t63 == 0u) lD0 = rdlane(dir, 0);
+                        if (lD0 != 3u && (step_m & (m_ne(dir, lD0) | m_eq(dir, 0u))) != 0ull) lD0 = 3u;
+                        if (live) IDS[t63 + lane] = id;
+                        if (lD0 == 3u) {
+                            wave_sync();
+                            wmask d = 0;
+                            for (uint32_t m = 0; m < t63; ++m) d |= m_eq(id, IDS[m]);
+                            l_dup = (d & live_m) != 0ull;
+                        }
+                    }
+                }
                 {
-                    const uint32_t dir = idr > id ? 1u : idr < id ? 2u : 0u;
                     const uint32_t dprev = lane_below(dir);
                     const wmask oddm = step_m & (m_eq(dir, 0u) | (m_ge(j, 1u) & m_ne(dir, dprev)));
                     if (RARELY(oddm)) {
-                        const wmask search_m = live_m & ballot64(((low_bits64(lk) << lnb) & oddm) != 0ull);   // this lane's line is one of them
+                        // the lanes of the lines that have such a step (a sub-pass of a long line: every lane is that line's)
+                        const wmask search_m = live_m & (RARELY(lsub) ? ~0ull : ballot64(((low_bits64(lk) << lnb) & oddm) != 0ull));
                         const bool search = in_mask(search_m);
                         const uint32_t key = search ? (id | (ln << 26)) : NONE32;
+                        const uint32_t jl = j < lane ? j : lane;             // nodes of the line below this lane, in this pass
                         uint32_t y = key;
-                        for (uint32_t dd = 1; search_m & m_ge(j, dd); dd += 4) {
+                        for (uint32_t dd = 1; search_m & m_ge(jl, dd); dd += 4) {
                             y = lane_below_or(y, NONE32); if (y == key) f = lane - dd;
                             y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 1u;
                             y = lane_below_or(y, NONE32); if (y == key) f = lane - dd - 2u;
@@ -949,6 +998,16 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
                 const bool revisits = m_ne(f, lane) != 0;                // wave-uniform: some line of the pass comes back to a node
+                if (RARELY(lsub) && !(lsub & 0x100u)) {
+                    // sweep 0 of a long line ends here: a name the table does not hold (its record says so already) or a name that comes
+                    // twice -> the exact path; else on to the next sub-pass, or to sweep 1 with the path's total length
+                    if (live_m == 0ull || revisits || l_dup) {
+                        if (live_m != 0ull) { if (lane == 0) ((uint32_t *)&RL[i0])[2] = (rdlane(meta, 0) & 0x00FFFFFFu) | ((ST_DEFER + DC_LONG_PATH) << 24); wave_sync(); }
+                        ++i0; lsub = 0;
+                    } else if (lsub & 0x10000u) { lTOT = lS; lS = 0; lsub = 0x101u; }
+                    else ++lsub;
+                    continue;
+                }
                 // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
                 //    (str.split / list.index, filter-alignments.py:206, :269-271); equal names have equal ids and hashes --
                 uint32_t fl = lane, fr = lane + 1u, pre_l = pre, pre_rx = pre, orl = oribit, orr = nxv & 1u;
@@ -963,7 +1022,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // overlap test of the step (a lane without a step fails it); then the link is looked for among the (up to four)
                 // that sit in the left node's record — straight selects, no branches —; the link table is asked only if it is not
                 // there and the node has more links, or for a revisited node (the link between the first occurrences)
-                const wmask go_m = step_m & m_ge(pre_l, need_l) & m_ge(tot - (fr > lnb ? pre_rx : 0u), need_r);
+                const wmask go_m = step_m & m_ge(pre_l, need_l) & m_ge(tot - ((int32_t)fr > (int32_t)lnb ? pre_rx : 0u), need_r);   // (lnb < 0: a sub-pass inside a long line)
                 const uint32_t want = (idr << 2) | orl | (orr << 1);
                 const wmask le24 = m_le(len, 24u), le32 = m_le(len, 32u);   // (a longer name's bytes sit where the first links would)
                 const wmask m0 = le24 & m_eq(r2.x, want), m1 = le32 & m_eq(r2.z, want), m2 = le32 & m_eq(r3.x, want), m3 = m_eq(r3.z, want);
@@ -1023,6 +1082,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     for (uint32_t jj = hp ? 0u : 1u; jj < n; ++jj) emit(hp ? hp[jj] : h1, jj);
                 }
                 tick(6);
+                if (RARELY(lsub)) { if (lsub & 0x10000u) { ++i0; lsub = 0; } else ++lsub; }   // (sweep 1 of a long line: its next sub-pass, or the next line)
             }
             wave_sync();
             // ---- R6: lines for the exact path ------------------------------------------------------------------
@@ -1068,6 +1128,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     if ((a.diag & 16u) && lane == 0)
         for (int i = 0; i < 12; ++i) atomicAdd(&a.dbg[i], acc[i]);
 #endif
+}
+
+// svjg_copy_rate: a plain copy, 16 bytes per lane, grid-stride (what the HBM gives a kernel that does nothing else)
+__global__ __launch_bounds__(TPB) void k_copy16(uint4 *dst, const uint4 *src, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * TPB) dst[i] = src[i];
 }
 
 // svjg_run_resident: the three things a pass starts from — zero counts (and guard words), a fresh status block, "no row lacked its

@@ -4,6 +4,7 @@ There is no fallback: if the shared library is missing, or no MI355X is visible,
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -55,6 +56,9 @@ _SIGS = {
     "svjg_load_graph": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(CGraph)]),
     "svjg_release_host_tables": (None, []),
     "svjg_gaf_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "svjg_gaf_upload_part": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
+    "svjg_comm_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "svjg_copy_rate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double)]),
     "svjg_classify_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
     "svjg_classify": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
     "svjg_gaf_upload_file": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
@@ -270,7 +274,9 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("SVJG_HIP_LIB") or LIB_PATH    # SVJG_HIP_LIB: a measurement build of the same library (tools/mkvariant.sh -> build/lib_<name>.so)
+    if p != LIB_PATH and path is None:
+        sys.stderr.write(f"[svjg] measurement build in use: {p}\n")
     if not os.path.exists(p):
         raise SvjgError(f"{p} not found: build it first (python __graft_entry__.py build, needs hipcc); there is no CPU fallback")
     # Copies by shader, not by the copy engines: the ROCm runtime creates the queue of a copy engine the first time a copy happens
@@ -341,6 +347,30 @@ class Context:
     def upload(self, gaf):
         a = _as_u8(gaf)
         self._chk(self.lib.svjg_gaf_upload(self.h, a.ctypes.data if a.size else None, a.size))
+
+    def upload_parts(self, parts, capacity_bytes):
+        """the resident text from an iterable of pieces (ascending; at most `capacity_bytes` in all): a text the host never holds
+        whole (svjg_gaf_upload_part).  -> bytes uploaded"""
+        at, prev = 0, None
+        for p in parts:
+            if prev is not None:
+                self._chk(self.lib.svjg_gaf_upload_part(self.h, prev.ctypes.data if prev.size else None, prev.size, at, capacity_bytes, 0))
+                at += int(prev.size)
+            prev = _as_u8(p)
+        if prev is None:
+            prev = np.zeros(0, dtype=np.uint8)
+        self._chk(self.lib.svjg_gaf_upload_part(self.h, prev.ctypes.data if prev.size else None, prev.size, at, capacity_bytes, 1))
+        return at + int(prev.size)
+
+    def allreduce_on_second_stream(self, on):
+        """where the fused pass puts its all-reduce (svjg_comm_set_stream): False = the compute stream (default)"""
+        self._chk(self.lib.svjg_comm_set_stream(self.h, 1 if on else 0))
+
+    def copy_rate(self, n_bytes=1 << 31):
+        """GB/s (read + written) of a plain device-to-device copy on this GPU (svjg_copy_rate)"""
+        v = ctypes.c_double(0)
+        self._chk(self.lib.svjg_copy_rate(self.h, n_bytes, ctypes.byref(v)))
+        return v.value
 
     def classify_resident(self, base_offset=0, want_hits=False):
         self._chk(self.lib.svjg_classify_resident(self.h, base_offset, int(want_hits)))

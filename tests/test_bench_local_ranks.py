@@ -118,7 +118,7 @@ def test_bench_under_the_launcher_two_ranks(tmp_path):
     env = dict(os.environ, SVJG_BENCH_CAPI="tests.standin_capi", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--aln", "2000", "--svs", "300", "--no-e2e", "--no-cpu-baseline"]
+           "--aln", "2000", "--svs", "300", "--no-e2e", "--no-cpu-baseline", "--north-star-aln", "3000", "--north-star-svs", "200"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -127,3 +127,10 @@ def test_bench_under_the_launcher_two_ranks(tmp_path):
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak"
     assert r["rccl"]["ranks"] == 2 and r["config"]["alignments_per_gpu"] == 2000
     assert abs(r["value"] - 2 * 2000 * 2 / (r["ms_per_step"] * 2e-3)) < 1e-6 * r["value"]
+    # the timed passes again until they span a quarter of a second, and the north_star workload split over the two ranks
+    sus = r["sustained"]
+    assert sus["steps"] >= 2 and sus["seconds"] >= 0.2 and abs(sus["alignments_per_s"] - 2 * 2000 * sus["steps"] / sus["seconds"]) < 1e-6 * sus["alignments_per_s"]
+    ns = r["north_star"]
+    assert ns["n_gpus"] == 2 and ns["alignments"] == 3000 and ns["alignments_per_gpu"] == 1500 and ns["passes"] == 3
+    assert ns["digest_equal_across_ranks"] is True and len(ns["counts_digest"]) == 16 and ns["alignments_per_s"] > 0
+    assert "allreduce_stream" in r["rccl"] and "debug_info" in r["rccl"]

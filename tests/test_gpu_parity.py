@@ -204,16 +204,18 @@ def test_realshape_lines(ctx, golden, all_slow, tmp_path):
     if not all_slow:
         st = ctx.stats()
         n_lines = sum(1 for _ in open(f"{r}/r.gaf"))
-        # exact path: paths of more than 64 nodes, the line(s) next to an id:f: tag; the UCSC contig names of up to 36 bytes stay in the main kernel
+        # exact path: what no stripe of 8 KB holds — a line beyond 8 KB, a path of more than 216 nodes —, the line(s) next to an id:f: tag.  Paths of
+        # 65..216 nodes stay in the main kernel since r04 (sub-passes), as do the UCSC contig names of up to 36 bytes
         gl = [l.split("\t") for l in open(f"{r}/r.gaf")]
-        n_long = sum(1 for c in gl if c[5].count(">") + c[5].count("<") > 64)
+        k_of = [c[5].count(">") + c[5].count("<") for c in gl]
+        n_long = sum(1 for k in k_of if k > 64)
+        n_over = sum(1 for c, k in zip(gl, k_of) if k > 216 or len("\t".join(c)) > 8000)
         n_tag = sum(1 for c in gl if any(x.startswith("id:f:") for x in c[12:]))
         cause = ctx.defer_causes()
         assert st["n_lines"] == n_lines and st["n_deferred"] == sum(cause.values())
-        # (a path of hundreds of nodes also overfills its stripe's lists, a line beyond 8 KB has no stripe: those count as whole stripes)
-        assert cause["long_path"] + cause["whole_stripe"] >= n_long > 0 and cause["long_path"] > 0 and cause["node_name"] == 0 and cause["columns"] == 0
+        assert n_long > n_over > 0 and cause["long_path"] == 0 and cause["node_name"] == 0 and cause["columns"] == 0, (cause, n_long, n_over)
         assert cause["id_tag_filter"] <= 2 * n_tag + 2, (cause, n_tag)                   # (read names / cg:Z: strings hold no "d:"; a tag with a plain decimal value stays in the main kernel)
-        assert st["n_deferred"] <= n_long + 2 * n_tag + 4, (st, cause)                  # r02: up to 70 % of the 176 lines; now 15
+        assert st["n_deferred"] <= 2 * n_over + 2 * n_tag + 2, (st, cause)              # r02: up to 70 % of the 176 lines; r03: 15 (every path beyond 64 nodes)
 
 
 def test_two_gpus_one_rccl_allreduce(tmp_path):
@@ -582,7 +584,7 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
     names = [n for n in g.node_names if "." not in n.split(":")[-1]]          # reference nodes in genome order
     lens = {n: int(n.split(":")[1].split("-")[1]) - int(n.split(":")[1].split("-")[0]) + 1 for n in names}
     lines = []
-    for k, start in ((17, 3), (25, 40), (60, 100), (16, 200), (33, 300), (128, 350), (129, 10), (150, 500)):
+    for k, start in ((17, 3), (25, 40), (60, 100), (16, 200), (33, 300), (128, 350), (129, 10), (150, 500), (216, 420), (217, 30), (250, 333)):
         path = names[start:start + k]
         tlen = sum(lens[n] for n in path)
         fwd = "".join(">" + n for n in path)
@@ -597,7 +599,10 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
     ctx.classify(np.frombuffer(data, dtype=np.uint8))
     assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
     st = ctx.stats()
-    assert st["n_lines"] == n_lines and st["n_deferred"] >= 4          # 129 / 150 nodes in both directions (the long line only if it crosses its stripe's look-ahead)
+    # 217 / 250 nodes in both directions: more marks than a stripe's list holds (up to 216 nodes stay in the main kernel: sub-passes);
+    # the line with the 9 KB tag has no stripe
+    cause = ctx.defer_causes()
+    assert st["n_lines"] == n_lines and 4 <= st["n_deferred"] <= 8 and cause["long_path"] == 0, (st, cause)
     # a stripe of lines shorter than any valid GAF line
     dense = b"x\t1\n" * 20000
     with pytest.raises(ValueError):
@@ -778,9 +783,12 @@ def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
             c = l.split(b"\t"); c[7] = b" " + c[7]; l = b"\t".join(c)
         out.append(l)
     # one very long path: walk a chromosome's reference nodes forwards and backwards
+    # one very long path: a chromosome's reference nodes forwards, then one step back (a path of more than 64 nodes whose ids turn: the
+    # exact path finds the names' first occurrences), and the same without the turn (stays in the main kernel)
     names = [n for n in g.node_names if n.startswith("chr1:") and "." not in n.split(":")[1]][:70]
-    nlen = [int(n.split("-")[1]) - int(n.split(":")[1].split("-")[0]) + 1 for n in names]
-    out.insert(1000, b"long\t90000\t0\t90000\t+\t" + "".join(">" + n for n in names).encode() + b"\t%d\t0\t%d\t90000\t90000\t60\ttp:A:P" % (sum(nlen), sum(nlen)))
+    for tag, walk in ((b"turn", names + [names[-2]]), (b"straight", names)):
+        nlen = [int(n.split("-")[1]) - int(n.split(":")[1].split("-")[0]) + 1 for n in walk]
+        out.insert(1000, tag + b"\t90000\t0\t90000\t+\t" + "".join(">" + n for n in walk).encode() + b"\t%d\t0\t%d\t90000\t90000\t60\ttp:A:P" % (sum(nlen), sum(nlen)))
     data = np.frombuffer(b"\n".join(out) + b"\n", dtype=np.uint8)
     want, _, n_lines = orc.filter(data, want_hits=False)
     ctx.load_graph(g)
@@ -789,11 +797,92 @@ def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
     assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
     st, cause = ctx.stats(), ctx.defer_causes()
     assert st["n_lines"] == n_lines and st["n_deferred"] == sum(cause.values())
-    assert cause["long_path"] == 1 and cause["whole_stripe"] == 0 and cause["node_name"] == 0
+    assert cause["long_path"] == 1 and cause["whole_stripe"] == 0 and cause["node_name"] == 0       # (the path that turns; the straight one of 70 nodes stays)
     # a tagged line, and at most the two lines that share a 64-byte span with its tag (one of which may be a line with a blank)
     assert len(blank) - 8 <= cause["columns"] <= len(blank)
     assert len(tagged) <= cause["id_tag_filter"] <= 2 * len(tagged) + 2
     assert st["n_deferred"] <= 1 + len(blank) + 2 * len(tagged) + 2
+
+
+def test_paths_of_65_to_216_nodes(ctx, tmp_path):
+    """Paths longer than one node pass (64 nodes) stay in the main kernel up to what a stripe's list of marks holds (216): sub-passes of
+    64 nodes that overlap by one, walked twice (total length and monotone ids first, then the counts).  Lengths around every sub-pass
+    boundary, both directions, through insertion nodes, with margins that fail the overlap test at either end; a long path whose ids
+    turn (a node revisited mid-way, at a sub-pass boundary, right at the end) takes the exact path.  Counts are the C oracle's and
+    the JSON text the Python oracle's."""
+    import synth
+    from svjg import capi
+    from svjg.graph import Graph
+    pre = str(tmp_path / "c")
+    inf = synth.generate(pre, 3000, 900, 1, "mixed", 77, write_gaf=False, return_gaf=True)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    edges, alt = O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa")
+    orc = OC.COracle(edges, alt)
+    # walks over the graph's links that have SVs: from node to node along "L@+@R@+" keys, preferring insertion nodes now and then
+    nxt = {}
+    for key in edges:
+        l, ls, r, rs = key.split("@")
+        if ls == "+" and rs == "+":
+            nxt.setdefault(l, []).append(r)
+
+    def nlen(n):
+        c = n.split(":")[-1]
+        return alt[n] if "." in c else int(c.split("-")[1]) - int(c.split("-")[0]) + 1
+    ref = sorted((n for n in g.node_names if "." not in n.split(":")[-1]), key=lambda n: int(n.split(":")[1].split("-")[0]))
+    rng = np.random.default_rng(3)
+
+    def where(n):                                                # walk order: by position, an insertion's node in front of the reference node behind it
+        c = n.split(":")[-1]
+        return (int(c.split(".")[0]), 0) if "." in c else (int(c.split("-")[0]), 1)
+
+    def walk(k, start):
+        cur, out = ref[start], [ref[start]]
+        while len(out) < k:
+            cand = sorted((c for c in nxt.get(cur, []) if where(c) > where(cur)), key=where) or [ref[ref.index(cur) + 1]]
+            ins = [c for c in cand if where(c)[1] == 0]
+            cur = ins[0] if ins and rng.random() < 0.4 else cand[0]      # straight on, through an insertion now and then
+            out.append(cur)
+        return out
+
+    def line(name, path, rev=False, ts=5, te_back=7, ori=None):
+        tl = sum(nlen(n) for n in path)
+        if ori is not None:                                      # (orientation per node: an inverted stretch is walked backwards)
+            p = "".join(o + n for o, n in zip(ori, path)) if not rev else "".join((">" if o == "<" else "<") + n for o, n in zip(reversed(ori), reversed(path)))
+        else:
+            p = "".join(("<" if rev else ">") + n for n in (reversed(path) if rev else path))
+        return f"{name}\t{tl}\t0\t{tl}\t+\t{p}\t{tl}\t{ts}\t{tl - te_back}\t{tl}\t{tl}\t60\ttp:A:P\tcm:i:9\n".encode()
+    lines = []
+    for k in (65, 66, 100, 126, 127, 128, 129, 189, 190, 191, 192, 215, 216):
+        w = walk(k, int(rng.integers(0, 300)))
+        for rev in (False, True):
+            lines.append(line(f"k{k}r{int(rev)}", w, rev))
+            lines.append(line(f"k{k}r{int(rev)}m", w, rev, ts=nlen(w[-1 if rev else 0]) + 3, te_back=nlen(w[0 if rev else -1]) + 2))   # the first and last step fail the overlap test
+    for k, at in ((130, 64), (130, 63), (130, 100), (70, 69), (200, 127), (66, 1)):                     # ids that turn: node `at` - 1 comes again behind node `at`
+        w = walk(k, int(rng.integers(0, 300)))
+        w = w[:at + 1] + [w[at - 1]] + w[at + 1:]
+        lines.append(line(f"turn{k}at{at}", w))
+    # long paths whose ids turn although no name comes twice (a jump back to an earlier stretch of the chromosome, as over a translocation or
+    # across an inverted stretch): they stay in the main kernel — sweep 0 holds every node against the nodes before it —; the turn lies in the
+    # first sub-pass, at its last node, at the second sub-pass's first nodes, in the second
+    for lead in (30, 62, 63, 64, 65, 90, 126, 127):
+        a0 = 400 + lead
+        w = ref[a0: a0 + lead + 1] + ref[100 + lead: 100 + lead + 80]
+        for rev in (False, True):
+            lines.append(line(f"jump{lead}r{int(rev)}", w, rev))
+    body = inf["gaf"].tobytes()
+    data = body[:150000].rsplit(b"\n", 1)[0] + b"\n" + b"".join(lines) + body[150000:].split(b"\n", 1)[1]
+    want, hits, n_lines = orc.filter(data, want_hits=True)
+    ctx.load_graph(g)
+    ctx.reset_counts()
+    ctx.classify(np.frombuffer(data, dtype=np.uint8), want_hits=True)
+    assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 10000
+    st, cause = ctx.stats(), ctx.defer_causes()
+    assert st["n_lines"] == n_lines and cause["long_path"] == 6 and cause["whole_stripe"] == 0 and cause["node_name"] == 0, (st, cause)
+    capi.write_informative_json(str(tmp_path / "o.json"), np.frombuffer(data, dtype=np.uint8), ctx.hits(), g.sv_ids)
+    assert open(tmp_path / "o.json").read() == O.dump_informative(O.classify(data.decode().splitlines(True), edges, alt))
+    # the long lines alone carry hits (a walk crosses an SV at almost every step)
+    only, _, _ = orc.filter(b"".join(lines), want_hits=False)
+    assert only.sum() > 3000
 
 
 def test_lines_longer_than_the_look_ahead(ctx, tmp_path):

@@ -2,7 +2,7 @@
 run on the GPU box with SVJG_DIAG=16: the library prints the cycle sums of lane 0 of every worker)"""
 import os, sys, tempfile, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-shutil.copy(os.path.join(ROOT, "build", "lib_timing.so"), os.path.join(ROOT, "svjedi-graph_amd", "csrc", "libsvjg_hip.so"))
+os.environ["SVJG_HIP_LIB"] = os.path.join(ROOT, "build", "lib_timing.so")      # (selected, not copied over the shipped library)
 for p in (ROOT, os.path.join(ROOT, "svjedi-graph_amd"), os.path.join(ROOT, "tools")):
     sys.path.insert(0, p)
 import synth

@@ -1,5 +1,5 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; export TMPDIR=/tmp
-cp svjedi-graph_amd/csrc/libsvjg_hip.so /tmp/keep.so; cp build/lib_ablate.so svjedi-graph_amd/csrc/libsvjg_hip.so
+export SVJG_HIP_LIB=$R/build/lib_ablate.so     # (selected through svjg/capi.py, never copied over the shipped library)
 for d in 32 1 2 8 0; do
   export SVJG_DIAG=$d SVJG_BENCH_SYNC=1
   rm -rf /tmp/pm; timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY -d /tmp/pm -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-e2e --steps 2 --warmup 1 > /tmp/pm.log 2>&1
@@ -15,4 +15,3 @@ print(" ".join(f"{k.replace('SQ_','')}={sum(v)/len(v)/1e6:.1f}M" for k, v in sor
 PY
 )"
 done
-cp /tmp/keep.so svjedi-graph_amd/csrc/libsvjg_hip.so

@@ -96,3 +96,87 @@ long svjg_synth_gaf(const char *names, const uint32_t *name_off, const uint32_t 
     }
     return (long)(p - out);
 }
+
+
+/* Long-read shaped lines (bench.py's secondary block; tests/golden/realshape has the hand-made originals): PacBio / ONT style read
+ * names, paths whose length is long-tailed — 2 + Geometric(mean ~9) for most, a uniform 65..200 nodes for 3 % of the lines — in both
+ * directions, the five minigraph tags, and on a third of the lines a cg:Z: string of 20..420 operations (none where the path alone
+ * fills most of a stripe).  Same counter-based stream per line as above. */
+#define KLONGMAX 304
+long svjg_synth_gaf_long(const char *names, const uint32_t *name_off, const uint32_t *node_len,
+                         uint32_t n_ref_nodes, const uint32_t *arc_ptr, const uint32_t *arc_to,
+                         const int32_t *arc_sv, const uint8_t *sv_gt, uint64_t seed,
+                         uint64_t first, uint64_t n, char *out, uint64_t cap)
+{
+    char *p = out, *end = out + cap;
+    static const char hex[] = "0123456789abcdef";
+    for (uint64_t li = first; li < first + n; ++li) {
+        rng_t r; r.s = seed * 0xD1342543DE82EF95ull + li * 0x2545F4914F6CDD1Dull + 7;
+        sm64(&r.s);
+        uint32_t st[KLONGMAX + 4]; int k = 1;
+        st[0] = (uint32_t)below(&r, n_ref_nodes) * 2u;
+        int want = 2;
+        if (below(&r, 100) < 3) want = 65 + (int)below(&r, 136);
+        else while (want < 64 && below(&r, 9) != 0) ++want;
+        int hap = (int)(sm64(&r.s) & 1);
+        while (k < want) {
+            uint32_t cur = st[k - 1], a0 = arc_ptr[cur], a1 = arc_ptr[cur + 1];
+            int32_t pick = -1, refarc = -1;
+            for (uint32_t a = a0; a < a1; ++a) {
+                if (arc_sv[a] < 0) { if (refarc < 0) refarc = (int32_t)a; continue; }
+                uint8_t g = sv_gt[arc_sv[a]];
+                if (pick < 0 && (g == 2 || (g == 1 && hap))) pick = (int32_t)a;
+            }
+            if (pick < 0) pick = refarc;
+            if (pick < 0) break;
+            st[k++] = arc_to[pick];
+        }
+        if (k >= 2 && below(&r, 1000) == 0 && k + 2 <= KLONGMAX) {  /* 0.1 %: revisit a node pair */
+            int j = (int)below(&r, (uint64_t)(k - 1));
+            memmove(&st[j + 4], &st[j + 2], (size_t)(k - j - 2) * sizeof(uint32_t));
+            st[j + 2] = st[j]; st[j + 3] = st[j + 1];
+            k += 2;
+        }
+        if (sm64(&r.s) & 1) {
+            for (int i = 0; i < k / 2; ++i) { uint32_t t = st[i]; st[i] = st[k - 1 - i]; st[k - 1 - i] = t; }
+            for (int i = 0; i < k; ++i) st[i] ^= 1u;
+        }
+        uint64_t tlen = 0, path_bytes = 0;
+        for (int i = 0; i < k; ++i) { tlen += node_len[st[i] >> 1]; path_bytes += 1 + name_off[(st[i] >> 1) + 1] - name_off[st[i] >> 1]; }
+        uint64_t lf = node_len[st[0] >> 1], ll = node_len[st[k - 1] >> 1];
+        uint64_t ts = below(&r, lf < 400 ? lf : 400);
+        uint64_t te = tlen - below(&r, ll < 400 ? ll : 400);
+        if (te <= ts) { ts = 0; te = tlen; }
+        uint64_t alen = te - ts, am = alen - alen / 10 - below(&r, alen / 20 + 1);
+        int n_ops = (below(&r, 3) == 0 && path_bytes < 4500) ? 20 + (int)below(&r, 401) : 0;
+        if ((uint64_t)(end - p) < 768 + path_bytes + (uint64_t)n_ops * 8) return -1;
+        if (li & 1) {                                            /* PacBio: movie/zmw/ccs */
+            memcpy(p, "m64011_190830_220126/", 21); p += 21; p = put_u64(p, 4000000 + li % 90000000); memcpy(p, "/ccs", 4); p += 4;
+        } else {                                                 /* ONT: a UUID */
+            uint64_t a = sm64(&r.s), b = sm64(&r.s);
+            for (int i = 0; i < 32; ++i) { if (i == 8 || i == 12 || i == 16 || i == 20) *p++ = '-'; *p++ = hex[((i < 16 ? a : b) >> (4 * (i & 15))) & 15]; }
+        }
+        *p++ = '\t';
+        p = put_u64(p, alen + 37); *p++ = '\t'; p = put_u64(p, 12); *p++ = '\t'; p = put_u64(p, alen + 12); *p++ = '\t';
+        *p++ = '+'; *p++ = '\t';
+        for (int i = 0; i < k; ++i) {
+            uint32_t nd = st[i] >> 1, l = name_off[nd + 1] - name_off[nd];
+            *p++ = (st[i] & 1) ? '<' : '>';
+            memcpy(p, names + name_off[nd], l); p += l;
+        }
+        *p++ = '\t'; p = put_u64(p, tlen); *p++ = '\t'; p = put_u64(p, ts); *p++ = '\t'; p = put_u64(p, te); *p++ = '\t';
+        p = put_u64(p, am); *p++ = '\t'; p = put_u64(p, alen); *p++ = '\t'; p = put_u64(p, 60);
+        memcpy(p, "\ttp:A:P\tcm:i:", 13); p += 13; p = put_u64(p, am / 12 + 1);
+        memcpy(p, "\ts1:i:", 6); p += 6; p = put_u64(p, am - am / 7);
+        memcpy(p, "\ts2:i:", 6); p += 6; p = put_u64(p, below(&r, 200));
+        memcpy(p, "\tdv:f:0.", 8); p += 8;
+        { uint64_t dv = below(&r, 1500); *p++ = (char)('0' + dv / 1000); *p++ = (char)('0' + dv / 100 % 10);
+          *p++ = (char)('0' + dv / 10 % 10); *p++ = (char)('0' + dv % 10); }
+        if (n_ops) {
+            memcpy(p, "\tcg:Z:", 6); p += 6;
+            for (int i = 0; i < n_ops; ++i) { p = put_u64(p, 1 + below(&r, (i & 1) ? 4 : 300)); *p++ = (i & 1) ? ((i & 2) ? 'I' : 'D') : 'M'; }
+        }
+        *p++ = '\n';
+    }
+    return (long)(p - out);
+}

@@ -38,10 +38,11 @@ def build_lib():
         os.makedirs(os.path.dirname(so), exist_ok=True)
         subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
     lib = ctypes.CDLL(so)
-    lib.svjg_synth_gaf.restype = ctypes.c_long
-    lib.svjg_synth_gaf.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
-                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                   ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    for fn in (lib.svjg_synth_gaf, lib.svjg_synth_gaf_long):
+        fn.restype = ctypes.c_long
+        fn.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                       ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
     _LIB = lib
     return lib
 
@@ -63,7 +64,18 @@ def _draws(seed, n, stream):
 _INS_UNIT = "ACGTTGCAAGCT"
 
 
-def make_svs(n_sv, n_chrom, mix, seed):
+_UCSC = ["chr1", "chr2", "chrX", "chr1_KI270706v1_random", "chr14_GL000009v2_random", "chrUn_KI270442v1", "chr17_JH159146v1_alt", "chrUn_GL000195v1",
+         "chr3", "chr4", "chr22_KI270879v1_alt", "chr5", "chrY", "chr6", "chr19_KI270938v1_alt", "chr7"]
+
+
+def chrom_names(n_chrom, style="plain"):
+    """plain: chr1 .. chrN; ucsc: GRCh38-style names, contigs of up to 23 bytes among them (node names of up to ~40 bytes)"""
+    if style == "ucsc":
+        return [_UCSC[c] if c < len(_UCSC) else "chr%d_alt%d" % (c % 22 + 1, c) for c in range(n_chrom)]
+    return ["chr%d" % (c + 1) for c in range(n_chrom)]
+
+
+def make_svs(n_sv, n_chrom, mix, seed, chrom_style="plain"):
     """-> list of SV dicts in VCF order, chromosome names, chromosome lengths."""
     W = 1000 if mix == "del" else 8000
     u_type = _draws(seed, n_sv, 1) % np.uint64(1000)
@@ -88,7 +100,7 @@ def make_svs(n_sv, n_chrom, mix, seed):
         if t == "INS" and int(u_c[i] % np.uint64(100)) < 5:
             pair_next = True
     n_win = w + 1
-    chroms = ["chr%d" % (c + 1) for c in range(n_chrom)]
+    chroms = chrom_names(n_chrom, chrom_style)
     first_win = [(c * n_win) // n_chrom for c in range(n_chrom + 1)]
     win_chrom = np.searchsorted(np.array(first_win[1:]), np.arange(n_win), side="right")
     chrom_len = [(first_win[c + 1] - first_win[c] + 2) * W for c in range(n_chrom)]
@@ -298,9 +310,11 @@ def load_tables(prefix):
     return tab
 
 
-def gaf_bytes(tab, seed, first, n, threads=8):
-    """GAF text for lines [first, first+n) as one numpy uint8 array."""
+def gaf_bytes(tab, seed, first, n, threads=8, shape="short"):
+    """GAF text for lines [first, first+n) as one numpy uint8 array.  shape "long": long-read shaped lines (svjg_synth_gaf_long: read
+    names of sequencers, paths long-tailed to 200 nodes, cg:Z: strings on a third of the lines)."""
     lib = build_lib()
+    fn = lib.svjg_synth_gaf_long if shape == "long" else lib.svjg_synth_gaf
     threads = max(1, min(threads, (n + 9999) // 10000))
     step = (n + threads - 1) // threads
     # measurement only (SVJG_SYNTH_HOT=d): reads start in the first 1/d of the reference nodes, so that the records they touch fit the L2
@@ -309,9 +323,9 @@ def gaf_bytes(tab, seed, first, n, threads=8):
     def work(t):
         a = first + t * step
         cnt = max(0, min(step, first + n - a))
-        cap = cnt * 700 + 4096
+        cap = cnt * (2600 if shape == "long" else 700) + 16384
         buf = np.empty(cap, dtype=np.uint8)
-        got = lib.svjg_synth_gaf(tab["blob"], tab["off"].ctypes.data, tab["len"].ctypes.data, n_start,
+        got = fn(tab["blob"], tab["off"].ctypes.data, tab["len"].ctypes.data, n_start,
                                  tab["ptr"].ctypes.data, tab["to"].ctypes.data, tab["sv"].ctypes.data,
                                  tab["gt"].ctypes.data, seed, a, cnt, buf.ctypes.data, cap)
         assert got >= 0
@@ -322,9 +336,9 @@ def gaf_bytes(tab, seed, first, n, threads=8):
     return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
 
-def generate(prefix, n_aln, n_sv, n_chrom, mix, seed, write_gaf=True, threads=8, return_gaf=False):
+def generate(prefix, n_aln, n_sv, n_chrom, mix, seed, write_gaf=True, threads=8, return_gaf=False, chrom_style="plain", shape="short"):
     """Writes {prefix}.vcf, {prefix}.gfa, {prefix}_svs_edges.json (and {prefix}.gaf)."""
-    svs, chroms, chrom_len = make_svs(n_sv, n_chrom, mix, seed)
+    svs, chroms, chrom_len = make_svs(n_sv, n_chrom, mix, seed, chrom_style)
     with open(prefix + ".vcf", "w") as fh:
         fh.write(vcf_text(svs, chroms, chrom_len))
     g = build_graph(svs, chroms, chrom_len)
@@ -336,7 +350,7 @@ def generate(prefix, n_aln, n_sv, n_chrom, mix, seed, write_gaf=True, threads=8,
     info = {"n_sv": n_sv, "n_nodes": len(g["node_names"]), "n_edge_keys": len(g["edges"]), "tables": tab,
             "chroms": chroms, "chrom_len": chrom_len, "svs": svs}
     if write_gaf or return_gaf:
-        buf = gaf_bytes(tab, seed, 0, n_aln, threads)
+        buf = gaf_bytes(tab, seed, 0, n_aln, threads, shape)
         info["gaf_bytes"] = int(buf.size)
         if write_gaf:
             buf.tofile(prefix + ".gaf")

@@ -7,10 +7,10 @@ R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/variants; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 W=${1:-c3}
-cp svjedi-graph_amd/csrc/libsvjg_hip.so /tmp/lib_keep.so
+
 for f in build/lib_*.so; do
   n=$(basename $f .so)
-  cp $f svjedi-graph_amd/csrc/libsvjg_hip.so
+  export SVJG_HIP_LIB=$R/$f
   for d in ${DIAGS:-0}; do
     export SVJG_DIAG=$d
     timeout -k 10 200 python3 bench.py --workload $W --no-cpu-baseline --steps 10 --warmup 2 > $O/$n.d$d.json 2> $O/$n.d$d.err || { echo "$n diag $d: bench failed"; tail -3 $O/$n.d$d.err; continue; }
@@ -34,4 +34,3 @@ PY
     echo "$line" | tee -a $O/summary.txt
   done
 done
-cp /tmp/lib_keep.so svjedi-graph_amd/csrc/libsvjg_hip.so
