@@ -341,10 +341,10 @@ def main():
 def rccl_debug_capture(tmp):
     """RCCL's own account of what it set up (record algorithm / protocol / channels): NCCL_DEBUG=INFO into a file of this
     process, parsed once after the passes.  Leaves a caller's own NCCL_DEBUG settings alone."""
-    if os.environ.get("NCCL_DEBUG"):
-        return os.environ.get("NCCL_DEBUG_FILE")
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("INFO", "TRACE") and os.environ.get("NCCL_DEBUG_FILE"):
+        return os.environ["NCCL_DEBUG_FILE"]                      # (the caller logs already: read that file)
     path = os.path.join(tmp, "rccl.%h.%p.log")
-    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ["NCCL_DEBUG"] = "INFO"                             # (over a weaker setting such as VERSION / WARN as well)
     os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING,GRAPH")
     os.environ["NCCL_DEBUG_FILE"] = path
     return path
@@ -382,9 +382,10 @@ def rccl_debug_summary(path):
 def long_read_block(capi, synth, Graph, ctx, tmp, check=True):
     """Untimed for `value`: what the headline workload says nothing about — long-read shaped text (tools/svjg_synth.c: svjg_synth_gaf_long;
     the hand-made originals are tests/golden/realshape): sequencer read names, UCSC contig names of up to 23 bytes, paths long-tailed to 200
-    nodes (3 % beyond one node pass of 64), cg:Z: strings on a third of the lines; 1 M lines x 20 k mixed SVs on 8 contigs.  Classification
+    nodes (3 % beyond one node pass of 64), cg:Z: strings on a third of the lines; 3 M lines (2.2 GB, the size of the headline workload's text)
+    x 20 k mixed SVs on 8 contigs.  Classification
     only (main kernel + exact path), kernel time by HIP events: lines per second, how many lines took the exact path and why."""
-    n_lines, n_sv, seed = 1_000_000, 20_000, 20260515 + 9
+    n_lines, n_sv, seed = int(os.environ.get("SVJG_LONG_READ_LINES", 3_000_000)), 20_000, 20260515 + 9
     pre = os.path.join(tmp, "long_read")
     inf = synth.generate(pre, 0, n_sv, 8, "mixed", seed, write_gaf=False, chrom_style="ucsc")
     gaf = synth.gaf_bytes(inf["tables"], seed, 0, n_lines, threads=min(16, os.cpu_count() or 8), shape="long")

@@ -102,6 +102,7 @@ struct svjg_ctx {
     uint64_t *d_host = nullptr;      uint64_t host_cap = 0;     // offsets of the lines set aside for the host (SVJG_EXC_ASK_HOST)
     DevStatus *d_st = nullptr;
     unsigned long long *d_dbg = nullptr;
+    uint32_t *d_long = nullptr;          // LONG_WORDS words per worker of k_classify_main (ClassifyArgs::long_pre)
     DevStatus *h_stp = nullptr;          // host twin of d_st in pinned memory: the status copies are asynchronous in both directions
     DevStatus &hs() { return *h_stp; }
     uint64_t total_deferred = 0;
@@ -197,6 +198,7 @@ extern "C" void svjg_destroy(svjg_ctx *c) {
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->comm) ncclCommDestroy(c->comm);
     free_graph(c);
+    hipFree(c->d_long);
     hipFree(c->d_gaf); hipFree(c->d_deferred); hipFree(c->d_recs); hipFree(c->d_host); hipFree(c->d_st); hipFree(c->d_logfact);
     hipFree(c->d_bsum); hipFree(c->d_maxn); hipFree(c->d_rows); hipFree(c->d_run_in);
     for (auto &r : c->run) {
@@ -457,6 +459,7 @@ static void main_launch_setup(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_
         const int by_lds = (int)((160u * 1024u) / ((lds + LDS_GRANULE - 1) / LDS_GRANULE * LDS_GRANULE));
         if (by_lds >= 1 && occ > by_lds) occ = by_lds;
         c->occ_main = occ;
+        hipFree(c->d_long); c->d_long = nullptr;
 #ifdef SVJG_ABLATE
         { const char *oc = getenv("SVJG_OCC"); fprintf(stderr, "[svjg diag] occupancy API: %d workgroups of %u threads per CU (LDS %zu)\n", occ, WG, lds); if (oc && atoi(oc) > 0) c->occ_main = atoi(oc); }
 #endif
@@ -466,6 +469,8 @@ static void main_launch_setup(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_
     // A worker's first chunk is most of an even share, fixed; what is left goes in small chunks to whoever is free next
     // (svjg_kernels.h: the workers of a CU do not run equally fast).  Inputs too small for that: even shares of at least a stripe.
     const uint64_t full = (uint64_t)c->n_cu * (uint64_t)c->occ_main;
+    if (!c->d_long && hipMalloc((void **)&c->d_long, full * LONG_WORDS * sizeof(uint32_t)) != hipSuccess) c->d_long = nullptr;   // (checked by the callers: a launch without it is refused)
+    a.long_pre = c->d_long;
     const uint64_t share = (n + full - 1) / full;
     uint64_t region = (share + 15) & ~15ull;
     a.small = 0;
@@ -498,6 +503,7 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         uint32_t grid = 0;
         size_t lds = 0;
         main_launch_setup(c, begin, end, base_offset, want_hits, a, grid, lds);
+        if (!a.long_pre) { c->err = "no memory for the workers' scratch words"; return SVJG_E_NOMEM; }
 #ifdef SVJG_TIMING
         if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
 #endif
@@ -1043,6 +1049,7 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         uint32_t grid = 0;
         size_t lds = 0;
         main_launch_setup(c, 0, n, base_offset, 0, a, grid, lds);
+        if (!a.long_pre) { c->err = "no memory for the workers' scratch words"; return SVJG_E_NOMEM; }
         a.st = d_st; a.counts = r.counts;
         HIPCHK(c, hipEventRecord(r.ev[0], c->stream));
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);

@@ -43,9 +43,12 @@ constexpr uint32_t KMAX = 64;                    // path nodes of one node pass 
 // A line of more than KMAX nodes — up to KLONG, what the stripe's list of marks and the 8-bit node count of a line's record hold — is
 // walked in sub-passes of 64 nodes that overlap by one (the step into the next sub-pass's first node is that sub-pass's own), twice:
 // once to learn the path's total length (the right-hand overlap test needs it, filter-alignments.py:271) and that its ids rise or
-// fall all the way or, where they turn, that no name comes twice (then list.index is the position itself), once to count.  A long
-// line that does come back to a node takes the exact path.
+// fall all the way or, where they turn, whether a name comes twice, once to count.  Where no name comes twice list.index is the position
+// itself; where one does, sweep 1 takes every node's first occurrence over the WHOLE line (the ids of all nodes wait in LDS, the running
+// path lengths in a few words of global memory of the worker's own).
 constexpr uint32_t KLONG = CAP_O < 255u ? CAP_O : 255u;
+constexpr uint32_t LONG_WORDS = 256;             // per worker, in global memory: the running path length behind every node of a long line (ClassifyArgs::long_pre)
+static_assert(KLONG <= LONG_WORDS && KLONG * 4 <= TEXT / 8 + 16, "a long line's per-node words fit their places");
 constexpr uint32_t LRW = MAXL;                   // lines per round
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
@@ -108,6 +111,7 @@ struct ClassifyArgs {
     uint64_t *host_lines; uint64_t host_cap;
     DevStatus *st;
     unsigned long long *dbg;             // measurement only (SVJG_DIAG & 16): per-phase cycle sums of lane 0 of every worker
+    uint32_t *long_pre;                  // LONG_WORDS words per worker: running path length behind every node of a long line (written in sweep 0, read in sweep 1 by a line that comes back to a node)
 };
 
 // (the exact-path kernels look for a line's end with these)
@@ -955,25 +959,33 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t idl = id, idr = nxv >> 1;
                 uint32_t f = lane;
                 const uint32_t dir = idr > id ? 1u : idr < id ? 2u : 0u;
-                bool l_dup = false;
+                bool l_dup = false, l_fail = false;
                 if (RARELY(lsub)) {
                     // -- a sub-pass of a long line: the path's length in front of it and its total come from the sub-passes before;
-                    //    sweep 0 only measures (total length, no name twice, every name known), sweep 1 counts --
+                    //    sweep 0 only measures (total length, does a name come twice, is every name known), sweep 1 counts --
                     pre = gsum + lS; tot = lTOT;
-                    lS += rdlane(gsum, (lsub & 0x10000u) ? n_pass - 1u : n_pass - 2u);   // (the last node of a sub-pass that is not the last is the next one's first)
+                    {
+                        const uint32_t inc = rdlane(gsum, (lsub & 0x10000u) ? n_pass - 1u : n_pass - 2u);   // (the last node of a sub-pass that is not the last is the next one's first)
+                        l_fail = lS + inc < lS;                          // (a path of 4 Gbp and more: the sums here are 32 bits wide)
+                        lS += inc;
+                    }
                     if (!(lsub & 0x100u)) {
                         // Does a name come twice?  While the ids rise (or fall) all the way, no.  Once they turn, every node is held against
                         // the nodes of the sub-passes before it (their ids wait where the tab bitmap was: the line phase is over) and, further
-                        // down, against those of its own sub-pass (the search every pass has for lines whose ids turn).
+                        // down, against those of its own sub-pass (the search every pass has for lines whose ids turn).  lD0: 1 / 2 the ids
+                        // rise / fall, 3 they turn, 4 a name comes twice (sweep 1 then looks every first occurrence up).
                         const uint32_t t63 = ((lsub & 0xFFu) - 1u) * 63u;
                         uint32_t *IDS = tbm;
                         if (t63 == 0u) lD0 = rdlane(dir, 0);
-                        if (lD0 != 3u && (step_m & (m_ne(dir, lD0) | m_eq(dir, 0u))) != 0ull) lD0 = 3u;
-                        if (live) IDS[t63 + lane] = id;
+                        if (lD0 < 3u && (step_m & (m_ne(dir, lD0) | m_eq(dir, 0u))) != 0ull) lD0 = 3u;
+                        if (live) {
+                            IDS[t63 + lane] = id | (oribit << 31);
+                            a.long_pre[(size_t)blockIdx.x * LONG_WORDS + t63 + lane] = pre;
+                        }
                         if (lD0 == 3u) {
                             wave_sync();
                             wmask d = 0;
-                            for (uint32_t m = 0; m < t63; ++m) d |= m_eq(id, IDS[m]);
+                            for (uint32_t m = 0; m < t63; ++m) d |= m_eq(id, IDS[m] & 0x00FFFFFFu);
                             l_dup = (d & live_m) != 0ull;
                         }
                     }
@@ -999,13 +1011,15 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 }
                 const bool revisits = m_ne(f, lane) != 0;                // wave-uniform: some line of the pass comes back to a node
                 if (RARELY(lsub) && !(lsub & 0x100u)) {
-                    // sweep 0 of a long line ends here: a name the table does not hold (its record says so already) or a name that comes
-                    // twice -> the exact path; else on to the next sub-pass, or to sweep 1 with the path's total length
-                    if (live_m == 0ull || revisits || l_dup) {
+                    // sweep 0 of a long line ends here: a name the table does not hold (its record says so already) -> the exact path; else on
+                    // to the next sub-pass, or to sweep 1 with the path's total length
+                    if (live_m == 0ull || l_fail) {
                         if (live_m != 0ull) { if (lane == 0) ((uint32_t *)&RL[i0])[2] = (rdlane(meta, 0) & 0x00FFFFFFu) | ((ST_DEFER + DC_LONG_PATH) << 24); wave_sync(); }
                         ++i0; lsub = 0;
-                    } else if (lsub & 0x10000u) { lTOT = lS; lS = 0; lsub = 0x101u; }
-                    else ++lsub;
+                        continue;
+                    }
+                    if (revisits || l_dup) lD0 = 4u;
+                    if (lsub & 0x10000u) { lTOT = lS; lS = 0; lsub = 0x101u; } else ++lsub;
                     continue;
                 }
                 // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
@@ -1018,6 +1032,25 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     pre_l = (uint32_t)__shfl((int)pre, (int)fl);
                     pre_rx = (uint32_t)__shfl((int)pre, (int)((fr - 1u) & 63u));
                     orl = (uint32_t)__shfl((int)oribit, (int)fl); orr = (uint32_t)__shfl((int)oribit, (int)(fr & 63u));
+                }
+                if (RARELY(lsub) && lD0 == 4u) {
+                    // sweep 1 of a long line that comes back to a node: every node's first occurrence over the WHOLE line (list.index), its
+                    // orientation there and the path length in front of it — the ids of all nodes wait in LDS, the running lengths in the
+                    // worker's words of global memory (written in sweep 0 by this wave; read past the L1)
+                    const uint32_t t63 = ((lsub & 0xFFu) - 1u) * 63u, K = rdlane(kall, i0), upto = K < t63 + 64u ? K : t63 + 64u;
+                    const uint32_t *IDS = tbm;
+                    const uint32_t jg = t63 + lane;
+                    uint32_t fg = jg;
+                    for (uint32_t m = 0; m < upto; ++m) { const uint32_t w = IDS[m] & 0x00FFFFFFu; if (w == id && m < fg) fg = m; }
+                    const uint32_t fgr = lane_above(fg);
+                    moved_m = step_m & (m_ne(fg, jg) | m_ne(fgr, jg + 1u));
+                    pre_l = pre; pre_rx = pre; orl = oribit; orr = nxv & 1u; fr = lane + 1u;
+                    if (in_mask(moved_m)) {
+                        const uint32_t *P = a.long_pre + (size_t)blockIdx.x * LONG_WORDS;
+                        pre_l = __hip_atomic_load(P + fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pre_rx = fgr ? __hip_atomic_load(P + fgr - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                        orl = IDS[fg] >> 31; orr = IDS[fgr] >> 31;
+                    }
                 }
                 // overlap test of the step (a lane without a step fails it); then the link is looked for among the (up to four)
                 // that sit in the left node's record — straight selects, no branches —; the link table is asked only if it is not
@@ -1190,9 +1223,17 @@ __device__ inline uint64_t slow_n_def(const ClassifyArgs &a, uint64_t n_def, uin
     const uint64_t n = a.st->n_deferred;
     return (n > lo && n <= hi) ? n : 0;
 }
+// (r04) The per-node results — strand of the name's first occurrence, id, get_node_len or the exception it raises — are kept per lane in
+// LDS (SLOW_LANE_NODES nodes a line, the lanes of the wave interleaved: no bank conflicts) and every link adds up what is there, as the
+// one-wave-per-line kernel does (svjg_line.h: slow_wave_phase1 / phase2 with one lane): O(k) name resolutions a line instead of O(k^2).
+// A path of more nodes runs through slow_line as before.
+constexpr uint32_t SLOW_LANE_NODES = 12;
 __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint64_t n_def_arg, uint64_t lo, uint64_t hi) {
     const uint64_t n_def = slow_n_def(a, n_def_arg, lo, hi);
     __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LANE_LDS];
+    __shared__ int64_t c_len[SLOW_LANE_NODES * SLOW_TPB];
+    __shared__ uint32_t c_id[SLOW_LANE_NODES * SLOW_TPB];
+    __shared__ uint8_t c_rc[SLOW_LANE_NODES * SLOW_TPB], c_strand[SLOW_LANE_NODES * SLOW_TPB];
     const uint32_t lane = threadIdx.x;
     for (uint64_t b0 = (uint64_t)blockIdx.x * SLOW_TPB; b0 < n_def; b0 += (uint64_t)gridDim.x * SLOW_TPB) {
         const bool have = b0 + lane < n_def;
@@ -1224,7 +1265,17 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
             int rc;
             if (staged) {
                 typedef const __attribute__((address_space(3))) uint8_t *lds_text;
-                rc = slow_line(a.g, (lds_text)(stage + off), s - a0, s - a0 + (e - s), em);
+                const lds_text t = (lds_text)(stage + off);
+                SlowLine ln;
+                rc = slow_prologue(t, s - a0, s - a0 + (e - s), ln);
+                if (!rc && ln.k >= 2) {
+                    if (ln.k <= SLOW_LANE_NODES) {
+                        NodeScratch ns{c_id + lane, c_len + lane, c_rc + lane, c_strand + lane, SLOW_LANE_NODES, SLOW_TPB};
+                        uint64_t order = 0;
+                        rc = slow_wave_phase1(a.g, t, ln, ns, 0u, 1u, &order);
+                        if (!rc) rc = slow_wave_phase2(a.g, ln, ns, em, 0u, 1u, &order);
+                    } else rc = slow_line(a.g, t, s - a0, s - a0 + (e - s), em);
+                }
             } else rc = slow_line(a.g, a.gaf, s, e, em);
             if (rc) report_line(a, a.base_offset + s, rc);
         }
@@ -1244,6 +1295,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
     __shared__ int64_t n_len[SLOW_NODES];
     __shared__ uint32_t n_id[SLOW_NODES];
     __shared__ uint8_t n_rc[SLOW_NODES], n_strand[SLOW_NODES];
+    __shared__ uint32_t n_piece[SLOW_NODES];                           // the path's pieces: start | length << 16 (svjg_line.h: strand_of_pieces)
     const uint32_t lane = threadIdx.x;
     for (uint64_t b = blockIdx.x; b < n_def; b += gridDim.x) {
         const uint64_t s = a.deferred[b];
@@ -1283,8 +1335,35 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
             if (!rc && ln.k >= 2) {
                 if (ln.k <= SLOW_NODES) {
                     NodeScratch ns{n_id, n_len, n_rc, n_strand, SLOW_NODES};
+                    // the table of the path's pieces, 64 bytes of the path per step: a piece starts at a byte that is no separator and
+                    // has one (or the path's start) in front of it; its length: up to the separator(s) in front of the next piece
+                    {
+                        const uint8_t sep1 = ln.oriented ? '<' : ',', sep2 = ln.oriented ? '>' : ',';
+                        uint32_t run = 0;
+                        for (uint64_t base = ln.ps; base < ln.pe; base += 64) {
+                            const uint64_t q = base + lane;
+                            bool st = false;
+                            if (q < ln.pe) {
+                                const uint8_t c = t[q], pc = q > ln.ps ? (uint8_t)t[q - 1] : sep1;
+                                st = c != sep1 && c != sep2 && (pc == sep1 || pc == sep2);
+                            }
+                            const unsigned long long m = __ballot(st);
+                            if (st) { const uint32_t i = run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); if (i < SLOW_NODES) n_piece[i] = (uint32_t)q; }
+                            run += (uint32_t)__popcll(m);
+                        }
+                        __syncthreads();
+                        for (uint32_t i = lane; i < ln.k; i += 64) {
+                            const uint32_t s0 = n_piece[i];
+                            uint32_t e0 = i + 1 < ln.k ? n_piece[i + 1] - 1u : (uint32_t)ln.pe;
+                            while (e0 > s0 && ((uint8_t)t[e0 - 1] == sep1 || (uint8_t)t[e0 - 1] == sep2)) --e0;
+                            n_len[i] = (int64_t)(e0 - s0);                   // (kept aside: the starts are still being read by the neighbours)
+                        }
+                        __syncthreads();
+                        for (uint32_t i = lane; i < ln.k; i += 64) n_piece[i] |= (uint32_t)n_len[i] << 16;
+                        __syncthreads();
+                    }
                     // (the call fills `order`: result and order are separate statements, not two arguments of one call)
-                    const int r1 = slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order);
+                    const int r1 = slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order, n_piece);
                     rc = wave_min(r1, order);
                     __syncthreads();
                     if (!rc) { const int r2 = slow_wave_phase2(a.g, ln, ns, em, lane, 64u, &order); rc = wave_min(r2, order); }

@@ -348,6 +348,31 @@ SVJG_HD int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &stran
     return SVJG_EXC_INDEX_ERROR;                                  // unreachable: the name is part of the path
 }
 
+// The same through a table of the path's pieces (the maximal runs of bytes between its separators: '<' '>' of an oriented path, ',' of
+// an unoriented one; pos[i] = start | length << 16, offsets below 65536): a node name holds none of its path's separators, so an
+// occurrence lies inside ONE piece, and the first occurrence is the first piece — in order — that holds the name, at its first offset.
+// Compared from the name's end (names of one path differ in their coordinates).  O(pieces) instead of O(bytes of the path) per name:
+// what makes a path of hundreds of nodes affordable for the one-wave-per-line kernel.
+template <class P>
+SVJG_HD int strand_of_pieces(P t, uint64_t ps, const uint32_t *pos, uint32_t n_pieces, NameRef nm, uint32_t &strand) {
+    const uint64_t n = nm.e - nm.s;
+    if (n == 0) return SVJG_EXC_VALUE_ERROR;                      // str.split("")
+    for (uint32_t i = 0; i < n_pieces; ++i) {
+        const uint64_t a = pos[i] & 0xFFFFu, L = pos[i] >> 16;
+        if (L < n) continue;
+        for (uint64_t q = a; q + n <= a + L; ++q) {
+            uint64_t b = n;
+            while (b && t[q + b - 1] == t[nm.s + b - 1]) --b;
+            if (b == 0) {
+                if (q == ps) return SVJG_EXC_INDEX_ERROR;         // ""[-1]
+                strand = t[q - 1] == '>' ? 0u : 1u;
+                return 0;
+            }
+        }
+    }
+    return SVJG_EXC_INDEX_ERROR;                                  // unreachable: the name is part of the path
+}
+
 // The per-line part of the exact routine (filter-alignments.py:184-198 read_gaf_line, :351-373 extract_nodes): columns,
 // the nine int() columns, the id:f: tag, the path column and its node count.  0 or the exception class.
 struct SlowLine { uint64_t ps, pe; bool oriented; uint32_t k; int64_t Tlen, Ts, Te; };
@@ -393,21 +418,38 @@ SVJG_HD int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
 // Per-node scratch (LDS in k_classify_slow_wave, plain arrays in tests/hostsim): what the reference recomputes for every
 // link is kept per node.  phase 1: lane l takes the nodes l (mod nlanes): strand of the name (str.split quirk), node id,
 // get_node_len or the exception it raises.  phase 2 (after a barrier): lane l takes the links l (mod nlanes).
-struct NodeScratch { uint32_t *id; int64_t *len; uint8_t *rc; uint8_t *strand; uint32_t cap; };
+// stride: node j's entries sit at index j * stride (1: one line per array; 64: the lanes of a wave interleaved, one line per lane)
+struct NodeScratch { uint32_t *id; int64_t *len; uint8_t *rc; uint8_t *strand; uint32_t cap; uint32_t stride = 1; };
 
+// pieces: table of the path's pieces (strand_of_pieces), or nullptr: the path is searched byte by byte
 template <class P>
-SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeScratch &ns, uint32_t lane, uint32_t nlanes, uint64_t *order) {
+SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeScratch &ns, uint32_t lane, uint32_t nlanes, uint64_t *order,
+                             const uint32_t *pieces = nullptr) {
     NameRef nm{0, 0}; uint64_t pos = ln.ps; bool more = true;
+    if (pieces) {                                                    // node j is piece j (an unoriented path's node: the piece without its last byte)
+        for (uint32_t j = lane; j < ln.k; j += nlanes) {
+            nm.s = pieces[j] & 0xFFFFu; nm.e = nm.s + (pieces[j] >> 16) - (ln.oriented ? 0u : 1u);
+            uint32_t st = 0;
+            int rc = strand_of_pieces(t, ln.ps, pieces, ln.k, nm, st);
+            if (rc) { *order = (1ull << 32) | j; return rc; }
+            int64_t l1 = 0;
+            ns.strand[j * ns.stride] = (uint8_t)st;
+            ns.id[j * ns.stride] = resolve_name(g, t, nm, nullptr);
+            ns.rc[j * ns.stride] = (uint8_t)generic_node_len(g, t, nm, l1);
+            ns.len[j * ns.stride] = l1;
+        }
+        return 0;
+    }
     for (uint32_t j = 0; j < lane && more; ++j) more = next_node(t, ln.pe, ln.oriented, pos, nm);
     for (uint32_t j = lane; more && next_node(t, ln.pe, ln.oriented, pos, nm); j += nlanes) {
         uint32_t st = 0;
         int rc = strand_of(t, ln.ps, ln.pe, nm, st);                 // get_aln_links walks every node first (:203-209)
         if (rc) { *order = (1ull << 32) | j; return rc; }
         int64_t l1 = 0;
-        ns.strand[j] = (uint8_t)st;
-        ns.id[j] = resolve_name(g, t, nm, nullptr);
-        ns.rc[j] = (uint8_t)generic_node_len(g, t, nm, l1);
-        ns.len[j] = l1;
+        ns.strand[j * ns.stride] = (uint8_t)st;
+        ns.id[j * ns.stride] = resolve_name(g, t, nm, nullptr);
+        ns.rc[j * ns.stride] = (uint8_t)generic_node_len(g, t, nm, l1);
+        ns.len[j * ns.stride] = l1;
         NameRef skip{0, 0};
         for (uint32_t q = 1; q < nlanes && more; ++q) more = next_node(t, ln.pe, ln.oriented, pos, skip);
     }
@@ -416,22 +458,23 @@ SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeSc
 
 template <class Emit>
 SVJG_HD int slow_wave_phase2(const GraphView &g, const SlowLine &ln, const NodeScratch &ns, Emit &emit, uint32_t lane, uint32_t nlanes, uint64_t *order) {
+    const uint32_t S = ns.stride;
     for (uint32_t i = lane; i + 1 < ln.k; i += nlanes) {
-        const uint32_t lid = ns.id[i], rid = ns.id[i + 1];
+        const uint32_t lid = ns.id[i * S], rid = ns.id[(i + 1) * S];
         if (lid == NONE32 || rid == NONE32) continue;
-        const uint32_t ei = edge_find(g, lid, ns.strand[i], rid, ns.strand[i + 1]);
+        const uint32_t ei = edge_find(g, lid, ns.strand[i * S], rid, ns.strand[(i + 1) * S]);
         if (ei == NONE32) continue;
         const svjg_edge ed = g.edges[ei];
         const uint32_t nh = ed.meta >> 2;
         if (!nh) continue;
         // list.index of both names (:269-271): a name that resolves has one spelling, so equal names <=> equal ids
         uint32_t il = 0, ir = 0;
-        while (ns.id[il] != lid) ++il;
-        while (ns.id[ir] != rid) ++ir;
+        while (ns.id[il * S] != lid) ++il;
+        while (ns.id[ir * S] != rid) ++ir;
         int64_t left = 0, right = 0;
-        for (uint32_t j = 0; j <= il; ++j) { if (ns.rc[j]) { *order = (2ull << 32) | i; return ns.rc[j]; } left += ns.len[j]; }
+        for (uint32_t j = 0; j <= il; ++j) { if (ns.rc[j * S]) { *order = (2ull << 32) | i; return ns.rc[j * S]; } left += ns.len[j * S]; }
         if (g.dover_list) { *order = (2ull << 32) | i; return SVJG_EXC_TYPE_ERROR; }   // int >= list (:269), before the right sum is formed
-        for (uint32_t j = ir; j < ln.k; ++j) { if (ns.rc[j]) { *order = (2ull << 32) | i; return ns.rc[j]; } right += ns.len[j]; }
+        for (uint32_t j = ir; j < ln.k; ++j) { if (ns.rc[j * S]) { *order = (2ull << 32) | i; return ns.rc[j * S]; } right += ns.len[j * S]; }
         if (left - ln.Ts >= (int64_t)g.d_over && right - (ln.Tlen - ln.Te - 1) >= (int64_t)g.d_over)
             for (uint32_t j = 0; j < nh; ++j) { uint32_t hv = edge_hit(g, ed, j); emit(hv >> 1, hv & 1u); }
     }

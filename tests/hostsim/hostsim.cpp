@@ -53,10 +53,28 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
             if (!rc && ln.k >= 2) {
                 std::vector<uint32_t> id(ln.k); std::vector<int64_t> len(ln.k); std::vector<uint8_t> nrc(ln.k), strand(ln.k);
                 NodeScratch ns{id.data(), len.data(), nrc.data(), strand.data(), ln.k};
+                // the table of the path's pieces, as k_classify_slow_wave builds it (there 64 bytes per step); offsets relative to the line
+                // start like the kernel's staged copy (below 65536 for the lines the harness is given; longer ones: byte-by-byte search)
+                std::vector<uint32_t> pieces;
+                const uint8_t *tl = t + pos;
+                SlowLine ll = ln; ll.ps -= pos; ll.pe -= pos;
+                if (e - pos < 65536) {
+                    const uint8_t s1 = ln.oriented ? '<' : ',', s2 = ln.oriented ? '>' : ',';
+                    for (uint64_t q = ll.ps; q < ll.pe; ++q) {
+                        const uint8_t c = tl[q], pc = q > ll.ps ? tl[q - 1] : s1;
+                        if (c != s1 && c != s2 && (pc == s1 || pc == s2)) pieces.push_back((uint32_t)q);
+                    }
+                    for (size_t i = 0; i < pieces.size(); ++i) {
+                        uint32_t e0 = i + 1 < pieces.size() ? pieces[i + 1] - 1u : (uint32_t)ll.pe;
+                        while (e0 > pieces[i] && (tl[e0 - 1] == s1 || tl[e0 - 1] == s2)) --e0;
+                        pieces[i] |= (e0 - pieces[i]) << 16;
+                    }
+                    if (pieces.size() != ln.k) { *exc = 7; *err_off = pos; return SVJG_E_INPUT; }   // (harness self-check: pieces == nodes)
+                }
                 uint64_t best = ~0ull;
                 for (uint32_t lane = 0; lane < 64; ++lane) {
                     uint64_t order = 0;
-                    int r = slow_wave_phase1(v, t, ln, ns, lane, 64u, &order);
+                    int r = pieces.empty() ? slow_wave_phase1(v, t, ln, ns, lane, 64u, &order) : slow_wave_phase1(v, tl, ll, ns, lane, 64u, &order, pieces.data());
                     if (r && ((order << 3) | (uint64_t)r) < best) best = (order << 3) | (uint64_t)r;
                 }
                 if (best == ~0ull)
@@ -66,6 +84,17 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
                         if (r && ((order << 3) | (uint64_t)r) < best) best = (order << 3) | (uint64_t)r;
                     }
                 if (best != ~0ull) rc = (int)(best & 7);
+            }
+        } else if (g->flags & 32u) {                                       // harness only: one lane with its per-node results kept (k_classify_slow since r04), the lanes' entries interleaved
+            SlowLine ln;
+            rc = slow_prologue(t, pos, e, ln);
+            if (!rc && ln.k >= 2) {
+                const uint32_t S = 64, lane = (uint32_t)(*n_lines % 64);
+                std::vector<uint32_t> id((size_t)ln.k * S); std::vector<int64_t> len((size_t)ln.k * S); std::vector<uint8_t> nrc((size_t)ln.k * S), strand((size_t)ln.k * S);
+                NodeScratch ns{id.data() + lane, len.data() + lane, nrc.data() + lane, strand.data() + lane, ln.k, S};
+                uint64_t order = 0;
+                rc = slow_wave_phase1(v, t, ln, ns, 0u, 1u, &order);
+                if (!rc) rc = slow_wave_phase2(v, ln, ns, em, 0u, 1u, &order);
             }
         } else if (g->flags & 4u) {                                        // harness only: 64 cooperating lanes, as k_classify_slow_wave runs a line with too many nodes
             uint64_t best = ~0ull;

@@ -783,8 +783,8 @@ def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
             c = l.split(b"\t"); c[7] = b" " + c[7]; l = b"\t".join(c)
         out.append(l)
     # one very long path: walk a chromosome's reference nodes forwards and backwards
-    # one very long path: a chromosome's reference nodes forwards, then one step back (a path of more than 64 nodes whose ids turn: the
-    # exact path finds the names' first occurrences), and the same without the turn (stays in the main kernel)
+    # very long paths: a chromosome's reference nodes forwards, then one step back (more than 64 nodes and a name that comes twice), and the
+    # same without the turn: both stay in the main kernel since r04 (sub-passes; first occurrences over the whole line)
     names = [n for n in g.node_names if n.startswith("chr1:") and "." not in n.split(":")[1]][:70]
     for tag, walk in ((b"turn", names + [names[-2]]), (b"straight", names)):
         nlen = [int(n.split("-")[1]) - int(n.split(":")[1].split("-")[0]) + 1 for n in walk]
@@ -797,19 +797,20 @@ def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
     assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
     st, cause = ctx.stats(), ctx.defer_causes()
     assert st["n_lines"] == n_lines and st["n_deferred"] == sum(cause.values())
-    assert cause["long_path"] == 1 and cause["whole_stripe"] == 0 and cause["node_name"] == 0       # (the path that turns; the straight one of 70 nodes stays)
+    assert cause["long_path"] == 0 and cause["whole_stripe"] == 0 and cause["node_name"] == 0
     # a tagged line, and at most the two lines that share a 64-byte span with its tag (one of which may be a line with a blank)
     assert len(blank) - 8 <= cause["columns"] <= len(blank)
     assert len(tagged) <= cause["id_tag_filter"] <= 2 * len(tagged) + 2
-    assert st["n_deferred"] <= 1 + len(blank) + 2 * len(tagged) + 2
+    assert st["n_deferred"] <= len(blank) + 2 * len(tagged) + 2
 
 
 def test_paths_of_65_to_216_nodes(ctx, tmp_path):
     """Paths longer than one node pass (64 nodes) stay in the main kernel up to what a stripe's list of marks holds (216): sub-passes of
-    64 nodes that overlap by one, walked twice (total length and monotone ids first, then the counts).  Lengths around every sub-pass
-    boundary, both directions, through insertion nodes, with margins that fail the overlap test at either end; a long path whose ids
-    turn (a node revisited mid-way, at a sub-pass boundary, right at the end) takes the exact path.  Counts are the C oracle's and
-    the JSON text the Python oracle's."""
+    64 nodes that overlap by one, walked twice (total length and "does a name come twice" first, then the counts).  Lengths around every
+    sub-pass boundary, both directions, through insertion nodes, with margins that fail the overlap test at either end; paths whose ids
+    turn without a name coming twice; paths that do come back to a node — mid-way, at a sub-pass boundary, right at the end, a whole
+    stretch walked back the other way round (the reference takes name, strand and position of the FIRST occurrence: list.index /
+    str.split) —: none takes the exact path.  Counts are the C oracle's and the JSON text the Python oracle's."""
     import synth
     from svjg import capi
     from svjg.graph import Graph
@@ -857,10 +858,18 @@ def test_paths_of_65_to_216_nodes(ctx, tmp_path):
         for rev in (False, True):
             lines.append(line(f"k{k}r{int(rev)}", w, rev))
             lines.append(line(f"k{k}r{int(rev)}m", w, rev, ts=nlen(w[-1 if rev else 0]) + 3, te_back=nlen(w[0 if rev else -1]) + 2))   # the first and last step fail the overlap test
-    for k, at in ((130, 64), (130, 63), (130, 100), (70, 69), (200, 127), (66, 1)):                     # ids that turn: node `at` - 1 comes again behind node `at`
+    for k, at in ((130, 64), (130, 63), (130, 100), (70, 69), (200, 127), (66, 1)):                     # a name twice: node `at` - 1 comes again behind node `at`
         w = walk(k, int(rng.integers(0, 300)))
         w = w[:at + 1] + [w[at - 1]] + w[at + 1:]
-        lines.append(line(f"turn{k}at{at}", w))
+        for rev in (False, True):
+            lines.append(line(f"turn{k}at{at}r{int(rev)}", w, rev))
+    for fwd, back in ((70, 30), (100, 60), (64, 64), (130, 80), (63, 5)):                                  # a stretch walked back the other way round
+        w = walk(fwd, int(rng.integers(0, 300)))
+        ww = w + list(reversed(w))[:back]
+        ori = [">"] * fwd + ["<"] * back
+        for rev in (False, True):
+            lines.append(line(f"fold{fwd}b{back}r{int(rev)}", ww, rev, ori=ori))
+            lines.append(line(f"fold{fwd}b{back}r{int(rev)}m", ww, rev, ori=ori, ts=nlen(ww[-1 if rev else 0]) + 3, te_back=nlen(ww[0 if rev else -1]) + 2))
     # long paths whose ids turn although no name comes twice (a jump back to an earlier stretch of the chromosome, as over a translocation or
     # across an inverted stretch): they stay in the main kernel — sweep 0 holds every node against the nodes before it —; the turn lies in the
     # first sub-pass, at its last node, at the second sub-pass's first nodes, in the second
@@ -877,7 +886,7 @@ def test_paths_of_65_to_216_nodes(ctx, tmp_path):
     ctx.classify(np.frombuffer(data, dtype=np.uint8), want_hits=True)
     assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 10000
     st, cause = ctx.stats(), ctx.defer_causes()
-    assert st["n_lines"] == n_lines and cause["long_path"] == 6 and cause["whole_stripe"] == 0 and cause["node_name"] == 0, (st, cause)
+    assert st["n_lines"] == n_lines and cause["long_path"] == 0 and cause["whole_stripe"] == 0 and cause["node_name"] == 0, (st, cause)
     capi.write_informative_json(str(tmp_path / "o.json"), np.frombuffer(data, dtype=np.uint8), ctx.hits(), g.sv_ids)
     assert open(tmp_path / "o.json").read() == O.dump_informative(O.classify(data.decode().splitlines(True), edges, alt))
     # the long lines alone carry hits (a walk crosses an SV at almost every step)

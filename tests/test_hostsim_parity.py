@@ -20,7 +20,7 @@ def _as_dict(graph, counts):
     return {graph.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(graph.n_slots) if counts[i].sum()}
 
 
-@pytest.mark.parametrize("tables,wave", [(True, 0), (False, 0), (True, 1), (True, 2)], ids=["name_table", "sorted_table", "wave_lanes", "wave_two_phase"])
+@pytest.mark.parametrize("tables,wave", [(True, 0), (False, 0), (True, 1), (True, 2), (True, 3)], ids=["name_table", "sorted_table", "wave_lanes", "wave_two_phase", "lane_cached"])
 @pytest.mark.parametrize("name", QUIRKS)
 def test_quirks(golden, name, tables, wave):
     q = f"{golden}/quirks"
@@ -40,7 +40,7 @@ def test_quirks(golden, name, tables, wave):
 DOVER = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "dover")) if f.endswith(".gaf"))
 
 
-@pytest.mark.parametrize("wave", [0, 1, 2], ids=["one_lane", "wave_lanes", "wave_two_phase"])
+@pytest.mark.parametrize("wave", [0, 1, 2, 3], ids=["one_lane", "wave_lanes", "wave_two_phase", "lane_cached"])
 @pytest.mark.parametrize("name", DOVER)
 def test_dover_flag(golden, name, wave):
     """golden/dover (the reference run with -O): the exact routine under SVJG_GRAPH_DOVER_LIST raises TypeError where the reference
@@ -60,7 +60,7 @@ def test_dover_flag(golden, name, wave):
         assert type(ei.value).__name__ == man["error"]
 
 
-@pytest.mark.parametrize("tables,wave", [(True, 0), (True, 2)], ids=["name_table", "wave_two_phase"])
+@pytest.mark.parametrize("tables,wave", [(True, 0), (True, 2), (True, 3)], ids=["name_table", "wave_two_phase", "lane_cached"])
 def test_realshape_lines(golden, tables, wave):
     """the exact per-line routine on the lines shaped like real minigraph output (paths of up to 300 nodes, kilobyte tags)"""
     import gzip

@@ -10,11 +10,11 @@ WL="${*:-c3 c4shard}"
 export TMPDIR=/tmp
 cd $R
 python3 bench.py --workload c3 > $O/bench_c3.json 2> $O/bench.err
-python3 bench.py --workload c2 --no-cpu-baseline > $O/bench_c2.json 2>> $O/bench.err
-python3 bench.py --workload c4shard --no-cpu-baseline > $O/bench_c4shard.json 2>> $O/bench.err
-SVJG_BENCH_SYNC=1 python3 bench.py --workload c3 --no-cpu-baseline --no-e2e > $O/bench_c3_one_pass_at_a_time.json 2>> $O/bench.err
+python3 bench.py --workload c2 --no-cpu-baseline --no-north-star --no-long-read > $O/bench_c2.json 2>> $O/bench.err
+python3 bench.py --workload c4shard --no-cpu-baseline --no-north-star --no-long-read > $O/bench_c4shard.json 2>> $O/bench.err
+SVJG_BENCH_SYNC=1 python3 bench.py --workload c3 --no-cpu-baseline --no-e2e --no-north-star --no-long-read > $O/bench_c3_one_pass_at_a_time.json 2>> $O/bench.err
 for W in $WL; do
-  B="python3 bench.py --workload $W --no-cpu-baseline --no-e2e --no-north-star"
+  B="python3 bench.py --workload $W --no-cpu-baseline --no-e2e --no-north-star --no-long-read"
   P=$O/raw_$W; mkdir -p $P
   echo "== $W: kernel trace" 
   rocprofv3 --kernel-trace --stats -d $P/kt -o k --output-format csv -- $B --steps 10 --warmup 2 > $P/kt.log 2>&1
@@ -35,5 +35,6 @@ for W in $WL; do
   done
   rm -rf $P
 done
+bash tools/resource_usage.sh > $O/resource_usage.txt 2>&1 || true
 python3 tools/mk_traffic.py $O $WL
 ls -la $O
