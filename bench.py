@@ -128,8 +128,8 @@ def timed_steps(ctxs, steps, warmup, min_support=3, err=0.00005, outer_barrier=N
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)          # (a step is ~1.3 ms: 200 of them behind 20 untimed ones give the clocks time to settle)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--aln", type=int, default=0, help="override alignments per rank")
     ap.add_argument("--svs", type=int, default=0, help="override the number of SVs (experiments only)")
@@ -246,10 +246,10 @@ def main():
     st = ctx.stats()
     counts = ctx.counts()
     gt, pl, raw, done = out
-    copy_gbs = None
+    copy_gbs = read_gbs = None
     if rank == 0 and hasattr(ctx, "copy_rate"):
         try:
-            copy_gbs = ctx.copy_rate(1 << 31)                    # 2 GB read + 2 GB written, in this process, on this GPU
+            copy_gbs, read_gbs = ctx.copy_rate(1 << 31)          # 2 GB read + 2 GB written / 2 GB read, in this process, on this GPU
         except Exception as e:                                   # noqa: BLE001 (a measurement beside the point of the run)
             sys.stderr.write(f"[bench] copy rate not measured: {e}\n")
     ns = None
@@ -294,6 +294,8 @@ def main():
         if copy_gbs:
             res["roofline"]["measured_copy_gbs"] = copy_gbs      # bytes read + written per second by a plain copy kernel in this process
             res["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+            res["roofline"]["measured_read_gbs"] = read_gbs      # bytes per second of a kernel that only reads (what this read-dominated path could at best stream at)
+            res["roofline"]["frac_of_measured_read"] = achieved / read_gbs if read_gbs else None
         if ns is not None:
             res["north_star"] = ns
         if lr is not None:

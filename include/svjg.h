@@ -278,9 +278,10 @@ void svjg_vcf_free(svjg_vcf *v);
 /* ---- measurement hooks (bench.py): HIP-event time of the kernels of the last classify / genotype ---- */
 int svjg_last_kernel_ms(svjg_ctx *ctx, float *classify_main_ms, float *classify_slow_ms, float *genotype_ms);
 int svjg_sync(svjg_ctx *ctx);
-/* what a plain device-to-device copy of n_bytes reaches on this GPU right now (16 B per lane, grid-stride; best of three):
- * bytes read + bytes written per second, in GB/s — the measured ceiling bench.py reports beside the 8 TB/s of the data sheet */
-int svjg_copy_rate(svjg_ctx *ctx, uint64_t n_bytes, double *gb_per_s);
+/* what plain streams of n_bytes reach on this GPU right now (16 B per lane, non-temporal, four in flight per lane; best of three), in
+ * GB/s: copy = a device-to-device copy, bytes read + bytes written per second; read = a kernel that only reads (and folds what it read
+ * into one word) — the measured ceilings bench.py reports beside the 8 TB/s of the data sheet.  Either pointer may be NULL. */
+int svjg_copy_rate(svjg_ctx *ctx, uint64_t n_bytes, double *copy_gb_per_s, double *read_gb_per_s);
 
 #ifdef __cplusplus
 }

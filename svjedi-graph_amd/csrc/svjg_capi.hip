@@ -1199,27 +1199,33 @@ extern "C" int svjg_last_kernel_ms(svjg_ctx *c, float *m, float *s, float *g) {
     return 0;
 }
 
-extern "C" int svjg_copy_rate(svjg_ctx *c, uint64_t n_bytes, double *gb_per_s) {
-    if (!c || !gb_per_s || n_bytes < 65536) return SVJG_E_ARG;
+extern "C" int svjg_copy_rate(svjg_ctx *c, uint64_t n_bytes, double *copy_gb_per_s, double *read_gb_per_s) {
+    if (!c || n_bytes < (1u << 20)) return SVJG_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    n_bytes &= ~15ull;
+    n_bytes &= ~4095ull;
     uint4 *src = nullptr, *dst = nullptr;
     if (hipMalloc((void **)&src, n_bytes) != hipSuccess || hipMalloc((void **)&dst, n_bytes) != hipSuccess) { hipFree(src); c->err = "svjg_copy_rate: no memory for the two buffers"; return SVJG_E_NOMEM; }
     struct Free { uint4 *a, *b; ~Free() { hipFree(a); hipFree(b); } } fr{src, dst};
     HIPCHK(c, hipMemsetAsync(src, 0x5A, n_bytes, c->stream));
     HIPCHK(c, hipMemsetAsync(dst, 0, n_bytes, c->stream));
-    float best = 0;
-    for (int i = 0; i < 4; ++i) {                              // (the first run warms up)
-        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-        hipLaunchKernelGGL(k_copy16, dim3((uint32_t)c->n_cu * 8), dim3(TPB), 0, c->stream, dst, src, n_bytes / 16);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
-        if (i && (best == 0 || ms < best)) best = ms;
+    const uint32_t grid = (uint32_t)c->n_cu * 16;
+    for (int what = 0; what < 2; ++what) {
+        double *out = what ? read_gb_per_s : copy_gb_per_s;
+        if (!out) continue;
+        float best = 0;
+        for (int i = 0; i < 4; ++i) {                          // (the first run warms up)
+            HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+            if (what) hipLaunchKernelGGL(k_read16, dim3(grid), dim3(TPB), 0, c->stream, dst, src, n_bytes / 16);
+            else hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(TPB), 0, c->stream, dst, src, n_bytes / 16);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+            if (i && (best == 0 || ms < best)) best = ms;
+        }
+        *out = best > 0 ? (what ? 1.0 : 2.0) * (double)n_bytes / (best * 1e-3) / 1e9 : 0.0;
     }
-    *gb_per_s = best > 0 ? 2.0 * (double)n_bytes / (best * 1e-3) / 1e9 : 0.0;
     return 0;
 }
 

@@ -1163,9 +1163,31 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
 #endif
 }
 
-// svjg_copy_rate: a plain copy, 16 bytes per lane, grid-stride (what the HBM gives a kernel that does nothing else)
+// svjg_copy_rate: plain streams, 16 bytes per lane, non-temporal, four loads in flight per lane (what the HBM gives a kernel that does
+// nothing else): a copy, and a read that folds what it read into one word per block (written only if it is a value the data cannot make)
+typedef uint32_t svjg_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(TPB) void k_copy16(uint4 *dst, const uint4 *src, uint64_t n16) {
-    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * TPB) dst[i] = src[i];
+    const uint64_t stride = (uint64_t)gridDim.x * TPB;
+    uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const svjg_u32x4 a = __builtin_nontemporal_load((const svjg_u32x4 *)(src + i)), b = __builtin_nontemporal_load((const svjg_u32x4 *)(src + i + stride));
+        const svjg_u32x4 c = __builtin_nontemporal_load((const svjg_u32x4 *)(src + i + 2 * stride)), d = __builtin_nontemporal_load((const svjg_u32x4 *)(src + i + 3 * stride));
+        __builtin_nontemporal_store(a, (svjg_u32x4 *)(dst + i)); __builtin_nontemporal_store(b, (svjg_u32x4 *)(dst + i + stride));
+        __builtin_nontemporal_store(c, (svjg_u32x4 *)(dst + i + 2 * stride)); __builtin_nontemporal_store(d, (svjg_u32x4 *)(dst + i + 3 * stride));
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+__global__ __launch_bounds__(TPB) void k_read16(uint4 *sink, const uint4 *src, uint64_t n16) {
+    const uint64_t stride = (uint64_t)gridDim.x * TPB;
+    uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const svjg_u32x4 a = __builtin_nontemporal_load((const svjg_u32x4 *)(src + i)), b = __builtin_nontemporal_load((const svjg_u32x4 *)(src + i + stride));
+        const svjg_u32x4 c = __builtin_nontemporal_load((const svjg_u32x4 *)(src + i + 2 * stride)), d = __builtin_nontemporal_load((const svjg_u32x4 *)(src + i + 3 * stride));
+        acc ^= a.x ^ a.w ^ b.y ^ b.z ^ c.x ^ c.w ^ d.y ^ d.z;
+    }
+    for (; i < n16; i += stride) acc ^= src[i].x;
+    if (acc == 0x12345677u) sink[0].x = acc;
 }
 
 // svjg_run_resident: the three things a pass starts from — zero counts (and guard words), a fresh status block, "no row lacked its

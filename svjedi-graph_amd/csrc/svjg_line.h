@@ -113,6 +113,36 @@ SVJG_HD void link_slots(uint64_t v, uint32_t seed, uint32_t mask, uint32_t &s1, 
 
 SVJG_HD bool py_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
 
+// ---- byte searches of the exact routine, eight bytes per step ---------------------------------------------------------------
+// The exact routine walks a line byte by byte; where it only LOOKS FOR a byte (the next tab, the next path separator, the next 'i' of
+// an "id:f:") the text is taken eight bytes at a time (one unaligned 64-bit read: LDS and global memory of gfx950 serve any byte
+// address) and the byte is found with the zero-byte trick, whose lowest flag is exact.  t[q, e) must be readable, nothing beyond.
+typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
+template <class P>
+SVJG_HD uint64_t ld64(P t, uint64_t q) { return *(const u64_unaligned *)(&t[q]); }
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+SVJG_HD uint64_t ld64(const __attribute__((address_space(3))) uint8_t *t, uint64_t q) { return *(const __attribute__((address_space(3))) u64_unaligned *)(t + q); }
+#endif
+SVJG_HD uint64_t eq_byte_flags(uint64_t w, uint32_t c) {            // 0x80 in the lowest byte of w that equals c (flags above it may be wrong)
+    const uint64_t x = w ^ (0x0101010101010101ull * c);
+    return (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+}
+template <class P>
+SVJG_HD uint64_t find_byte(P t, uint64_t q, uint64_t e, uint32_t c) {   // first position in [q, e) that holds c, or e
+    for (; q + 8 <= e; q += 8) { const uint64_t m = eq_byte_flags(ld64(t, q), c); if (m) return q + ((uint64_t)__builtin_ctzll(m) >> 3); }
+    for (; q < e; ++q) if ((uint32_t)(uint8_t)t[q] == c) return q;
+    return e;
+}
+template <class P>
+SVJG_HD uint64_t find_byte2(P t, uint64_t q, uint64_t e, uint32_t c1, uint32_t c2) {   // ... that holds c1 or c2
+    for (; q + 8 <= e; q += 8) {
+        const uint64_t w = ld64(t, q), m1 = eq_byte_flags(w, c1), m2 = eq_byte_flags(w, c2);
+        if (m1 | m2) { const uint64_t a = m1 ? (uint64_t)__builtin_ctzll(m1) : 64u, b = m2 ? (uint64_t)__builtin_ctzll(m2) : 64u; return q + ((a < b ? a : b) >> 3); }
+    }
+    for (; q < e; ++q) { const uint32_t c = (uint8_t)t[q]; if (c == c1 || c == c2) return q; }
+    return e;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // graph lookups
 // ---------------------------------------------------------------------------------------------------
@@ -245,10 +275,10 @@ struct NameRef { uint64_t s, e; };     // node name = t[s, e)
 template <class P>
 SVJG_HD bool next_node(P t, uint64_t pe, bool oriented, uint64_t &pos, NameRef &out) {
     uint64_t st = pos;
-    for (uint64_t q = pos; q <= pe; ++q) {
-        bool brk = q == pe || (oriented ? (t[q] == '<' || t[q] == '>') : t[q] == ',');
-        if (!brk) continue;
+    for (;;) {
+        const uint64_t q = oriented ? find_byte2(t, st, pe, '<', '>') : find_byte(t, st, pe, ',');   // the piece's end: a separator, or the path's end
         if (q > st) { out.s = st; out.e = oriented ? q : q - 1; pos = q + 1; return true; }
+        if (q >= pe) break;
         st = q + 1;
     }
     pos = pe + 1;
@@ -391,16 +421,20 @@ SVJG_HD int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
     // (str.rstrip() also takes Unicode blanks: a line that ends in a byte >= 0x80 is the host's if anything below fails on it)
     uint64_t fs[12], fe[12]; uint32_t nf = 0;
     { uint64_t st = s;
-      for (uint64_t q = s; q <= e && nf < 12; ++q)
-          if (q == e || t[q] == '\t') { fs[nf] = st; fe[nf] = q; ++nf; st = q + 1; } }
+      while (nf < 12) {
+          const uint64_t q = find_byte(t, st, e, '\t');             // (the last field ends with the line)
+          fs[nf] = st; fe[nf] = q; ++nf;
+          if (q >= e) break;
+          st = q + 1;
+      } }
     if (nf < 12) return SVJG_EXC_VALUE_ERROR;
     int64_t v[12];
     const int cols[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
     for (int j = 0; j < 9; ++j)
         if (!py_int(t, fs[cols[j]], fe[cols[j]], v[cols[j]])) return has_high(t, fs[cols[j]], fe[cols[j]]) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR;
     { uint64_t last = e;                                           // "id:f:" in line  (:193-196)
-      for (uint64_t q = s; q + 5 <= e; ++q)
-          if (t[q] == 'i' && t[q + 1] == 'd' && t[q + 2] == ':' && t[q + 3] == 'f' && t[q + 4] == ':') last = q;
+      for (uint64_t q = find_byte(t, s, e, 'i'); q + 5 <= e; q = find_byte(t, q + 1, e, 'i'))
+          if (t[q + 1] == 'd' && t[q + 2] == ':' && t[q + 3] == 'f' && t[q + 4] == ':') last = q;
       if (last != e) {
           uint64_t a = last + 5, b = a;
           while (b < e && t[b] != '\t') ++b;

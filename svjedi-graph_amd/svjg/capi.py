@@ -58,7 +58,7 @@ _SIGS = {
     "svjg_gaf_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
     "svjg_gaf_upload_part": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
     "svjg_comm_set_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    "svjg_copy_rate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double)]),
+    "svjg_copy_rate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "svjg_classify_resident": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]),
     "svjg_classify": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]),
     "svjg_gaf_upload_file": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64]),
@@ -367,10 +367,10 @@ class Context:
         self._chk(self.lib.svjg_comm_set_stream(self.h, 1 if on else 0))
 
     def copy_rate(self, n_bytes=1 << 31):
-        """GB/s (read + written) of a plain device-to-device copy on this GPU (svjg_copy_rate)"""
-        v = ctypes.c_double(0)
-        self._chk(self.lib.svjg_copy_rate(self.h, n_bytes, ctypes.byref(v)))
-        return v.value
+        """-> (GB/s read + written by a plain device-to-device copy, GB/s of a kernel that only reads) on this GPU (svjg_copy_rate)"""
+        v, r = ctypes.c_double(0), ctypes.c_double(0)
+        self._chk(self.lib.svjg_copy_rate(self.h, n_bytes, ctypes.byref(v), ctypes.byref(r)))
+        return v.value, r.value
 
     def classify_resident(self, base_offset=0, want_hits=False):
         self._chk(self.lib.svjg_classify_resident(self.h, base_offset, int(want_hits)))

@@ -1,14 +1,7 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/j7
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "quirks or fuzz or random_graphs or unicode or realshape or dover or deferral or identity_tag or paths_of_65 or long_paths or lines_longer or stripes" > gpurun_out/j7/tests.log 2>&1; tail -4 gpurun_out/j7/tests.log
-python3 - <<PY > gpurun_out/j7/long_read.txt 2>&1
-import os, sys, json, tempfile
-sys.path[:0] = [os.getcwd(), os.getcwd() + "/svjedi-graph_amd", os.getcwd() + "/tools"]
-import bench, synth
-from svjg import capi
-from svjg.graph import Graph
-ctx = capi.Context(0)
-print(json.dumps(bench.long_read_block(capi, synth, Graph, ctx, tempfile.mkdtemp(), check=True)))
-PY
-cat gpurun_out/j7/long_read.txt
-ALL_SLOW=1 python3 tools/slowpath_bench.py 0 > gpurun_out/j7/slowpath_all_slow.txt 2>&1; tail -2 gpurun_out/j7/slowpath_all_slow.txt
+mkdir -p gpurun_out/j8
+python -m pytest tests -x -q -m gpu > gpurun_out/j8/tests_all.log 2>&1; tail -5 gpurun_out/j8/tests_all.log
+ALL_SLOW=1 python3 tools/slowpath_bench.py 0 > gpurun_out/j8/slowpath_all_slow.txt 2>&1; tail -2 gpurun_out/j8/slowpath_all_slow.txt
+python3 bench.py --no-north-star > gpurun_out/j8/bench_c3.json 2> gpurun_out/j8/bench_c3.err; python3 -c "
+import json; r=json.load(open('gpurun_out/j8/bench_c3.json')); print(r['value']/1e9, r['ms_per_step'], r['kernel_ms'], r['roofline']); print(r['long_read'])"
+bash tests/fuzz_campaign.sh 20000 800 20 > gpurun_out/j8/fuzz.log 2>&1; tail -3 gpurun_out/j8/fuzz.log; cp gpurun_out/fuzz/campaign.txt gpurun_out/j8/fuzz_campaign.txt
