@@ -347,7 +347,7 @@ def rccl_debug_capture(tmp):
         return os.environ["NCCL_DEBUG_FILE"]                      # (the caller logs already: read that file)
     path = os.path.join(tmp, "rccl.%h.%p.log")
     os.environ["NCCL_DEBUG"] = "INFO"                             # (over a weaker setting such as VERSION / WARN as well)
-    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING,GRAPH")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING,ENV")   # (not COLL: that logs a line per collective call, inside the timed passes)
     os.environ["NCCL_DEBUG_FILE"] = path
     return path
 

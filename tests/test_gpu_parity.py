@@ -1407,6 +1407,34 @@ def test_fused_pass_with_many_deferred_lines_under_a_communicator(tmp_path):
         c.close()
 
 
+def test_resident_text_uploaded_in_pieces(tmp_path):
+    """svjg_gaf_upload_part (what bench.py's north_star block uses for 21.6 GB on one GPU): the text in pieces cut anywhere — inside lines
+    too — under a capacity larger than the text gives the counts of one upload; out-of-order pieces are refused.  svjg_copy_rate answers."""
+    from svjg import capi
+    pre, gaf, g, orc = _synth_case(tmp_path, 30000, 800, 2, "mixed", 57)
+    c = capi.Context(0)
+    try:
+        c.load_graph(g)
+        c.upload(gaf)
+        c.classify_resident()
+        want = c.counts().copy()
+        cuts = [0, 1, 4097, 1000003, 2500000, int(gaf.size)]
+        got = c.upload_parts((gaf[a:b] for a, b in zip(cuts[:-1], cuts[1:])), int(gaf.size) + (5 << 20))
+        assert got == gaf.size
+        c.reset_counts()
+        c.classify_resident()
+        assert np.array_equal(c.counts(), want) and want.sum() > 0 and c.stats()["n_lines"] == 30000
+        lib = capi.load_library()
+        assert lib.svjg_gaf_upload_part(c.h, gaf.ctypes.data, 1000, 0, 1 << 20, 0) == 0
+        assert lib.svjg_gaf_upload_part(c.h, gaf.ctypes.data, 1000, 5000, 1 << 20, 0) < 0        # (a gap)
+        with pytest.raises(capi.SvjgError):
+            c.classify_resident()                                                                # (no resident text after a broken upload)
+        copy, read = c.copy_rate(1 << 28)
+        assert 500 < copy < 9000 and 500 < read < 9000                                           # GB/s, below the data sheet's 8 TB/s
+    finally:
+        c.close()
+
+
 def test_bench_single_process_two_gpus():
     """bench.py --gpus 2 without a launcher: one process, one context and one thread per GPU, RCCL all-reduce inside the timed
     pass.  On a one-GPU box it must refuse (non-zero exit, no JSON line)."""
