@@ -46,7 +46,11 @@ constexpr uint32_t KMAX = 64;                    // path nodes of one node pass 
 // fall all the way or, where they turn, whether a name comes twice, once to count.  Where no name comes twice list.index is the position
 // itself; where one does, sweep 1 takes every node's first occurrence over the WHOLE line (the ids of all nodes wait in LDS, the running
 // path lengths in a few words of global memory of the worker's own).
+#ifdef SVJG_W16
+constexpr uint32_t KLONG = KMAX;                 // (measurement variant: the per-line records live where a long line's ids would wait)
+#else
 constexpr uint32_t KLONG = CAP_O < 255u ? CAP_O : 255u;
+#endif
 constexpr uint32_t LONG_WORDS = 256;             // per worker, in global memory: the running path length behind every node of a long line (ClassifyArgs::long_pre)
 static_assert(KLONG <= LONG_WORDS && KLONG * 4 <= TEXT / 8 + 16, "a long line's per-node words fit their places");
 constexpr uint32_t LRW = MAXL;                   // lines per round
