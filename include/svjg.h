@@ -162,9 +162,10 @@ int svjg_input_error(svjg_ctx *ctx, int *exc_class, uint64_t *line_offset);
 /* Why lines took the exact string path since the last svjg_reset_counts (their sum is svjg_stats.n_deferred):
  * out[0] columns that are not twelve plain ones (blanks, signs, too few, Alen = 0, ...), [1] a 64-byte span of the line holds the
  * byte pair "d:" and the line is not decided in the main kernel (an id:f: tag, filter-alignments.py:193-196, whose value is not a
- * plain decimal, or several pairs in the line's spans), [2] a path of more than 64 nodes, [3] a node name
+ * plain decimal, or several pairs in the line's spans), [2] a path of 4 Gbp and more (the main kernel's path sums are 32 bits wide; paths of
+ * up to 216 nodes — more marks than that and the line's stripe cannot list it: [4] — stay in the main kernel), [3] a node name
  * the kernel's name table does not hold (not in the graph, a substring of another name, longer than 48 bytes, alt node without a
- * length), [4] whole stripes of 8 KB (more than 64 lines or 216 orientation marks, a line longer than 8 KB, SVJG_GRAPH_ALL_SLOW),
+ * length), [4] whole stripes of 8 KB (more than 64 lines or 216 orientation marks, a line longer than 8 KB, SVJG_GRAPH_ALL_SLOW / _DOVER_LIST),
  * [5..7] reserved (0). */
 int svjg_get_defer_causes(svjg_ctx *ctx, uint64_t *out8);
 

@@ -285,13 +285,28 @@ SVJG_HD bool next_node(P t, uint64_t pe, bool oriented, uint64_t &pos, NameRef &
     return false;
 }
 
+// name_windows for a name INSIDE a line whose twelve columns were found (the exact routine): at least eight more bytes of the line follow
+// the name's first byte — six more columns —, so the windows are read eight bytes at a time and only a name shorter than eight bytes is
+// masked.  Same words as name_windows (checked by the host build on every fixture: both resolve every node of the graph).
+template <class P>
+SVJG_HD void name_windows_inline(P t, uint64_t s, uint32_t len, uint32_t d[NAME_WORDS]) {
+    const uint32_t o2 = len < 8u ? 0u : (len - 8u < 16u ? len - 8u : 16u), o1 = o2 >> 1;
+    uint64_t w0 = ld64(t, s), w1 = ld64(t, s + o1), w2 = ld64(t, s + o2);
+    if (len < 8u) { const uint64_t m = ~(~0ull << (8u * len)); w0 &= m; w1 &= m; w2 &= m; }
+    d[0] = (uint32_t)w0; d[1] = (uint32_t)(w0 >> 32); d[2] = (uint32_t)w1; d[3] = (uint32_t)(w1 >> 32); d[4] = (uint32_t)w2; d[5] = (uint32_t)(w2 >> 32);
+    const uint64_t w3 = len > 24u ? ld64(t, s + len - 8u) : 0ull;
+    d[6] = (uint32_t)w3; d[7] = (uint32_t)(w3 >> 32);
+    const uint64_t w4 = len > 32u ? ld64(t, s + len - 24u) : 0ull, w5 = len > 32u ? ld64(t, s + len - 16u) : 0ull;
+    d[8] = (uint32_t)w4; d[9] = (uint32_t)(w4 >> 32); d[10] = (uint32_t)w5; d[11] = (uint32_t)(w5 >> 32);
+}
+
 // Node-name table of the main kernel (svjg_host_tables.h), probed with the raw bytes of a name of 1..48 bytes:
 // node id, or NONE32 when the name's slot does not hold this spelling.
 template <class P>
 SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
     const uint32_t len = (uint32_t)(nm.e - nm.s);
     uint32_t d[NAME_WORDS];
-    name_windows(t, nm.s, len, d);
+    name_windows_inline(t, nm.s, len, d);
     const uint64_t h = name_prehash(d, len);
     const uint32_t slot = name_slot(h, g.name_disp[name_bucket(h, g.name_buckets)], g.name_slots);
     const uint32_t *e = g.name_tab + (uint64_t)slot * 16;
@@ -340,11 +355,9 @@ SVJG_HD uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_
     return id;
 }
 
-// get_node_len (filter-alignments.py:343-349): 0 = ok, else the exception class
+// get_node_len (filter-alignments.py:343-349): 0 = ok, else the exception class.  (id, alt): what resolve_name said about the name
 template <class P>
-SVJG_HD int generic_node_len(const GraphView &g, P t, NameRef nm, int64_t &len) {
-    bool alt;
-    uint32_t id = resolve_name(g, t, nm, &alt);
+SVJG_HD int node_len_resolved(const GraphView &g, P t, NameRef nm, uint32_t id, bool alt, int64_t &len) {
     if (alt) {
         if (id == NONE32 || g.nodes[id].aux == SVJG_LEN_UNKNOWN || !((g.nodes[id].key >> 15) & 1)) return SVJG_EXC_KEY_ERROR;
         len = g.nodes[id].aux;
@@ -362,6 +375,12 @@ SVJG_HD int generic_node_len(const GraphView &g, P t, NameRef nm, int64_t &len) 
     if (!py_int(t, c0, d1, a)) return SVJG_EXC_VALUE_ERROR;
     len = b - a + 1;
     return 0;
+}
+template <class P>
+SVJG_HD int generic_node_len(const GraphView &g, P t, NameRef nm, int64_t &len) {
+    bool alt;
+    const uint32_t id = resolve_name(g, t, nm, &alt);
+    return node_len_resolved(g, t, nm, id, alt, len);
 }
 
 // char before the first occurrence of the name as a substring of the path (filter-alignments.py:206)
@@ -468,8 +487,10 @@ SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeSc
             if (rc) { *order = (1ull << 32) | j; return rc; }
             int64_t l1 = 0;
             ns.strand[j * ns.stride] = (uint8_t)st;
-            ns.id[j * ns.stride] = resolve_name(g, t, nm, nullptr);
-            ns.rc[j * ns.stride] = (uint8_t)generic_node_len(g, t, nm, l1);
+            bool alt;
+            const uint32_t id = resolve_name(g, t, nm, &alt);      // (once: the id for the links, the form for get_node_len)
+            ns.id[j * ns.stride] = id;
+            ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1);
             ns.len[j * ns.stride] = l1;
         }
         return 0;
@@ -481,8 +502,10 @@ SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeSc
         if (rc) { *order = (1ull << 32) | j; return rc; }
         int64_t l1 = 0;
         ns.strand[j * ns.stride] = (uint8_t)st;
-        ns.id[j * ns.stride] = resolve_name(g, t, nm, nullptr);
-        ns.rc[j * ns.stride] = (uint8_t)generic_node_len(g, t, nm, l1);
+        bool alt;
+        const uint32_t id = resolve_name(g, t, nm, &alt);          // (once: the id for the links, the form for get_node_len)
+        ns.id[j * ns.stride] = id;
+        ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1);
         ns.len[j * ns.stride] = l1;
         NameRef skip{0, 0};
         for (uint32_t q = 1; q < nlanes && more; ++q) more = next_node(t, ln.pe, ln.oriented, pos, skip);
