@@ -309,13 +309,22 @@ SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
     name_windows_inline(t, nm.s, len, d);
     const uint64_t h = name_prehash(d, len);
     const uint32_t slot = name_slot(h, g.name_disp[name_bucket(h, g.name_buckets)], g.name_slots);
-    const uint32_t *e = g.name_tab + (uint64_t)slot * 16;
-    const uint32_t meta = e[6];
+    // the record: 64 bytes, 16-byte aligned, read as four 16-byte words (one load each, like the main kernel's) instead of word by word
+    typedef uint32_t w4 __attribute__((vector_size(16)));
+    const w4 *e = (const w4 *)(g.name_tab + (uint64_t)slot * 16);
+    const w4 a = e[0], b = e[1];
+    const uint32_t meta = b[2];
     if (meta == 0xFFFFFFFFu || (meta & NAME_LEN_MASK) != len - 1u) return NONE32;
-    if (e[0] == d[0] && e[1] == d[1] && e[2] == d[2] && e[3] == d[3] && e[4] == d[4] && e[5] == d[5] && (len <= 24u || (e[8] == d[6] && e[9] == d[7])) &&
-        (len <= 32u || (e[10] == d[8] && e[11] == d[9] && e[12] == d[10] && e[13] == d[11])))
-        return g.node_of_kid[meta >> NAME_ID_SHIFT];
-    return NONE32;
+    if (a[0] != d[0] || a[1] != d[1] || a[2] != d[2] || a[3] != d[3] || b[0] != d[4] || b[1] != d[5]) return NONE32;
+    if (len > 24u) {
+        const w4 c = e[2];
+        if (c[0] != d[6] || c[1] != d[7]) return NONE32;
+        if (len > 32u) {
+            const w4 f = e[3];
+            if (c[2] != d[8] || c[3] != d[9] || f[0] != d[10] || f[1] != d[11]) return NONE32;
+        }
+    }
+    return g.node_of_kid[meta >> NAME_ID_SHIFT];
 }
 
 // exact name -> node id (only canonical spellings can be in the table)
@@ -388,6 +397,18 @@ template <class P>
 SVJG_HD int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &strand) {
     uint64_t n = nm.e - nm.s;
     if (n == 0) return SVJG_EXC_VALUE_ERROR;                      // str.split("")
+    if (n >= 8) {
+        // names of one path begin alike (the chromosome) and differ at their ends (the coordinates): a candidate position is first held
+        // against the name's LAST eight bytes, one 8-byte read, and only then against the rest
+        const uint64_t tail = ld64(t, nm.e - 8);
+        for (uint64_t q = ps; q + n <= pe; ++q)
+            if (ld64(t, q + n - 8) == tail && bytes_eq(t, q, nm.s, n - 8)) {
+                if (q == ps) return SVJG_EXC_INDEX_ERROR;         // ""[-1]
+                strand = t[q - 1] == '>' ? 0u : 1u;
+                return 0;
+            }
+        return SVJG_EXC_INDEX_ERROR;                              // unreachable: the name is part of the path
+    }
     for (uint64_t q = ps; q + n <= pe; ++q)
         if (t[q] == t[nm.s] && bytes_eq(t, q, nm.s, n)) {
             if (q == ps) return SVJG_EXC_INDEX_ERROR;             // ""[-1]

@@ -1444,10 +1444,14 @@ def test_bench_single_process_two_gpus():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     have = capi.device_count()
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c2", "--aln", "200000", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-e2e"], capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-e2e", "--north-star-aln", "400000", "--north-star-svs", "5000"], capture_output=True, text=True, timeout=600)
     if have < 2:
         assert r.returncode != 0 and "needs 2 devices, found" in r.stderr and not r.stdout.strip()
         return
     assert r.returncode == 0, r.stderr[-500:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl"]["ranks"] == 2 and line["value"] > 0 and line["deferred_lines_per_step"] == 0
+    # the all-reduce on either stream, RCCL's own account of its rings, the north_star workload over both GPUs with equal digests
+    assert line["rccl"]["allreduce_stream"]["second"]["ms_per_step"] > 0 and "debug_info" in line["rccl"]
+    ns = line["north_star"]
+    assert ns["n_gpus"] == 2 and ns["alignments"] == 400000 and ns["digest_equal_across_ranks"] is True and ns["alignments_per_s"] > 0
