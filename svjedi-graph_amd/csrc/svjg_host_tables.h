@@ -234,7 +234,10 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
         uint64_t slots = n + n / 4 + 16;                      // load <= 0.8
         for (int grow = 0;; ++grow) {
             kt.name_slots = (uint32_t)slots;
-            uint32_t lambda = 3;                             // keys per bucket (SVJG_NAME_LAMBDA: measurement only)
+            // keys per bucket: 8 since r04 (3 before): the displacement array is a third of the size (50 KB at configs[2], 250 KB at
+            // configs[3]) and hits the caches more often: -0.9 % kernel time on both (profiles/r04/experiments/displacement_buckets.txt);
+            // the largest displacement is ~15 000 of the 65 535 a u16 holds, 12 keys already reach for the limit.  (SVJG_NAME_LAMBDA: measurement only)
+            uint32_t lambda = 8;
             { const char *e = getenv("SVJG_NAME_LAMBDA"); if (e && atoi(e) >= 1 && atoi(e) <= 16) lambda = (uint32_t)atoi(e); }
             kt.name_buckets = (uint32_t)(n / lambda + 1);
             if (chd_place(hs, kt.name_slots, kt.name_buckets, kt.disp, slot_of)) break;

@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/j12
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "quirks or fuzz or random_graphs or unicode or realshape or dover or deferral or identity_tag or paths_of_65 or long_paths or lines_longer or stripes or node_names" > gpurun_out/j12/tests.log 2>&1; tail -4 gpurun_out/j12/tests.log
-for i in 1 2; do ALL_SLOW=1 python3 tools/slowpath_bench.py 0 2>&1 | tail -1; done | tee gpurun_out/j12/slowpath_all_slow.txt
-python3 tools/slow_long_probe.py 2>&1 | tee gpurun_out/j12/slow_long_probe.txt
+mkdir -p gpurun_out/j13
+for lam in 3 5 8 12; do
+  for W in c4shard c3; do
+    echo "lambda=$lam $W $(SVJG_NAME_LAMBDA=$lam SVJG_BENCH_SYNC=1 python3 bench.py --workload $W --no-cpu-baseline --no-e2e --no-north-star --no-long-read --steps 30 --warmup 5 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.readline()); print(round(r['kernel_ms']['classify_main'],4), r['setup_s'])")"
+  done
+done | tee gpurun_out/j13/lambda.txt

@@ -37,7 +37,19 @@ def main():
     gaf = synth.gaf_bytes(inf["tables"], seed, 0, n_aln, threads=min(16, os.cpu_count() or 8))
     graph = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
     orc = oracle_c.COracle(oracle_py.load_edges(pre + "_svs_edges.json"), oracle_py.load_alt_node_len(pre + ".gfa"))
-    _S.update(orc=orc, gaf=gaf, map=np.array([graph.slot_of[s] for s in orc.sv_ids], dtype=np.uint32))
+    slot = np.array([graph.slot_of[s] for s in orc.sv_ids], dtype=np.uint32)
+    if len(sys.argv) > 3 and sys.argv[3] == "genome-order":      # experiment: count slots numbered along the genome instead of by the ids' string order
+        import re
+
+        def where(sv):
+            c, rest = sv.split(":", 1)
+            m = re.match(r"[A-Z]+-(\d+)", rest) or re.search(r"(\d+)$", rest)
+            return (c, int(m.group(1)))
+        order = sorted(range(len(graph.sv_ids)), key=lambda i: where(graph.sv_ids[i]))
+        perm = np.empty(len(order), dtype=np.uint32)
+        perm[np.array(order)] = np.arange(len(order), dtype=np.uint32)
+        slot = perm[slot]
+    _S.update(orc=orc, gaf=gaf, map=slot)
     cores = min(len(os.sched_getaffinity(0)), 16)
     nl = np.flatnonzero(gaf == 10)
     per = nl.size // cores
