@@ -165,7 +165,7 @@ int svjg_input_error(svjg_ctx *ctx, int *exc_class, uint64_t *line_offset);
  * plain decimal, or several pairs in the line's spans), [2] a path of 4 Gbp and more (the main kernel's path sums are 32 bits wide; paths of
  * up to 216 nodes — more marks than that and the line's stripe cannot list it: [4] — stay in the main kernel), [3] a node name
  * the kernel's name table does not hold (not in the graph, a substring of another name, longer than 48 bytes, alt node without a
- * length), [4] whole stripes of 8 KB (more than 64 lines or 216 orientation marks, a line longer than 8 KB, SVJG_GRAPH_ALL_SLOW / _DOVER_LIST),
+ * length), [4] whole stripes of 8 KB (more than 64 lines or 216 orientation marks, a line whose columns and path run beyond 8 KB or whose tail beyond them is not plain, SVJG_GRAPH_ALL_SLOW / _DOVER_LIST),
  * [5..7] reserved (0). */
 int svjg_get_defer_causes(svjg_ctx *ctx, uint64_t *out8);
 

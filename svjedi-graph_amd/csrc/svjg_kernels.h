@@ -290,7 +290,7 @@ __device__ inline uint32_t idsum_of(uint32_t pair_lo, uint32_t pair_hi) {   // (
     return ((cnt < 3u ? cnt : 3u) << 6) | pos;
 }
 __device__ inline uint32_t lane_above_or0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }   // wave_shl:1, lane 63 gets 0
-__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t *tbm, uint32_t slot, uint64_t c0, uint32_t V,
+__device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text, uint32_t *ndbm, uint32_t *tbm, uint32_t half, uint32_t slot, uint64_t c0, uint32_t V,
                                      unsigned long long &NL, unsigned long long &ORI, SpanFlags &fl) {
     const uint32_t sp = slot * SPAN;
     // rotated piece order: the 16-byte LDS reads of a wave hit different banks.  The planes are those of the span rotated by
@@ -319,7 +319,7 @@ __device__ inline void classify_span(const ClassifyArgs &a, const uint8_t *text,
         const uint32_t pair_lo = (uint32_t)dee & s_lo, pair_hi = (uint32_t)(dee >> 32) & s_hi;
         fl.idf |= pair_lo | pair_hi;
         if (RARELY(m_ne(pair_lo | pair_hi, 0u))) {                       // (wave-uniform: no tag minigraph writes holds the pair)
-            if ((pair_lo | pair_hi) != 0u) fl.idsum |= idsum_of(pair_lo, pair_hi) << (slot >= WG ? 8 : 0);
+            if ((pair_lo | pair_hi) != 0u) fl.idsum |= idsum_of(pair_lo, pair_hi) << (half ? 8 : 0);
         }
         fl.dee_last = (uint32_t)(dee >> 63);
     }
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             wave_sync();
             __builtin_amdgcn_s_setprio(0);
             fl.idf = 0u;
-            classify_span(a, text, ndbm, tbm, h * WG + lane, c0, V, NL[h], ORI[h], fl);
+            classify_span(a, text, ndbm, tbm, h, h * WG + lane, c0, V, NL[h], ORI[h], fl);
             IDM[h] = ballot64(fl.idf != 0);
             if (h == 0) dee_end = rdlane(fl.dee_last, WG - 1);
             else if (dee_end != 0 && text[HALF] == ':') {                // (the pair straddles the halves: its 'd' is the first half's last byte)
@@ -628,14 +628,54 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 NL[h] &= keep; ORI[h] &= keep;
             }
         }
+        // A line longer than the staged text (r04): if what runs past the stage is only the line's TAIL — its twelve columns and its path
+        // lie in the staged 8 KB: the line phase finds out — the line stays here.  The tail is walked first, 4 KB per step from the
+        // prefetch registers, no LDS, no byte classes: where is the terminator; does the tail hold a carriage return or the byte pair "d:"
+        // (an id:f: tag: then the exact path decides, as for any tag the line phase cannot read) or a byte >= 0x80 (the host validates
+        // UTF-8).  With a clean tail the stripe is handled like a text's last one (its line ends where the stage ends) and the next stripe
+        // begins behind the terminator; otherwise, and beyond 256 KB, the line takes the exact path as before.
+        // (Such a stripe is known below by long_line && eof_h: the two never hold together otherwise.)
+        if (RARELY(long_line) && Vh == TEXT && !a.all_slow && tot_ori <= CAP_O && text[TEXT - 1] != 'd') {
+            unsigned long long at = c0 + TEXT, E = ~0ull;
+            bool clean = true;
+            for (uint32_t it = 0; it < 64u && clean && E == ~0ull; ++it, at += HALF) {
+                if (at >= a.n_bytes) { E = a.n_bytes; break; }           // the text ends inside the line (no terminator)
+                fetch_half(at);
+#pragma unroll
+                for (uint32_t i = 0; i < NPF; ++i) {
+                    if (E != ~0ull || !clean) break;
+                    const uint4 v = pf[i];
+                    const uint32_t nl = eq_mask16(v, 0x0A0A0A0Au), dee = eq_mask16(v, 0x64646464u), col = eq_mask16(v, 0x3A3A3A3Au);
+                    const uint32_t bad = eq_mask16(v, 0x0D0D0D0Du) | (dee & ((col >> 1) | 0x8000u));   // (a 'd' at a piece's end: its ':' would be the next piece's)
+                    if (ballot64(((v.x | v.y | v.z | v.w) & 0x80808080u) != 0) != 0 && lane == 0) a.st->non_ascii = 1;
+                    uint32_t front = 0xFFFFu;                            // the piece's bytes in front of the terminator
+                    const unsigned long long b = ballot64(nl != 0);
+                    if (b != 0) {
+                        const uint32_t L = (uint32_t)__builtin_ctzll(b), bit = (uint32_t)__builtin_ctz(rdlane(nl, L));
+                        E = at + (unsigned long long)((i * WG + L) * 16u + bit);
+                        front = lane < L ? 0xFFFFu : lane == L ? (1u << bit) - 1u : 0u;
+                    }
+                    if (ballot64((bad & front) != 0) != 0) clean = false;
+                }
+                if (E != ~0ull && E >= a.n_bytes) E = a.n_bytes;         // (cannot happen: the padding behind the text holds no terminator)
+            }
+            if (clean && E != ~0ull) {
+                eof_h = true;
+                next_pos = E < a.n_bytes ? E + 1ull : a.n_bytes;
+                last_stripe = next_pos >= rend;
+            }
+        }
         if (!last_stripe) {
-            const uint32_t d0 = (uint32_t)((next_pos & ~15ull) - c0);    // the next stripe begins inside (or right behind) this one's staged text
-            pf_head = d0 ? (uint32_t)text[d0 - 1] : head_byte;
+            if (RARELY(long_line && eof_h)) pf_head = (next_pos & 15ull) ? (uint32_t)'x' : (uint32_t)'\n';   // (the byte in front of the next stripe: a byte of the tail, or its terminator)
+            else {
+                const uint32_t d0 = (uint32_t)((next_pos & ~15ull) - c0);    // the next stripe begins inside (or right behind) this one's staged text
+                pf_head = d0 ? (uint32_t)text[d0 - 1] : head_byte;
+            }
             fetch_half(next_pos & ~15ull);
         }
         tick(1);
 
-        if (a.all_slow || long_line || n_s > MAXL || tot_ori > CAP_O) {
+        if (a.all_slow || (long_line && !eof_h) || n_s > MAXL || tot_ori > CAP_O) {
             // the lists cannot hold this stripe / the caller wants the exact path: every owned line is deferred as it is
             if (n_own) {
                 unsigned long long dbase = 0;

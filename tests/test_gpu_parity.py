@@ -895,9 +895,10 @@ def test_paths_of_65_to_216_nodes(ctx, tmp_path):
 
 
 def test_lines_longer_than_the_look_ahead(ctx, tmp_path):
-    """Every line carries a 3 KB tag: many lines run past the staged text of their stripe.  They get a stripe of their own in
-    a second launch of the main kernel instead of the exact path (and the library widens the look-ahead for the next
-    batch).  Lines longer than the whole staged text still take the exact path.  Counts are the oracle's every time."""
+    """Every line carries a 3 KB tag: many lines run past the staged text of their stripe; the next stripe begins with them.  Lines longer
+    than the whole staged text (8 KB; r04) stay in the main kernel too when what runs past the stage is a plain tail — the worker walks it for
+    the terminator —, and take the exact path when the tail holds a carriage return, the byte pair "d:" (an id:f: tag decides the line), or
+    no terminator within 256 KB.  Counts, line counts and hit records are the oracle's every time."""
     import synth
     from svjg.graph import Graph
     pre = str(tmp_path / "c")
@@ -908,11 +909,27 @@ def test_lines_longer_than_the_look_ahead(ctx, tmp_path):
     pad = b"\tzz:Z:" + b"ACGT" * 750
     data = b"".join(l + pad + b"\n" for l in lines)
     huge = b"".join(l + (b"\tzz:Z:" + b"ACGT" * 6000 if i % 97 == 0 else pad if i % 3 else b"") + b"\n" for i, l in enumerate(lines))
+
+    def tail(i):
+        kind = (i // 89) % 8
+        t = b"\tcg:Z:" + b"12M3D" * (1700 + 37 * kind)
+        if kind == 1: t += b"\tid:f:0.0"                       # the tag decides the line (identity 0: no hit) — exact path
+        if kind == 2: t += b"\rx"                               # a bare carriage return ends the line (universal newlines): the rest is a bad line of its own
+        if kind == 3: t += b"\txd:Z:" + b"A" * 5000             # "d:" that is no id:f: tag — still the exact path's call
+        if kind == 4: t += b"\tzz:Z:" + "\u00e9".encode() * 40  # bytes >= 0x80 (the host validates UTF-8; the kernel's verdict stands)
+        if kind == 5: t += b"\tzz:Z:" + b"C" * 300000           # no terminator within 256 KB
+        if kind == 6: t += b"\tzz:Z:" + b"G" * (8192 * 3 - len(t) - len(lines[i]) - 7 + (i % 32))    # the terminator near a 16-byte / 4 KB boundary
+        return t
+    mixed_l = [l + (tail(i) if i % 89 == 0 else pad if i % 5 == 0 else b"") for i, l in enumerate(lines)]
+    mixed_l = [l for i, l in enumerate(mixed_l) if not (i % 89 == 0 and (i // 89) % 8 == 2)]      # (the '\r' case is checked apart: the oracle dies on its second line)
+    mixed = b"\n".join(mixed_l) + b"\n"
+    n_mixed_exact = sum(1 for i in range(len(lines)) if i % 89 == 0 and (i // 89) % 8 in (1, 3, 5))
+    no_end = mixed + lines[7] + b"\tcg:Z:" + b"9M" * 9000                                      # the text ends inside a long line
     from svjg import capi
-    for text, n_exact in ((data, 0), (huge, len(lines) // 97 + 1)):
+    for text, n_exact in ((data, 0), (huge, 0), (mixed, n_mixed_exact), (no_end, n_mixed_exact)):
         want, _, n_lines = orc.filter(text, want_hits=False)
         arr = np.frombuffer(text, dtype=np.uint8)
-        c2 = capi.Context(0)                       # a fresh context: the look-ahead is per context and only grows
+        c2 = capi.Context(0)
         try:
             c2.load_graph(g)
             for _ in range(3):
@@ -920,10 +937,17 @@ def test_lines_longer_than_the_look_ahead(ctx, tmp_path):
                 c2.classify(arr, want_hits=True)
                 assert _counts_dict(g, c2.counts()) == _oracle_dict(orc, want)
                 st = c2.stats()
-                assert st["n_lines"] == n_lines and st["n_deferred"] == n_exact
+                assert st["n_lines"] == n_lines and st["n_deferred"] == n_exact, (st, n_lines, n_exact)
                 assert st["n_hitrecs"] == int(want.sum())
         finally:
             c2.close()
+    # a carriage return in a long tail: the reference's (and the oracle's) line ends there, and what follows is a line of two columns
+    cr = lines[0] + b"\tcg:Z:" + b"5M" * 6000 + b"\rx\ty\n" + lines[1] + b"\n"
+    with pytest.raises(ValueError):
+        orc.filter(cr, want_hits=False)
+    ctx.load_graph(g)
+    with pytest.raises(ValueError):
+        ctx.classify(np.frombuffer(cr, dtype=np.uint8))
 
 
 def test_sharded_and_chunked_ingest_is_the_same_file(golden, tmp_path, monkeypatch):
