@@ -33,6 +33,11 @@ def od(want):
 good, bad = [], []
 for _ in range(n_mut):
     m = mutate(rng.choice(lines), rng, MORE_TAGS)
+    if rng.random() < 0.02:                        # r04: a tail that runs past the main kernel's staged 8 KB (plain, or with what sends the line to the exact path)
+        body = m.rstrip(b"\r\n")
+        fill = rng.choice((b"12M3D", b"ACGT", b"A", b"7M", b"9I2D", b"d", b"5M:d"))
+        extra = rng.choice((b"", b"", b"", b"\tid:f:0.9", b"\tid:f:0", b"\rx", b"\txd:i:1", b" ", b"\t"))
+        m = body + b"\tcg:Z:" + fill * (rng.choice((7000, 8200, 12300, 16380, 24000, 31000)) // len(fill)) + extra + m[len(body):]
     if b"\xd9\xa3" in m or any(c >= 0x80 for c in m):
         continue                                   # documented divergences / UTF-8 handling is the host's
     if len(m) > 32768:
