@@ -17,6 +17,16 @@
 #ifndef SVJG_HD
 #define SVJG_HD __host__ __device__ inline __attribute__((always_inline))
 #endif
+// The exact routine's larger helpers are real calls (r04): inlined into the two exact-path kernels they cost 389 / 390 SGPR spills (saved
+// exec masks of deeply nested divergent code); as calls 0 / 8, with a stack of 544 bytes a lane, at the same kernel times
+// (profiles/r04/experiments/exact_path.txt).  -DSVJG_SLOW_INLINE builds the inlined form.
+#ifndef SVJG_FN
+#ifdef SVJG_SLOW_INLINE
+#define SVJG_FN SVJG_HD
+#else
+#define SVJG_FN __host__ __device__ __attribute__((noinline))
+#endif
+#endif
 
 namespace svjg {
 
@@ -200,7 +210,7 @@ constexpr int64_t BIGV = (int64_t)1 << 61;
 
 // Python int(): blanks, sign, digits with single inner underscores (ASCII subset)
 template <class P>
-SVJG_HD bool py_int(P t, uint64_t a, uint64_t b, int64_t &out) {
+SVJG_FN bool py_int(P t, uint64_t a, uint64_t b, int64_t &out) {
     while (a < b && py_space(t[a])) ++a;
     while (b > a && py_space(t[b - 1])) --b;
     bool neg = false;
@@ -242,7 +252,7 @@ SVJG_HD bool word_is(P t, uint64_t a, uint64_t b, const char *w, uint32_t wl) {
 
 // would Python's float() accept t[a,b) ?
 template <class P>
-SVJG_HD bool py_float_ok(P t, uint64_t a, uint64_t b) {
+SVJG_FN bool py_float_ok(P t, uint64_t a, uint64_t b) {
     while (a < b && py_space(t[a])) ++a;
     while (b > a && py_space(t[b - 1])) --b;
     if (a < b && (t[a] == '+' || t[a] == '-')) ++a;
@@ -329,7 +339,7 @@ SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
 
 // exact name -> node id (only canonical spellings can be in the table)
 template <class P>
-SVJG_HD uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_form) {
+SVJG_FN uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_form) {
     uint64_t colon = nm.e;
     for (uint64_t q = nm.e; q > nm.s; --q) if (t[q - 1] == ':') { colon = q - 1; break; }
     if (is_alt_form) {
@@ -394,7 +404,7 @@ SVJG_HD int generic_node_len(const GraphView &g, P t, NameRef nm, int64_t &len) 
 
 // char before the first occurrence of the name as a substring of the path (filter-alignments.py:206)
 template <class P>
-SVJG_HD int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &strand) {
+SVJG_FN int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &strand) {
     uint64_t n = nm.e - nm.s;
     if (n == 0) return SVJG_EXC_VALUE_ERROR;                      // str.split("")
     if (n >= 8) {
@@ -424,7 +434,7 @@ SVJG_HD int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &stran
 // Compared from the name's end (names of one path differ in their coordinates).  O(pieces) instead of O(bytes of the path) per name:
 // what makes a path of hundreds of nodes affordable for the one-wave-per-line kernel.
 template <class P>
-SVJG_HD int strand_of_pieces(P t, uint64_t ps, const uint32_t *pos, uint32_t n_pieces, NameRef nm, uint32_t &strand) {
+SVJG_FN int strand_of_pieces(P t, uint64_t ps, const uint32_t *pos, uint32_t n_pieces, NameRef nm, uint32_t &strand) {
     const uint64_t n = nm.e - nm.s;
     if (n == 0) return SVJG_EXC_VALUE_ERROR;                      // str.split("")
     for (uint32_t i = 0; i < n_pieces; ++i) {
@@ -455,7 +465,7 @@ SVJG_HD bool has_high(P t, uint64_t a, uint64_t b) {
 }
 
 template <class P>
-SVJG_HD int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
+SVJG_FN int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
     o.k = 0;
     while (e > s && py_space(t[e - 1])) --e;
     // (str.rstrip() also takes Unicode blanks: a line that ends in a byte >= 0x80 is the host's if anything below fails on it)

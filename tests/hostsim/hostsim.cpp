@@ -4,6 +4,7 @@
 // -fsanitize=address,undefined).  The main kernel (k_classify_main) is wave/block-level code and is covered
 // by the -m gpu tests through the C ABI.
 #define SVJG_HD inline
+#define SVJG_FN inline
 #include "../../svjedi-graph_amd/csrc/svjg_line.h"
 #include "../../svjedi-graph_amd/csrc/svjg_host_tables.h"
 #include "../../svjedi-graph_amd/csrc/svjg_planes.h"

@@ -14,11 +14,11 @@ tmp = tempfile.mkdtemp(); pre = os.path.join(tmp, "w")
 seed = 20260515 + 9
 inf = synth.generate(pre, 0, 20000, 8, "mixed", seed, write_gaf=False, chrom_style="ucsc")
 gaf = synth.gaf_bytes(inf["tables"], seed, 0, 300000, threads=16, shape="long")
-g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", all_slow=True)     # (r04: a plain tail no longer sends a line to the exact path: every line is sent)
 lines = bytes(gaf).split(b"\n")[:-1]
 longest = max(lines, key=len)
 k = longest.split(b"\t")[5].count(b">") + longest.split(b"\t")[5].count(b"<")
-pad = b"".join(l + b"\n" for l in lines[:2000] if len(l) < 2000)
+pad = b"".join(l + b"\n" for l in lines[:20] if len(l) < 2000)
 ctx = capi.Context(0); ctx.load_graph(g)
 print(f"the line: {len(longest)} bytes, {k} nodes")
 for n in (1, 8, 64, 512):
