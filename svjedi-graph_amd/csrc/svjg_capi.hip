@@ -518,8 +518,8 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         if (a.diag & 16u) {
             unsigned long long d[12];
             HIPCHK(c, hipMemcpy(d, c->d_dbg, sizeof d, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A+B1 %llu  prefix %llu  B2 %llu  R1 %llu  NP: lists %llu  names+disp %llu  records %llu  scan+search %llu  links+atomics %llu  R6+end %llu\n",
-                    d[0], d[1], d[2], d[3], d[8], d[9], d[4], d[5], d[6], d[7]);
+            fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A+B1 %llu  prefix %llu  B2 %llu  R1 %llu  NP: lists %llu  names+disp %llu  records %llu  scan+search %llu  links+atomics %llu  R6+end %llu;  passes %llu (sub-passes of long lines %llu), nodes in them %llu\n",
+                    d[0], d[1], d[2], d[3], d[8], d[9], d[4], 0ull, d[6], d[7], d[10], d[11], d[5]);
         }
 #endif
         c->ms_slow = 0;

@@ -471,6 +471,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     auto tick = [&](int ph) { const unsigned long long t = __builtin_readcyclecounter(); acc[ph] += t - stamp; stamp = t; };
     // (8 .. 10 split the node pass's load phase: these wait for the loads they stamp, which the shipped kernel does not do there)
 #define tick_mem(ph) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tick(ph); } while (0)
+#define tally(ph, n) do { acc[ph] += (n); } while (0)             // (5: nodes in passes, 10: passes, 11: sub-passes of long lines)
 #elif defined(SVJG_MARK)
     // static census (tools/isa): the phase boundaries show up as comments in the -S output
 #define tick(ph) asm volatile("; MARK " #ph)
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
 #endif
 #ifndef SVJG_TIMING
 #define tick_mem(ph) do { } while (0)
+#define tally(ph, n) do { } while (0)
 #endif
 
     // stripe prefetch registers: the FIRST HALF of a stripe waits in registers while the stripe in front of it is worked off (piece i
@@ -923,6 +925,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     okl = 1ull << i0;
                 }
                 __builtin_amdgcn_s_setprio(P_LOAD);
+                tally(10, 1); tally(5, n_pass); if (lsub) tally(11, 1);
                 // -- the node of this lane: line, index in the line, name.  Every lane runs the same straight code on indices that
                 //    are safe to read (a lane beyond the pass looks at the pass's first mark); `live` says whose results count --
                 const wmask act_m = low_bits64(n_pass);

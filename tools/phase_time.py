@@ -8,10 +8,15 @@ for p in (ROOT, os.path.join(ROOT, "svjedi-graph_amd"), os.path.join(ROOT, "tool
 import synth
 from svjg import capi
 from svjg.graph import Graph
-n_aln, n_sv, n_chrom, mix, seed = 10_000_000, 100_000, 4, "mixed", 20260517
 tmp = tempfile.mkdtemp(); pre = os.path.join(tmp, "w")
-inf = synth.generate(pre, 0, n_sv, n_chrom, mix, seed, write_gaf=False)
-gaf = synth.gaf_bytes(inf["tables"], seed, 0, n_aln, threads=16)
+if len(sys.argv) > 1 and sys.argv[1] == "long":                  # bench.py's long_read block
+    seed = 20260515 + 9
+    inf = synth.generate(pre, 0, 20_000, 8, "mixed", seed, write_gaf=False, chrom_style="ucsc")
+    gaf = synth.gaf_bytes(inf["tables"], seed, 0, 3_000_000, threads=16, shape="long")
+else:
+    n_aln, n_sv, n_chrom, mix, seed = 10_000_000, 100_000, 4, "mixed", 20260517
+    inf = synth.generate(pre, 0, n_sv, n_chrom, mix, seed, write_gaf=False)
+    gaf = synth.gaf_bytes(inf["tables"], seed, 0, n_aln, threads=16)
 graph = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
 ctx = capi.Context(0); ctx.load_graph(graph); ctx.upload(gaf)
 for it in range(3):
