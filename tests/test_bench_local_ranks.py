@@ -134,3 +134,5 @@ def test_bench_under_the_launcher_two_ranks(tmp_path):
     assert ns["n_gpus"] == 2 and ns["alignments"] == 3000 and ns["alignments_per_gpu"] == 1500 and ns["passes"] == 3
     assert ns["digest_equal_across_ranks"] is True and len(ns["counts_digest"]) == 16 and ns["alignments_per_s"] > 0
     assert "allreduce_stream" in r["rccl"] and "debug_info" in r["rccl"]
+    ars = r["rccl"]["allreduce_stream"]                           # both placements of the pass's all-reduce were timed
+    assert ars["compute"]["ms_per_step"] > 0 and ars["second"]["steps"] >= 2 and ars["second"]["ms_per_step"] > 0

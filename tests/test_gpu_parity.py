@@ -1401,7 +1401,8 @@ def test_fused_pass_with_many_deferred_lines_under_a_communicator(tmp_path):
     wave per line is good for (16 384): the lane-per-line kernel is enqueued in the pass itself and reads the number on the device,
     so the pass's own all-reduce already sums complete counts — no repeat, ONE collective per pass —; and when the list of
     deferred lines overflows, the guard word that travels through the all-reduce makes the rank(s) repeat the pass with one more
-    collective (svjg_pass.h).  Both equal the step-by-step calls; with two passes in flight too."""
+    collective (svjg_pass.h).  Both equal the step-by-step calls; with two passes in flight too; and with the pass's all-reduce on either of
+    its two streams."""
     from svjg import capi, genotype, shard
     pre, gaf, g, orc = _synth_case(tmp_path, 40000, 1500, 3, "mixed", 35)
     rows = genotype.VcfRows(pre + ".vcf", g.slot_of)
@@ -1413,9 +1414,10 @@ def test_fused_pass_with_many_deferred_lines_under_a_communicator(tmp_path):
         c.load_graph(g)
         c.set_rows(rows.sv_type, rows.slot, rows.ok)
         shard.RcclGroup(c, 1, 0, lambda uid: uid)
-        for text, n_def in ((mid, 40000), (many, 160000), (gaf, None)):
+        for text, n_def, second in ((mid, 40000, False), (many, 160000, False), (gaf, None, False), (mid, 40000, True), (many, 160000, True), (gaf, None, True)):
             want = _step_by_step(c, text, rows)
             assert n_def is None or want[1]["n_deferred"] == n_def
+            c.allreduce_on_second_stream(second)                               # (bench.py measures both placements at N > 1: svjg_comm_set_stream)
             for _ in range(2):
                 gt, pl, raw, flags = (np.array(x) for x in c.run_resident(3, 0.00005))
                 assert np.array_equal(c.counts(), want[0]) and want[0].sum() > 0
