@@ -19,7 +19,7 @@ for W in $WL; do
   echo "== $W: kernel trace" 
   rocprofv3 --kernel-trace --stats -d $P/kt -o k --output-format csv -- $B --steps 10 --warmup 2 > $P/kt.log 2>&1
   cp $(ls $P/kt/*kernel_stats.csv | head -1) $O/kernel_stats_bench_$W.csv
-  tail -1 $P/kt.log > $O/bench_${W}_under_kernel_trace.json
+  grep '^{' $P/kt.log | tail -1 > $O/bench_${W}_under_kernel_trace.json
   i=0
   for grp in "fetch_size:FETCH_SIZE" "write_size:WRITE_SIZE" "sq_group1:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
              "sq_group2:SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
