@@ -968,13 +968,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 asm volatile("" : "=v"(r2.x), "=v"(r2.y), "=v"(r2.z), "=v"(r2.w), "=v"(r3.x), "=v"(r3.y), "=v"(r3.z), "=v"(r3.w));
                 if (probe) {
                     const uint4 *e = (const uint4 *)(g.name_tab + (size_t)name_slot(h, dsp, g.name_slots) * 16);
-#ifdef SVJG_HALFREC
-                    // measurement: the record's second half (its inline links; the tail of a name beyond 24 bytes) only for lanes that step on
-                    r0 = e[0]; r1 = e[1];
-                    if ((j + 1u < lk && lane + 1u < n_pass) || len > 24u) { r2 = e[2]; r3 = e[3]; }
-#else
                     r0 = e[0]; r1 = e[1]; r2 = e[2]; r3 = e[3];
-#endif
                 }
                 __builtin_amdgcn_s_setprio(P_REST);
                 uint32_t id = NONE32, lbp = 0;
