@@ -382,7 +382,7 @@ extern "C" int svjg_gaf_upload(svjg_ctx *c, const char *gaf, uint64_t n) {
 }
 
 extern "C" int svjg_gaf_upload_part(svjg_ctx *c, const char *gaf, uint64_t n, uint64_t offset, uint64_t capacity, int last) {
-    if (!c || (n && !gaf) || offset + n > capacity) return SVJG_E_ARG;
+    if (!c || (n && !gaf) || n > capacity || offset > capacity - n) return SVJG_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (offset == 0) {
         int rc = gaf_reserve(c, capacity, &c->part_need);
