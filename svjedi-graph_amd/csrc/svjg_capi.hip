@@ -169,7 +169,7 @@ extern "C" int svjg_init(int device, svjg_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     for (auto &ev : c->ev) hipEventCreate(&ev);
-    if (hipMalloc(&c->d_dbg, 16 * 8) != hipSuccess || hipMalloc(&c->d_st, sizeof(DevStatus)) != hipSuccess || hipMalloc(&c->d_maxn, sizeof(unsigned int)) != hipSuccess ||
+    if (hipMalloc(&c->d_dbg, 32 * 8) != hipSuccess || hipMalloc(&c->d_st, sizeof(DevStatus)) != hipSuccess || hipMalloc(&c->d_maxn, sizeof(unsigned int)) != hipSuccess ||
         hipHostMalloc((void **)&c->h_stp, 2 * sizeof(DevStatus), hipHostMallocDefault) != hipSuccess) {
         g_init_error = "hipMalloc failed";
         delete c;
@@ -505,7 +505,7 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         main_launch_setup(c, begin, end, base_offset, want_hits, a, grid, lds);
         if (!a.long_pre) { c->err = "no memory for the workers' scratch words"; return SVJG_E_NOMEM; }
 #ifdef SVJG_TIMING
-        if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 16 * 8, c->stream));
+        if (a.diag & 16u) HIPCHK(c, hipMemsetAsync(c->d_dbg, 0, 32 * 8, c->stream));
 #endif
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         hipLaunchKernelGGL(k_classify_main, dim3(grid), dim3(WG), lds, c->stream, a);
@@ -539,6 +539,14 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
             HIPCHK(c, hipMemcpyAsync(&c->hs(), c->d_st, sizeof(DevStatus), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipEventElapsedTime(&c->ms_slow, c->ev[2], c->ev[3]));
+#ifdef SVJG_TIMING
+            if (a.diag & 16u) {
+                unsigned long long d[8];
+                HIPCHK(c, hipMemcpy(d, c->d_dbg + 16, sizeof d, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[svjg diag] one wave per line, the longest any line took per step (counter ticks): terminator + staging %llu  per-line part %llu  piece table %llu  nodes %llu  links %llu\n",
+                        d[0], d[1], d[2], d[3], d[4]);
+            }
+#endif
         }
         HIPCHK(c, hipEventElapsedTime(&c->ms_main, c->ev[0], c->ev[1]));
         if (!c->hs().overflow) {

@@ -10,6 +10,7 @@
 //   k_genotype       one VCF row per lane, fp64 / double-double likelihoods (predict-genotype.py:281-325)
 #pragma once
 #include <hip/hip_runtime.h>
+#define SVJG_TAB_AS __attribute__((address_space(3)))      // the exact routine's per-node scratch and piece tables are LDS arrays here (svjg_line.h)
 #include "svjg_line.h"
 #include "svjg_planes.h"
 #include "svjg_pass.h"
@@ -1339,7 +1340,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
                 rc = slow_prologue(t, s - a0, s - a0 + (e - s), ln);
                 if (!rc && ln.k >= 2) {
                     if (ln.k <= SLOW_LANE_NODES) {
-                        NodeScratch ns{c_id + lane, c_len + lane, c_rc + lane, c_strand + lane, SLOW_LANE_NODES, SLOW_TPB};
+                        NodeScratch ns{(SVJG_TAB_AS uint32_t *)c_id + lane, (SVJG_TAB_AS int64_t *)c_len + lane, (SVJG_TAB_AS uint8_t *)c_rc + lane, (SVJG_TAB_AS uint8_t *)c_strand + lane, SLOW_LANE_NODES, SLOW_TPB};
                         uint64_t order = 0;
                         rc = slow_wave_phase1(a.g, t, ln, ns, 0u, 1u, &order);
                         if (!rc) rc = slow_wave_phase2(a.g, ln, ns, em, 0u, 1u, &order);
@@ -1358,6 +1359,82 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
 // resolutions per lane where one lane per line needs O(k^2).  An error is the one the reference would meet first
 // (smallest position in its sequence of steps).
 constexpr uint32_t SLOW_NODES = 1024;                                  // path nodes the per-node scratch of one line holds
+
+// which of the eight bytes of w equal the byte c: bit i = byte i (exact)
+__device__ inline uint32_t eq_bytes8(uint64_t w, uint32_t c) {
+    const uint64_t x = w ^ (0x0101010101010101ull * c);
+    const uint64_t z = ~((((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x)) & 0x8080808080808080ull;
+    return (uint32_t)(((z >> 7) * 0x0102040810204080ull) >> 56);
+}
+// svjg_line.h: slow_prologue, shared out over the 64 lanes of the wave that has the line to itself (r04): the three walks over the line
+// that one lane makes eight bytes per step — the first twelve tabs, the last "id:f:", the path's nodes (the caller counts them while it
+// builds the table of the path's pieces) — take 1 KB per step here; the short parts (rstrip, the nine int() columns, the tag's value) run
+// in every lane as before.  Same results, same order of the exceptions.  o.k is left to the caller.
+typedef const __attribute__((address_space(3))) uint8_t *slow_lds_text;
+__device__ inline int slow_prologue_wave(slow_lds_text t, uint64_t s, uint64_t e, SlowLine &o, uint32_t lane) {
+    o.k = 0;
+    while (e > s && py_space(t[e - 1])) --e;
+    // the first twelve tabs of t[s, e)
+    uint32_t tp[12], nt = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) tp[i] = (uint32_t)e;
+    for (uint64_t base = s; base < e && nt < 12; base += 1024) {
+        const uint64_t p = base + (uint64_t)lane * 16;
+        uint32_t m = 0;
+        if (p < e) {
+            m = eq_bytes8(ld64(t, p), '\t') | (eq_bytes8(ld64(t, p + 8), '\t') << 8);
+            if (p + 16 > e) m &= (1u << (e - p)) - 1u;               // (bytes behind the line's end: whatever the buffer holds)
+        }
+        for (;;) {
+            const unsigned long long hit = __ballot(m != 0);
+            if (!hit || nt >= 12) break;
+            const int L = __builtin_ctzll(hit);
+            const uint32_t pos = (uint32_t)(base + (uint64_t)L * 16) + (uint32_t)__builtin_ctz((uint32_t)__shfl((int)m, L));
+#pragma unroll
+            for (int i = 0; i < 12; ++i) if ((uint32_t)i == nt) tp[i] = pos;
+            ++nt;
+            if ((int)lane == L) m &= m - 1u;
+        }
+    }
+    if (nt < 11) return SVJG_EXC_VALUE_ERROR;                         // fewer than twelve fields
+    auto fs = [&](int i) -> uint64_t { return i ? (uint64_t)tp[i - 1] + 1 : s; };
+    auto fe = [&](int i) -> uint64_t { return (uint64_t)tp[i]; };       // (tp[11] = e when the line has eleven tabs)
+    int64_t v6 = 0, v7 = 0, v8 = 0, v10 = 0;
+    {
+        int64_t v = 0;
+#define SVJG_COL(c, keep) do { if (!py_int(t, fs(c), fe(c), v)) return has_high(t, fs(c), fe(c)) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR; keep; } while (0)
+        SVJG_COL(1, (void)0); SVJG_COL(2, (void)0); SVJG_COL(3, (void)0); SVJG_COL(6, v6 = v); SVJG_COL(7, v7 = v); SVJG_COL(8, v8 = v);
+        SVJG_COL(9, (void)0); SVJG_COL(10, v10 = v); SVJG_COL(11, (void)0);
+#undef SVJG_COL
+    }
+    // the last "id:f:" of the line (:193-196)
+    {
+        unsigned long long mine = 0;                                  // position + 1 of the last one this lane saw
+        for (uint64_t base = s; base + 5 <= e; base += 1024) {
+            const uint64_t p = base + (uint64_t)lane * 16;
+            if (p + 5 <= e) {
+                uint32_t m = eq_bytes8(ld64(t, p), 'i') | (eq_bytes8(ld64(t, p + 8), 'i') << 8);
+                if (p + 16 + 4 > e) m &= (1u << (e - 4 - p)) - 1u;     // (an 'i' with fewer than four bytes behind it)
+                for (; m; m &= m - 1u) {
+                    const uint64_t q = p + (uint32_t)__builtin_ctz(m);
+                    if (t[q + 1] == 'd' && t[q + 2] == ':' && t[q + 3] == 'f' && t[q + 4] == ':') mine = q + 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d; d >>= 1) { const unsigned long long y = __shfl_xor(mine, d); mine = y > mine ? y : mine; }
+        if (mine) {
+            uint64_t a = mine - 1 + 5, b = a;
+            while (b < e && t[b] != '\t') ++b;
+            if (!py_float_ok(t, a, b)) return has_high(t, a, b) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR;
+        } else if (v10 == 0) return SVJG_EXC_ZERO_DIVISION;
+    }
+    o.ps = fs(5); o.pe = fe(5);
+    if (o.pe == o.ps) return SVJG_EXC_INDEX_ERROR;                  // p[0]
+    o.oriented = t[o.ps] == '<' || t[o.ps] == '>';
+    o.Tlen = v6; o.Ts = v7; o.Te = v8;
+    return 0;
+}
 __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a, uint64_t n_def_arg, uint64_t lo, uint64_t hi) {
     const uint64_t n_def = slow_n_def(a, n_def_arg, lo, hi);
     __shared__ __attribute__((aligned(16))) uint8_t stage[SLOW_LDS];
@@ -1365,9 +1442,19 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
     __shared__ uint32_t n_id[SLOW_NODES];
     __shared__ uint8_t n_rc[SLOW_NODES], n_strand[SLOW_NODES];
     __shared__ uint32_t n_piece[SLOW_NODES];                           // the path's pieces: start | length << 16 (svjg_line.h: strand_of_pieces)
+    __shared__ uint16_t n_colon[SLOW_NODES];                           // ... and where each has its ':' (piece_colons)
     const uint32_t lane = threadIdx.x;
+#ifdef SVJG_TIMING
+    // measurement only (SVJG_DIAG & 16): the longest any line took per step of this kernel (a.dbg[16 ..]: terminator + staging, per-line part,
+    // piece table, nodes, links)
+    unsigned long long wstamp = __builtin_readcyclecounter();
+#define wtick(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if ((a.diag & 16u) && lane == 0) atomicMax(&a.dbg[16 + (i)], t_ - wstamp); wstamp = t_; } while (0)
+#else
+#define wtick(i) do { } while (0)
+#endif
     for (uint64_t b = blockIdx.x; b < n_def; b += gridDim.x) {
         const uint64_t s = a.deferred[b];
+        wtick(7);
         // the terminator: 64 aligned 16-byte blocks per step
         const uint64_t a0 = s & ~15ull;
         uint64_t e = ~0ull;
@@ -1387,6 +1474,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
         const bool staged = span <= SLOW_LDS;
         if (staged) for (uint64_t o = (uint64_t)lane * 16; o < span; o += 1024) *(uint4 *)(stage + o) = *(const uint4 *)(a.gaf + a0 + o);
         __syncthreads();
+        wtick(0);
         SlowEmit em{&a, a.base_offset + s};
         uint64_t order = 0;
         int rc = 0;
@@ -1400,27 +1488,33 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
             typedef const __attribute__((address_space(3))) uint8_t *lds_text;
             const lds_text t = (lds_text)stage;
             SlowLine ln;
-            rc = slow_prologue(t, s - a0, s - a0 + (e - s), ln);        // per-line part: the same in every lane
+            rc = slow_prologue_wave(t, s - a0, s - a0 + (e - s), ln, lane);   // per-line part, shared out over the lanes (the same result in every lane)
+            wtick(1);
+            if (!rc) {
+                // the path's pieces, 64 bytes of the path per step: a piece starts at a byte that is no separator and has one (or the
+                // path's start) in front of it.  As many pieces as the path has nodes (extract_nodes keeps the non-empty ones)
+                const uint8_t sep1 = ln.oriented ? '<' : ',', sep2 = ln.oriented ? '>' : ',';
+                uint32_t run = 0;
+                for (uint64_t base = ln.ps; base < ln.pe; base += 64) {
+                    const uint64_t q = base + lane;
+                    bool st = false;
+                    if (q < ln.pe) {
+                        const uint8_t c = t[q], pc = q > ln.ps ? (uint8_t)t[q - 1] : sep1;
+                        st = c != sep1 && c != sep2 && (pc == sep1 || pc == sep2);
+                    }
+                    const unsigned long long m = __ballot(st);
+                    if (st) { const uint32_t i = run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); if (i < SLOW_NODES) n_piece[i] = (uint32_t)q; }
+                    run += (uint32_t)__popcll(m);
+                }
+                ln.k = run;
+                __syncthreads();
+            }
             if (!rc && ln.k >= 2) {
                 if (ln.k <= SLOW_NODES) {
-                    NodeScratch ns{n_id, n_len, n_rc, n_strand, SLOW_NODES};
-                    // the table of the path's pieces, 64 bytes of the path per step: a piece starts at a byte that is no separator and
-                    // has one (or the path's start) in front of it; its length: up to the separator(s) in front of the next piece
+                    NodeScratch ns{(SVJG_TAB_AS uint32_t *)n_id, (SVJG_TAB_AS int64_t *)n_len, (SVJG_TAB_AS uint8_t *)n_rc, (SVJG_TAB_AS uint8_t *)n_strand, SLOW_NODES};
+                    // the table of the path's pieces: start | length << 16, the length up to the separator(s) in front of the next piece
                     {
                         const uint8_t sep1 = ln.oriented ? '<' : ',', sep2 = ln.oriented ? '>' : ',';
-                        uint32_t run = 0;
-                        for (uint64_t base = ln.ps; base < ln.pe; base += 64) {
-                            const uint64_t q = base + lane;
-                            bool st = false;
-                            if (q < ln.pe) {
-                                const uint8_t c = t[q], pc = q > ln.ps ? (uint8_t)t[q - 1] : sep1;
-                                st = c != sep1 && c != sep2 && (pc == sep1 || pc == sep2);
-                            }
-                            const unsigned long long m = __ballot(st);
-                            if (st) { const uint32_t i = run + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); if (i < SLOW_NODES) n_piece[i] = (uint32_t)q; }
-                            run += (uint32_t)__popcll(m);
-                        }
-                        __syncthreads();
                         for (uint32_t i = lane; i < ln.k; i += 64) {
                             const uint32_t s0 = n_piece[i];
                             uint32_t e0 = i + 1 < ln.k ? n_piece[i + 1] - 1u : (uint32_t)ln.pe;
@@ -1428,14 +1522,17 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
                             n_len[i] = (int64_t)(e0 - s0);                   // (kept aside: the starts are still being read by the neighbours)
                         }
                         __syncthreads();
-                        for (uint32_t i = lane; i < ln.k; i += 64) n_piece[i] |= (uint32_t)n_len[i] << 16;
+                        for (uint32_t i = lane; i < ln.k; i += 64) { n_colon[i] = piece_colons(t, n_piece[i], (uint64_t)n_len[i]); n_piece[i] |= (uint32_t)n_len[i] << 16; }
                         __syncthreads();
                     }
+                    wtick(2);
                     // (the call fills `order`: result and order are separate statements, not two arguments of one call)
-                    const int r1 = slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order, n_piece);
+                    const int r1 = slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order, (const SVJG_TAB_AS uint32_t *)n_piece, (const SVJG_TAB_AS uint16_t *)n_colon);
                     rc = wave_min(r1, order);
                     __syncthreads();
+                    wtick(3);
                     if (!rc) { const int r2 = slow_wave_phase2(a.g, ln, ns, em, lane, 64u, &order); rc = wave_min(r2, order); }
+                    wtick(4);
                 } else { const int r3 = slow_line(a.g, t, s - a0, s - a0 + (e - s), em, lane, 64u, &order); rc = wave_min(r3, order); }   // a path of more nodes than the scratch holds
             }
         } else { const int r4 = slow_line(a.g, a.gaf, s, e, em, lane, 64u, &order); rc = wave_min(r4, order); }

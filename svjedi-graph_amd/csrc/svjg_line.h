@@ -17,6 +17,12 @@
 #ifndef SVJG_HD
 #define SVJG_HD __host__ __device__ inline __attribute__((always_inline))
 #endif
+// Where the exact routine's per-node scratch and its table of path pieces live: LDS in the kernels (they define SVJG_TAB_AS as the LDS
+// address space before this header: a plain pointer there is a FLAT pointer, and every read through one takes the long way round), plain
+// memory in tests/hostsim.
+#ifndef SVJG_TAB_AS
+#define SVJG_TAB_AS
+#endif
 // The exact routine's larger helpers are real calls (r04): inlined into the two exact-path kernels they cost 389 / 390 SGPR spills (saved
 // exec masks of deeply nested divergent code); as calls 0 / 8, with a stack of 544 bytes a lane, at the same kernel times
 // (profiles/r04/experiments/exact_path.txt).  -DSVJG_SLOW_INLINE builds the inlined form.
@@ -277,6 +283,14 @@ SVJG_HD bool bytes_eq(P t, uint64_t a, uint64_t b, uint64_t n) {
     return true;
 }
 
+// t[a, a + m) == t[b, b + m), eight bytes per step, for callers that have ALREADY found t[a + m, a + m + 8) == t[b + m, b + m + 8): the last
+// step may reach into those eight bytes (it reads nothing behind them)
+template <class P>
+SVJG_HD bool bytes_eq_before_tail(P t, uint64_t a, uint64_t b, uint64_t m) {
+    for (uint64_t i = 0; i < m; i += 8) if (ld64(t, a + i) != ld64(t, b + i)) return false;
+    return true;
+}
+
 struct NameRef { uint64_t s, e; };     // node name = t[s, e)
 
 // Node names of the path t[ps, pe), one after the other.  oriented: non-empty pieces between '<' / '>' ; otherwise the
@@ -412,7 +426,7 @@ SVJG_FN int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &stran
         // against the name's LAST eight bytes, one 8-byte read, and only then against the rest
         const uint64_t tail = ld64(t, nm.e - 8);
         for (uint64_t q = ps; q + n <= pe; ++q)
-            if (ld64(t, q + n - 8) == tail && bytes_eq(t, q, nm.s, n - 8)) {
+            if (ld64(t, q + n - 8) == tail && bytes_eq_before_tail(t, q, nm.s, n - 8)) {
                 if (q == ps) return SVJG_EXC_INDEX_ERROR;         // ""[-1]
                 strand = t[q - 1] == '>' ? 0u : 1u;
                 return 0;
@@ -433,10 +447,54 @@ SVJG_FN int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &stran
 // occurrence lies inside ONE piece, and the first occurrence is the first piece — in order — that holds the name, at its first offset.
 // Compared from the name's end (names of one path differ in their coordinates).  O(pieces) instead of O(bytes of the path) per name:
 // what makes a path of hundreds of nodes affordable for the one-wave-per-line kernel.
+// colon[i] (optional): where piece i has its ':' — offset of its only one from the piece's start | 1 << 14; 0: it has none; 2 << 14: several
+// (or a piece of 16 KB and more): every offset is tried (piece_colons).  A name with a ':' can only lie where its last ':' meets one of
+// the piece's: no ':' in the piece, no occurrence; one, ONE offset to try instead of (piece length - name length + 1) — a short name
+// against a long piece (another contig's node) was most of the search.
 template <class P>
-SVJG_FN int strand_of_pieces(P t, uint64_t ps, const uint32_t *pos, uint32_t n_pieces, NameRef nm, uint32_t &strand) {
+SVJG_HD uint16_t piece_colons(P t, uint64_t a, uint64_t L) {
+    uint32_t cnt = 0, last = 0;
+    for (uint64_t q = a; q < a + L; ++q) if (t[q] == ':') { ++cnt; last = (uint32_t)(q - a); }
+    return (uint16_t)(cnt == 0 ? 0u : (cnt == 1 && L < 16384u) ? (last | (1u << 14)) : (2u << 14));
+}
+template <class P>
+SVJG_FN int strand_of_pieces(P t, uint64_t ps, const SVJG_TAB_AS uint32_t *pos, const SVJG_TAB_AS uint16_t *colon, uint32_t n_pieces, NameRef nm, uint32_t &strand) {
     const uint64_t n = nm.e - nm.s;
     if (n == 0) return SVJG_EXC_VALUE_ERROR;                      // str.split("")
+    if (n >= 8) {
+        // as in strand_of: a candidate position is held against the name's last eight bytes first (one read; names of one path differ in
+        // their coordinates), then against the rest eight bytes per step.  ONE loop over (piece, offset): the lanes of a wave walk the
+        // pieces each with a name of its own, and nested loops made every lane wait, at every piece, for the lane with the most offsets
+        // to try there (a short name in a long piece) and for the one lane that is at its own piece (25 byte compares).
+        const uint64_t tail = ld64(t, nm.e - 8);
+        uint64_t cn = n;                                          // offset of the name's last ':' (n: it has none)
+        if (colon) for (uint64_t b = n; b; --b) if (t[nm.s + b - 1] == ':') { cn = b - 1; break; }
+        uint32_t i = 0;
+        uint64_t q = 0, last = 0;                                 // the piece in hand: candidate offsets q .. last (none: q > last)
+        bool have = false;
+        for (;;) {
+            if (!have) {
+                if (i >= n_pieces) return SVJG_EXC_INDEX_ERROR;   // unreachable: the name is part of the path
+                const uint64_t a = pos[i] & 0xFFFFu, L = pos[i] >> 16;
+                const uint32_t cw = cn < n ? colon[i] : (2u << 14);
+                ++i;
+                if (L < n) continue;
+                q = a; last = a + L - n; have = true;
+                if ((cw >> 14) == 0u) { have = false; continue; }
+                if ((cw >> 14) == 1u) {
+                    const uint64_t cp = cw & 0x3FFFu;
+                    if (cp < cn || a + cp - cn > last) { have = false; continue; }
+                    q = last = a + cp - cn;
+                }
+            }
+            if (ld64(t, q + n - 8) == tail && bytes_eq_before_tail(t, q, nm.s, n - 8)) {
+                if (q == ps) return SVJG_EXC_INDEX_ERROR;         // ""[-1]
+                strand = t[q - 1] == '>' ? 0u : 1u;
+                return 0;
+            }
+            if (++q > last) have = false;
+        }
+    }
     for (uint32_t i = 0; i < n_pieces; ++i) {
         const uint64_t a = pos[i] & 0xFFFFu, L = pos[i] >> 16;
         if (L < n) continue;
@@ -503,25 +561,33 @@ SVJG_FN int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
 // link is kept per node.  phase 1: lane l takes the nodes l (mod nlanes): strand of the name (str.split quirk), node id,
 // get_node_len or the exception it raises.  phase 2 (after a barrier): lane l takes the links l (mod nlanes).
 // stride: node j's entries sit at index j * stride (1: one line per array; 64: the lanes of a wave interleaved, one line per lane)
-struct NodeScratch { uint32_t *id; int64_t *len; uint8_t *rc; uint8_t *strand; uint32_t cap; uint32_t stride = 1; };
+struct NodeScratch { SVJG_TAB_AS uint32_t *id; SVJG_TAB_AS int64_t *len; SVJG_TAB_AS uint8_t *rc; SVJG_TAB_AS uint8_t *strand; uint32_t cap; uint32_t stride = 1; };
 
-// pieces: table of the path's pieces (strand_of_pieces), or nullptr: the path is searched byte by byte
+// pieces: table of the path's pieces (strand_of_pieces; colons: where each has its ':', optional), or nullptr: the path is searched byte by byte
 template <class P>
 SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeScratch &ns, uint32_t lane, uint32_t nlanes, uint64_t *order,
-                             const uint32_t *pieces = nullptr) {
+                             const SVJG_TAB_AS uint32_t *pieces = nullptr, const SVJG_TAB_AS uint16_t *colons = nullptr) {
     NameRef nm{0, 0}; uint64_t pos = ln.ps; bool more = true;
     if (pieces) {                                                    // node j is piece j (an unoriented path's node: the piece without its last byte)
         for (uint32_t j = lane; j < ln.k; j += nlanes) {
             nm.s = pieces[j] & 0xFFFFu; nm.e = nm.s + (pieces[j] >> 16) - (ln.oriented ? 0u : 1u);
             uint32_t st = 0;
-            int rc = strand_of_pieces(t, ln.ps, pieces, ln.k, nm, st);
+#ifndef SVJG_EXP_NOSTRAND
+            int rc = strand_of_pieces(t, ln.ps, pieces, colons, ln.k, nm, st);
             if (rc) { *order = (1ull << 32) | j; return rc; }
+#endif
             int64_t l1 = 0;
             ns.strand[j * ns.stride] = (uint8_t)st;
             bool alt;
+#ifdef SVJG_EXP_NORESOLVE
+            const uint32_t id = j; alt = false;
+            ns.id[j * ns.stride] = id;
+            ns.rc[j * ns.stride] = 0; l1 = 100;
+#else
             const uint32_t id = resolve_name(g, t, nm, &alt);      // (once: the id for the links, the form for get_node_len)
             ns.id[j * ns.stride] = id;
             ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1);
+#endif
             ns.len[j * ns.stride] = l1;
         }
         return 0;

@@ -72,7 +72,7 @@ def test_c_oracle_and_exact_device_routine(fuzz):
         except Exception as e:
             got = ("died", type(e).__name__)
         assert got == _want(c), ("C oracle", i, c["raw"])
-        for tables, wave in ((True, 0), (False, 0), (True, 1), (True, 2), (True, 3)):
+        for tables, wave in ((True, 0), (False, 0), (True, 1), (True, 2), (True, 3), (True, 4)):
             try:
                 cnt, _ = sim.classify(g, c["raw"], tables, wave)
                 got = ("ok", {g.sv_ids[j]: [int(cnt[j, 0]), int(cnt[j, 1])] for j in range(g.n_slots) if cnt[j].sum()})

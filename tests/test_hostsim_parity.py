@@ -20,7 +20,7 @@ def _as_dict(graph, counts):
     return {graph.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(graph.n_slots) if counts[i].sum()}
 
 
-@pytest.mark.parametrize("tables,wave", [(True, 0), (False, 0), (True, 1), (True, 2), (True, 3)], ids=["name_table", "sorted_table", "wave_lanes", "wave_two_phase", "lane_cached"])
+@pytest.mark.parametrize("tables,wave", [(True, 0), (False, 0), (True, 1), (True, 2), (True, 3), (True, 4)], ids=["name_table", "sorted_table", "wave_lanes", "wave_two_phase", "lane_cached", "wave_two_phase_every_offset"])
 @pytest.mark.parametrize("name", QUIRKS)
 def test_quirks(golden, name, tables, wave):
     q = f"{golden}/quirks"
