@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
 // per node in LDS — and after a barrier the links l (mod 64), which only add up what phase 1 left: O(k / 64) name
 // resolutions per lane where one lane per line needs O(k^2).  An error is the one the reference would meet first
 // (smallest position in its sequence of steps).
-constexpr uint32_t SLOW_NODES = 1024;                                  // path nodes the per-node scratch of one line holds
+constexpr uint32_t SLOW_NODES = 736;                                   // path nodes the per-node scratch of one line holds (28 bytes a node: three blocks' LDS fit a CU)
 
 // which of the eight bytes of w equal the byte c: bit i = byte i (exact)
 __device__ inline uint32_t eq_bytes8(uint64_t w, uint32_t c) {
@@ -1370,6 +1370,31 @@ __device__ inline uint32_t eq_bytes8(uint64_t w, uint32_t c) {
 // that one lane makes eight bytes per step — the first twelve tabs, the last "id:f:", the path's nodes (the caller counts them while it
 // builds the table of the path's pieces) — take 1 KB per step here; the short parts (rstrip, the nine int() columns, the tag's value) run
 // in every lane as before.  Same results, same order of the exceptions.  o.k is left to the caller.
+// svjg_line.h: slow_wave_phase2 for a line whose nodes all have a length (no exception waiting in a sum): the two sums of every link come
+// from ONE running sum over the path (P[j] = len[0] + ... + len[j], made in place by the caller, wrapping like the sums it replaces) and
+// list.index of a link's names (:269-271) from a table of first occurrences (first[j] = the first node with node j's id; the caller fills
+// it: j itself where the ids run one way) instead of four walks over the node list per link.
+template <class Emit>
+__device__ inline int slow_wave_links_summed(const GraphView &g, const SlowLine &ln, const SVJG_TAB_AS uint32_t *id, const SVJG_TAB_AS int64_t *P,
+                                             const SVJG_TAB_AS uint8_t *strand, const SVJG_TAB_AS uint32_t *first, Emit &emit, uint32_t lane, uint64_t *order) {
+    const uint64_t tot = (uint64_t)P[ln.k - 1];
+    for (uint32_t i = lane; i + 1 < ln.k; i += 64) {
+        const uint32_t lid = id[i], rid = id[i + 1];
+        if (lid == NONE32 || rid == NONE32) continue;
+        const uint32_t ei = edge_find(g, lid, strand[i], rid, strand[i + 1]);
+        if (ei == NONE32) continue;
+        const svjg_edge ed = g.edges[ei];
+        const uint32_t nh = ed.meta >> 2;
+        if (!nh) continue;
+        if (g.dover_list) { *order = (2ull << 32) | i; return SVJG_EXC_TYPE_ERROR; }   // int >= list (:269), before the right sum is formed
+        const uint32_t il = first[i], ir = first[i + 1];
+        const int64_t left = P[il], right = (int64_t)(tot - (ir ? (uint64_t)P[ir - 1] : 0ull));
+        if (left - ln.Ts >= (int64_t)g.d_over && right - (ln.Tlen - ln.Te - 1) >= (int64_t)g.d_over)
+            for (uint32_t j = 0; j < nh; ++j) { uint32_t hv = edge_hit(g, ed, j); emit(hv >> 1, hv & 1u); }
+    }
+    return 0;
+}
+
 typedef const __attribute__((address_space(3))) uint8_t *slow_lds_text;
 __device__ inline int slow_prologue_wave(slow_lds_text t, uint64_t s, uint64_t e, SlowLine &o, uint32_t lane) {
     o.k = 0;
@@ -1442,7 +1467,8 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
     __shared__ uint32_t n_id[SLOW_NODES];
     __shared__ uint8_t n_rc[SLOW_NODES], n_strand[SLOW_NODES];
     __shared__ uint32_t n_piece[SLOW_NODES];                           // the path's pieces: start | length << 16 (svjg_line.h: strand_of_pieces)
-    __shared__ uint16_t n_colon[SLOW_NODES];                           // ... and where each has its ':' (piece_colons)
+    __shared__ uint16_t n_colon[SLOW_NODES];                           // ... where each has its ':' (piece_colons)
+    __shared__ uint64_t n_key[SLOW_NODES];                             // ... and what stands around it (piece_key)
     const uint32_t lane = threadIdx.x;
 #ifdef SVJG_TIMING
     // measurement only (SVJG_DIAG & 16): the longest any line took per step of this kernel (a.dbg[16 ..]: terminator + staging, per-line part,
@@ -1522,16 +1548,47 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
                             n_len[i] = (int64_t)(e0 - s0);                   // (kept aside: the starts are still being read by the neighbours)
                         }
                         __syncthreads();
-                        for (uint32_t i = lane; i < ln.k; i += 64) { n_colon[i] = piece_colons(t, n_piece[i], (uint64_t)n_len[i]); n_piece[i] |= (uint32_t)n_len[i] << 16; }
+                        for (uint32_t i = lane; i < ln.k; i += 64) { const uint16_t cw = piece_colons(t, n_piece[i], (uint64_t)n_len[i]); n_colon[i] = cw; n_key[i] = piece_key(t, n_piece[i], cw); n_piece[i] |= (uint32_t)n_len[i] << 16; }
                         __syncthreads();
                     }
                     wtick(2);
                     // (the call fills `order`: result and order are separate statements, not two arguments of one call)
-                    const int r1 = slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order, (const SVJG_TAB_AS uint32_t *)n_piece, (const SVJG_TAB_AS uint16_t *)n_colon);
+                    const int r1 = slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order, (const SVJG_TAB_AS uint32_t *)n_piece, (const SVJG_TAB_AS uint16_t *)n_colon, (const SVJG_TAB_AS uint64_t *)n_key);
                     rc = wave_min(r1, order);
                     __syncthreads();
                     wtick(3);
-                    if (!rc) { const int r2 = slow_wave_phase2(a.g, ln, ns, em, lane, 64u, &order); rc = wave_min(r2, order); }
+                    if (!rc) {
+                        // has every node a length?  Then the links need no walks over the node list: a running sum in place, and a table of
+                        // first occurrences where the pieces were (they are not needed any more) — j itself where the ids run one way
+                        bool good = true, oneway = true;
+                        for (uint32_t i = lane; i < ln.k; i += 64) {
+                            const uint32_t x = n_id[i];
+                            good = good && n_rc[i] == 0;
+                            oneway = oneway && x != NONE32 && (i == 0 || (n_id[1] > n_id[0] ? x > n_id[i - 1] : x < n_id[i - 1]));
+                        }
+                        if (__ballot(!good) == 0ull) {
+                            oneway = __ballot(!oneway) == 0ull;
+                            __syncthreads();
+                            for (uint32_t j = lane; j < ln.k; j += 64) {
+                                uint32_t f = j;
+                                if (!oneway) { const uint32_t x = n_id[j]; if (x != NONE32) { f = 0; while (n_id[f] != x) ++f; } }
+                                n_piece[j] = f;
+                            }
+                            // every lane sums a run of consecutive nodes, the runs' totals are scanned across the lanes
+                            const uint32_t per = (ln.k + 63u) / 64u, j0 = lane * per < ln.k ? lane * per : ln.k, j1 = j0 + per < ln.k ? j0 + per : ln.k;
+                            unsigned long long sum = 0;
+                            for (uint32_t j = j0; j < j1; ++j) sum += (unsigned long long)n_len[j];
+                            unsigned long long inc = sum;
+#pragma unroll
+                            for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(inc, d); if ((int)lane >= d) inc += y; }
+                            unsigned long long run = inc - sum;
+                            for (uint32_t j = j0; j < j1; ++j) { run += (unsigned long long)n_len[j]; n_len[j] = (int64_t)run; }
+                            __syncthreads();
+                            const int r2 = slow_wave_links_summed(a.g, ln, (const SVJG_TAB_AS uint32_t *)n_id, (const SVJG_TAB_AS int64_t *)n_len, (const SVJG_TAB_AS uint8_t *)n_strand,
+                                                                  (const SVJG_TAB_AS uint32_t *)n_piece, em, lane, &order);
+                            rc = wave_min(r2, order);
+                        } else { const int r2 = slow_wave_phase2(a.g, ln, ns, em, lane, 64u, &order); rc = wave_min(r2, order); }
+                    }
                     wtick(4);
                 } else { const int r3 = slow_line(a.g, t, s - a0, s - a0 + (e - s), em, lane, 64u, &order); rc = wave_min(r3, order); }   // a path of more nodes than the scratch holds
             }

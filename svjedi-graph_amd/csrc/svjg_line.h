@@ -447,10 +447,12 @@ SVJG_FN int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &stran
 // occurrence lies inside ONE piece, and the first occurrence is the first piece — in order — that holds the name, at its first offset.
 // Compared from the name's end (names of one path differ in their coordinates).  O(pieces) instead of O(bytes of the path) per name:
 // what makes a path of hundreds of nodes affordable for the one-wave-per-line kernel.
-// colon[i] (optional): where piece i has its ':' — offset of its only one from the piece's start | 1 << 14; 0: it has none; 2 << 14: several
-// (or a piece of 16 KB and more): every offset is tried (piece_colons).  A name with a ':' can only lie where its last ':' meets one of
-// the piece's: no ':' in the piece, no occurrence; one, ONE offset to try instead of (piece length - name length + 1) — a short name
-// against a long piece (another contig's node) was most of the search.
+// colon[i]: where piece i has its ':' — offset of its only one from the piece's start | 1 << 14; 0: it has none; 2 << 14: several (or a
+// piece of 16 KB and more): every offset of such a piece is tried (piece_colons).  key[i]: for a piece with one ':', the eight bytes
+// around it, t[colon - 3, colon + 5) (piece_key).  A name with a ':' can only lie where its last ':' meets one of the piece's: no ':'
+// in the piece, no occurrence; one, ONE offset — and the name lies there only if the bytes around the two colons agree, which is asked
+// first: names of one path differ in their coordinates' leading digits or in their contig, so a pass over the table (three small reads a
+// piece) replaces (piece length - name length + 1) string compares per piece.
 template <class P>
 SVJG_HD uint16_t piece_colons(P t, uint64_t a, uint64_t L) {
     uint32_t cnt = 0, last = 0;
@@ -458,57 +460,50 @@ SVJG_HD uint16_t piece_colons(P t, uint64_t a, uint64_t L) {
     return (uint16_t)(cnt == 0 ? 0u : (cnt == 1 && L < 16384u) ? (last | (1u << 14)) : (2u << 14));
 }
 template <class P>
-SVJG_FN int strand_of_pieces(P t, uint64_t ps, const SVJG_TAB_AS uint32_t *pos, const SVJG_TAB_AS uint16_t *colon, uint32_t n_pieces, NameRef nm, uint32_t &strand) {
+SVJG_HD uint64_t piece_key(P t, uint64_t a, uint32_t cw) { return (cw >> 14) == 1u ? ld64(t, a + (cw & 0x3FFFu) - 3) : 0ull; }   // (a piece starts behind five columns: no underflow)
+
+// one candidate position of the name: true and the strand (or the IndexError of ""[-1]) if the name lies at q
+template <class P>
+SVJG_HD bool name_at(P t, uint64_t q, NameRef nm) {
+    const uint64_t n = nm.e - nm.s;
+    if (n >= 8) return ld64(t, q + n - 8) == ld64(t, nm.e - 8) && bytes_eq_before_tail(t, q, nm.s, n - 8);
+    return bytes_eq(t, q, nm.s, n);
+}
+
+// The strand of node j of the path (its name nm begins piece j): the char in front of the name's first occurrence (see above), which is
+// in one of the pieces in front of piece j, or else piece j's own start.
+template <class P>
+SVJG_FN int strand_of_pieces(P t, uint64_t ps, const SVJG_TAB_AS uint32_t *pos, const SVJG_TAB_AS uint16_t *colon, const SVJG_TAB_AS uint64_t *key,
+                             uint32_t j, NameRef nm, uint32_t &strand) {
     const uint64_t n = nm.e - nm.s;
     if (n == 0) return SVJG_EXC_VALUE_ERROR;                      // str.split("")
-    if (n >= 8) {
-        // as in strand_of: a candidate position is held against the name's last eight bytes first (one read; names of one path differ in
-        // their coordinates), then against the rest eight bytes per step.  ONE loop over (piece, offset): the lanes of a wave walk the
-        // pieces each with a name of its own, and nested loops made every lane wait, at every piece, for the lane with the most offsets
-        // to try there (a short name in a long piece) and for the one lane that is at its own piece (25 byte compares).
-        const uint64_t tail = ld64(t, nm.e - 8);
-        uint64_t cn = n;                                          // offset of the name's last ':' (n: it has none)
-        if (colon) for (uint64_t b = n; b; --b) if (t[nm.s + b - 1] == ':') { cn = b - 1; break; }
-        uint32_t i = 0;
-        uint64_t q = 0, last = 0;                                 // the piece in hand: candidate offsets q .. last (none: q > last)
-        bool have = false;
-        for (;;) {
-            if (!have) {
-                if (i >= n_pieces) return SVJG_EXC_INDEX_ERROR;   // unreachable: the name is part of the path
-                const uint64_t a = pos[i] & 0xFFFFu, L = pos[i] >> 16;
-                const uint32_t cw = cn < n ? colon[i] : (2u << 14);
-                ++i;
-                if (L < n) continue;
-                q = a; last = a + L - n; have = true;
-                if ((cw >> 14) == 0u) { have = false; continue; }
-                if ((cw >> 14) == 1u) {
-                    const uint64_t cp = cw & 0x3FFFu;
-                    if (cp < cn || a + cp - cn > last) { have = false; continue; }
-                    q = last = a + cp - cn;
-                }
-            }
-            if (ld64(t, q + n - 8) == tail && bytes_eq_before_tail(t, q, nm.s, n - 8)) {
-                if (q == ps) return SVJG_EXC_INDEX_ERROR;         // ""[-1]
-                strand = t[q - 1] == '>' ? 0u : 1u;
-                return 0;
-            }
-            if (++q > last) have = false;
+    uint64_t cn = n;                                              // offset of the name's last ':' (n: it has none, or there is no table)
+    if (colon && key) for (uint64_t b = n; b; --b) if (t[nm.s + b - 1] == ':') { cn = b - 1; break; }
+    uint64_t found = pos[j] & 0xFFFFu;
+    bool hit = false;
+    if (cn < n) {
+        uint64_t mask = 0;                                        // the bytes of the window t[colon - 3, colon + 5) that lie inside the name
+        for (uint32_t r = 0; r < 8; ++r) if (cn + r >= 3 && cn + r < n + 3) mask |= 0xFFull << (8 * r);
+        const uint64_t kn = ld64(t, nm.s + cn - 3) & mask;
+        for (uint32_t i = 0; i < j && !hit; ++i) {
+            const uint32_t cw = colon[i], pl = pos[i];            // (three reads that do not wait for each other)
+            const uint64_t ky = key[i];
+            const uint64_t a = pl & 0xFFFFu, L = pl >> 16, cp = cw & 0x3FFFu;
+            const bool one = (cw >> 14) == 1u && cp >= cn && L - cp >= n - cn && (ky & mask) == kn;
+            const bool many = (cw >> 14) == 2u && L >= n;
+            if (!(one || many)) continue;
+            if (one) { if (name_at(t, a + cp - cn, nm)) { found = a + cp - cn; hit = true; } }
+            else for (uint64_t q = a; q + n <= a + L && !hit; ++q) if (name_at(t, q, nm)) { found = q; hit = true; }
         }
-    }
-    for (uint32_t i = 0; i < n_pieces; ++i) {
-        const uint64_t a = pos[i] & 0xFFFFu, L = pos[i] >> 16;
-        if (L < n) continue;
-        for (uint64_t q = a; q + n <= a + L; ++q) {
-            uint64_t b = n;
-            while (b && t[q + b - 1] == t[nm.s + b - 1]) --b;
-            if (b == 0) {
-                if (q == ps) return SVJG_EXC_INDEX_ERROR;         // ""[-1]
-                strand = t[q - 1] == '>' ? 0u : 1u;
-                return 0;
-            }
+    } else
+        for (uint32_t i = 0; i < j && !hit; ++i) {
+            const uint64_t a = pos[i] & 0xFFFFu, L = pos[i] >> 16;
+            if (L < n) continue;
+            for (uint64_t q = a; q + n <= a + L && !hit; ++q) if (name_at(t, q, nm)) { found = q; hit = true; }
         }
-    }
-    return SVJG_EXC_INDEX_ERROR;                                  // unreachable: the name is part of the path
+    if (found == ps) return SVJG_EXC_INDEX_ERROR;                 // ""[-1]
+    strand = t[found - 1] == '>' ? 0u : 1u;
+    return 0;
 }
 
 // The per-line part of the exact routine (filter-alignments.py:184-198 read_gaf_line, :351-373 extract_nodes): columns,
@@ -563,31 +558,24 @@ SVJG_FN int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
 // stride: node j's entries sit at index j * stride (1: one line per array; 64: the lanes of a wave interleaved, one line per lane)
 struct NodeScratch { SVJG_TAB_AS uint32_t *id; SVJG_TAB_AS int64_t *len; SVJG_TAB_AS uint8_t *rc; SVJG_TAB_AS uint8_t *strand; uint32_t cap; uint32_t stride = 1; };
 
-// pieces: table of the path's pieces (strand_of_pieces; colons: where each has its ':', optional), or nullptr: the path is searched byte by byte
+// pieces: table of the path's pieces (strand_of_pieces; colons, keys: where each has its ':' and what stands around it, optional), or
+// nullptr: the path is searched byte by byte
 template <class P>
 SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeScratch &ns, uint32_t lane, uint32_t nlanes, uint64_t *order,
-                             const SVJG_TAB_AS uint32_t *pieces = nullptr, const SVJG_TAB_AS uint16_t *colons = nullptr) {
+                             const SVJG_TAB_AS uint32_t *pieces = nullptr, const SVJG_TAB_AS uint16_t *colons = nullptr, const SVJG_TAB_AS uint64_t *keys = nullptr) {
     NameRef nm{0, 0}; uint64_t pos = ln.ps; bool more = true;
     if (pieces) {                                                    // node j is piece j (an unoriented path's node: the piece without its last byte)
         for (uint32_t j = lane; j < ln.k; j += nlanes) {
             nm.s = pieces[j] & 0xFFFFu; nm.e = nm.s + (pieces[j] >> 16) - (ln.oriented ? 0u : 1u);
             uint32_t st = 0;
-#ifndef SVJG_EXP_NOSTRAND
-            int rc = strand_of_pieces(t, ln.ps, pieces, colons, ln.k, nm, st);
+            int rc = strand_of_pieces(t, ln.ps, pieces, colons, keys, j, nm, st);
             if (rc) { *order = (1ull << 32) | j; return rc; }
-#endif
             int64_t l1 = 0;
             ns.strand[j * ns.stride] = (uint8_t)st;
             bool alt;
-#ifdef SVJG_EXP_NORESOLVE
-            const uint32_t id = j; alt = false;
-            ns.id[j * ns.stride] = id;
-            ns.rc[j * ns.stride] = 0; l1 = 100;
-#else
             const uint32_t id = resolve_name(g, t, nm, &alt);      // (once: the id for the links, the form for get_node_len)
             ns.id[j * ns.stride] = id;
             ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1);
-#endif
             ns.len[j * ns.stride] = l1;
         }
         return 0;

@@ -56,7 +56,7 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
                 NodeScratch ns{id.data(), len.data(), nrc.data(), strand.data(), ln.k};
                 // the table of the path's pieces, as k_classify_slow_wave builds it (there 64 bytes per step); offsets relative to the line
                 // start like the kernel's staged copy (below 65536 for the lines the harness is given; longer ones: byte-by-byte search)
-                std::vector<uint32_t> pieces; std::vector<uint16_t> colons;
+                std::vector<uint32_t> pieces; std::vector<uint16_t> colons; std::vector<uint64_t> keys;
                 const uint8_t *tl = t + pos;
                 SlowLine ll = ln; ll.ps -= pos; ll.pe -= pos;
                 if (e - pos < 65536) {
@@ -71,13 +71,16 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
                         pieces[i] |= (e0 - pieces[i]) << 16;
                     }
                     if (!(g->flags & 64u))                                 // (flag 64, harness only: without the table of the pieces' colons)
-                        for (size_t i = 0; i < pieces.size(); ++i) colons.push_back(piece_colons(tl, pieces[i] & 0xFFFFu, pieces[i] >> 16));
+                        for (size_t i = 0; i < pieces.size(); ++i) {
+                            colons.push_back(piece_colons(tl, pieces[i] & 0xFFFFu, pieces[i] >> 16));
+                            keys.push_back(piece_key(tl, pieces[i] & 0xFFFFu, colons.back()));
+                        }
                     if (pieces.size() != ln.k) { *exc = 7; *err_off = pos; return SVJG_E_INPUT; }   // (harness self-check: pieces == nodes)
                 }
                 uint64_t best = ~0ull;
                 for (uint32_t lane = 0; lane < 64; ++lane) {
                     uint64_t order = 0;
-                    int r = pieces.empty() ? slow_wave_phase1(v, t, ln, ns, lane, 64u, &order) : slow_wave_phase1(v, tl, ll, ns, lane, 64u, &order, pieces.data(), colons.empty() ? nullptr : colons.data());
+                    int r = pieces.empty() ? slow_wave_phase1(v, t, ln, ns, lane, 64u, &order) : slow_wave_phase1(v, tl, ll, ns, lane, 64u, &order, pieces.data(), colons.empty() ? nullptr : colons.data(), keys.empty() ? nullptr : keys.data());
                     if (r && ((order << 3) | (uint64_t)r) < best) best = (order << 3) | (uint64_t)r;
                 }
                 if (best == ~0ull)
