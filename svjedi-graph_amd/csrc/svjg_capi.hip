@@ -525,10 +525,12 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         c->ms_slow = 0;
         if (n_def && !(c->hs().overflow & 1u)) {
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-            const uint64_t max_blocks = (uint64_t)c->n_cu * 4;              // 32 KB of LDS each: four per CU
+            const uint64_t max_blocks = (uint64_t)c->n_cu * 4;              // (53 KB of LDS each: three at a time per CU)
             const uint64_t lane_blocks = (uint64_t)c->n_cu * (160u * 1024u / (SLOW_LANE_LDS + 1024u));   // the lane-per-line kernel: as many as its staging buffer admits
-            if (n_def <= 16 * max_blocks) {
-                // few lines: one wave per line (latency of a line O(k) instead of O(k^2) name resolutions)
+            if (n_def <= 30 * max_blocks) {
+                // one wave per line: ~52 ns a line with every CU busy (10 k ordinary lines 0.53 ms); the lane-per-line kernel needs ~1.6 ms
+                // for any number of lines (sixty-four lines with sixty-four control flows share a wave) and ~4 ns for every further one:
+                // they meet at ~31 k lines (profiles/r04/experiments/exact_path.txt)
                 hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)(n_def < max_blocks ? n_def : max_blocks)), dim3(SLOW_TPB), 0, c->stream, a, n_def, 0ull, 0ull);
             } else {
                 const uint64_t want_blocks = (n_def + SLOW_TPB - 1) / SLOW_TPB;
@@ -545,6 +547,10 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
                 HIPCHK(c, hipMemcpy(d, c->d_dbg + 16, sizeof d, hipMemcpyDeviceToHost));
                 fprintf(stderr, "[svjg diag] one wave per line, the longest any line took per step (counter ticks): terminator + staging %llu  per-line part %llu  piece table %llu  nodes %llu  links %llu\n",
                         d[0], d[1], d[2], d[3], d[4]);
+                unsigned long long l[5];
+                HIPCHK(c, hipMemcpy(l, c->d_dbg + 24, sizeof l, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[svjg diag] one lane per line, ticks summed over the blocks of 64 lines: terminators + staging %llu  per-line part %llu  nodes %llu  links %llu  rest %llu\n",
+                        l[0], l[1], l[2], l[3], l[4]);
             }
 #endif
         }

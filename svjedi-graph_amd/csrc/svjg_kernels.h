@@ -1305,8 +1305,16 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
     __shared__ uint32_t c_id[SLOW_LANE_NODES * SLOW_TPB];
     __shared__ uint8_t c_rc[SLOW_LANE_NODES * SLOW_TPB], c_strand[SLOW_LANE_NODES * SLOW_TPB];
     const uint32_t lane = threadIdx.x;
+#ifdef SVJG_TIMING
+    // measurement only (SVJG_DIAG & 16): the longest any block of 64 lines took per step (a.dbg[24 ..]: terminators + staging, per-line part, nodes, links)
+    unsigned long long lstamp = __builtin_readcyclecounter();
+#define ltick(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if ((a.diag & 16u) && lane == 0) atomicAdd(&a.dbg[24 + (i)], t_ - lstamp); lstamp = t_; } while (0)
+#else
+#define ltick(i) do { } while (0)
+#endif
     for (uint64_t b0 = (uint64_t)blockIdx.x * SLOW_TPB; b0 < n_def; b0 += (uint64_t)gridDim.x * SLOW_TPB) {
         const bool have = b0 + lane < n_def;
+        ltick(4);
         uint64_t s = 0, e = 0;
         if (have) {
             s = a.deferred[b0 + lane];
@@ -1328,6 +1336,7 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
         if (staged)
             for (uint32_t o = 0; o < want; o += 16) *(uint4 *)(stage + off + o) = *(const uint4 *)(a.gaf + a0 + o);
         __syncthreads();
+        ltick(0);
         if (have) {
             // two instances of the string routine: on a pointer the compiler knows to be LDS (ds_read_u8 per byte) and on
             // global memory; one generic pointer would turn every byte access into a flat load (~10x slower per line)
@@ -1338,12 +1347,15 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow(ClassifyArgs a, uint
                 const lds_text t = (lds_text)(stage + off);
                 SlowLine ln;
                 rc = slow_prologue(t, s - a0, s - a0 + (e - s), ln);
+                ltick(1);
                 if (!rc && ln.k >= 2) {
                     if (ln.k <= SLOW_LANE_NODES) {
                         NodeScratch ns{(SVJG_TAB_AS uint32_t *)c_id + lane, (SVJG_TAB_AS int64_t *)c_len + lane, (SVJG_TAB_AS uint8_t *)c_rc + lane, (SVJG_TAB_AS uint8_t *)c_strand + lane, SLOW_LANE_NODES, SLOW_TPB};
                         uint64_t order = 0;
                         rc = slow_wave_phase1(a.g, t, ln, ns, 0u, 1u, &order);
+                        ltick(2);
                         if (!rc) rc = slow_wave_phase2(a.g, ln, ns, em, 0u, 1u, &order);
+                        ltick(3);
                     } else rc = slow_line(a.g, t, s - a0, s - a0 + (e - s), em);
                 }
             } else rc = slow_line(a.g, a.gaf, s, e, em);

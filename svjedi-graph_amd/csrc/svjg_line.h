@@ -327,7 +327,7 @@ SVJG_HD void name_windows_inline(P t, uint64_t s, uint32_t len, uint32_t d[NAME_
 // Node-name table of the main kernel (svjg_host_tables.h), probed with the raw bytes of a name of 1..48 bytes:
 // node id, or NONE32 when the name's slot does not hold this spelling.
 template <class P>
-SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
+SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm, int64_t *len_bp = nullptr) {   // len_bp: the node's length from its record, or -1 (none there)
     const uint32_t len = (uint32_t)(nm.e - nm.s);
     uint32_t d[NAME_WORDS];
     name_windows_inline(t, nm.s, len, d);
@@ -348,12 +348,14 @@ SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm) {
             if (c[2] != d[8] || c[3] != d[9] || f[0] != d[10] || f[1] != d[11]) return NONE32;
         }
     }
+    if (len_bp) *len_bp = (meta & NAME_FLAG_NOLEN) ? -1 : (int64_t)(b[3] & 0x7FFFFFFFu);      // (record word 7: length in bp | "no other links" << 31)
     return g.node_of_kid[meta >> NAME_ID_SHIFT];
 }
 
 // exact name -> node id (only canonical spellings can be in the table)
 template <class P>
-SVJG_FN uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_form) {
+SVJG_FN uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_form, int64_t *tab_len = nullptr) {
+    if (tab_len) *tab_len = -1;
     uint64_t colon = nm.e;
     for (uint64_t q = nm.e; q > nm.s; --q) if (t[q - 1] == ':') { colon = q - 1; break; }
     if (is_alt_form) {
@@ -362,7 +364,7 @@ SVJG_FN uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_
     }
     if (colon == nm.e) return NONE32;
     if (g.name_tab && nm.e - nm.s <= 4 * NAME_WORDS) {                             // the canonical spelling is the only one that resolves
-        uint32_t id = name_tab_find(g, t, nm);
+        uint32_t id = name_tab_find(g, t, nm, tab_len);
         if (id != NONE32 || g.name_complete) return id;
     }
     uint32_t h = FNV_INIT;
@@ -388,9 +390,12 @@ SVJG_FN uint32_t resolve_name(const GraphView &g, P t, NameRef nm, bool *is_alt_
     return id;
 }
 
-// get_node_len (filter-alignments.py:343-349): 0 = ok, else the exception class.  (id, alt): what resolve_name said about the name
+// get_node_len (filter-alignments.py:343-349): 0 = ok, else the exception class.  (id, alt, tab_len): what resolve_name said about the
+// name.  tab_len >= 0: the name is a node's one canonical spelling and its record holds the length — for a reference node exactly what
+// int(end) - int(start) + 1 gives on that spelling, without reading the name again.
 template <class P>
-SVJG_HD int node_len_resolved(const GraphView &g, P t, NameRef nm, uint32_t id, bool alt, int64_t &len) {
+SVJG_HD int node_len_resolved(const GraphView &g, P t, NameRef nm, uint32_t id, bool alt, int64_t &len, int64_t tab_len = -1) {
+    if (!alt && id != NONE32 && tab_len >= 0) { len = tab_len; return 0; }
     if (alt) {
         if (id == NONE32 || g.nodes[id].aux == SVJG_LEN_UNKNOWN || !((g.nodes[id].key >> 15) & 1)) return SVJG_EXC_KEY_ERROR;
         len = g.nodes[id].aux;
@@ -412,8 +417,17 @@ SVJG_HD int node_len_resolved(const GraphView &g, P t, NameRef nm, uint32_t id, 
 template <class P>
 SVJG_HD int generic_node_len(const GraphView &g, P t, NameRef nm, int64_t &len) {
     bool alt;
-    const uint32_t id = resolve_name(g, t, nm, &alt);
-    return node_len_resolved(g, t, nm, id, alt, len);
+    int64_t tl;
+    const uint32_t id = resolve_name(g, t, nm, &alt, &tl);
+    return node_len_resolved(g, t, nm, id, alt, len, tl);
+}
+
+// one candidate position of the name: does the name lie at q?
+template <class P>
+SVJG_HD bool name_at(P t, uint64_t q, NameRef nm) {
+    const uint64_t n = nm.e - nm.s;
+    if (n >= 8) return ld64(t, q + n - 8) == ld64(t, nm.e - 8) && bytes_eq_before_tail(t, q, nm.s, n - 8);
+    return bytes_eq(t, q, nm.s, n);
 }
 
 // char before the first occurrence of the name as a substring of the path (filter-alignments.py:206)
@@ -421,6 +435,25 @@ template <class P>
 SVJG_FN int strand_of(P t, uint64_t ps, uint64_t pe, NameRef nm, uint32_t &strand) {
     uint64_t n = nm.e - nm.s;
     if (n == 0) return SVJG_EXC_VALUE_ERROR;                      // str.split("")
+    {
+        // a name with a ':' lies only where its last ':' meets a ':' of the path: the path's colons, in order (found eight bytes per step),
+        // give the candidate positions in order — one per node in front of the name instead of one per byte
+        uint64_t cn = n;
+        for (uint64_t b = n; b; --b) if (t[nm.s + b - 1] == ':') { cn = b - 1; break; }
+        if (cn < n) {
+            for (uint64_t c = find_byte(t, ps, pe, ':'); c < pe; c = find_byte(t, c + 1, pe, ':')) {
+                if (c < ps + cn) continue;
+                const uint64_t q = c - cn;
+                if (q + n > pe) break;
+                if (name_at(t, q, nm)) {
+                    if (q == ps) return SVJG_EXC_INDEX_ERROR;     // ""[-1]
+                    strand = t[q - 1] == '>' ? 0u : 1u;
+                    return 0;
+                }
+            }
+            return SVJG_EXC_INDEX_ERROR;                          // unreachable: the name is part of the path
+        }
+    }
     if (n >= 8) {
         // names of one path begin alike (the chromosome) and differ at their ends (the coordinates): a candidate position is first held
         // against the name's LAST eight bytes, one 8-byte read, and only then against the rest
@@ -461,14 +494,6 @@ SVJG_HD uint16_t piece_colons(P t, uint64_t a, uint64_t L) {
 }
 template <class P>
 SVJG_HD uint64_t piece_key(P t, uint64_t a, uint32_t cw) { return (cw >> 14) == 1u ? ld64(t, a + (cw & 0x3FFFu) - 3) : 0ull; }   // (a piece starts behind five columns: no underflow)
-
-// one candidate position of the name: true and the strand (or the IndexError of ""[-1]) if the name lies at q
-template <class P>
-SVJG_HD bool name_at(P t, uint64_t q, NameRef nm) {
-    const uint64_t n = nm.e - nm.s;
-    if (n >= 8) return ld64(t, q + n - 8) == ld64(t, nm.e - 8) && bytes_eq_before_tail(t, q, nm.s, n - 8);
-    return bytes_eq(t, q, nm.s, n);
-}
 
 // The strand of node j of the path (its name nm begins piece j): the char in front of the name's first occurrence (see above), which is
 // in one of the pieces in front of piece j, or else piece j's own start.
@@ -573,9 +598,10 @@ SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeSc
             int64_t l1 = 0;
             ns.strand[j * ns.stride] = (uint8_t)st;
             bool alt;
-            const uint32_t id = resolve_name(g, t, nm, &alt);      // (once: the id for the links, the form for get_node_len)
+            int64_t tl;
+            const uint32_t id = resolve_name(g, t, nm, &alt, &tl); // (once: the id for the links, the form and the record's length for get_node_len)
             ns.id[j * ns.stride] = id;
-            ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1);
+            ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1, tl);
             ns.len[j * ns.stride] = l1;
         }
         return 0;
@@ -588,9 +614,10 @@ SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeSc
         int64_t l1 = 0;
         ns.strand[j * ns.stride] = (uint8_t)st;
         bool alt;
-        const uint32_t id = resolve_name(g, t, nm, &alt);          // (once: the id for the links, the form for get_node_len)
+        int64_t tl;
+        const uint32_t id = resolve_name(g, t, nm, &alt, &tl);     // (once: the id for the links, the form and the record's length for get_node_len)
         ns.id[j * ns.stride] = id;
-        ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1);
+        ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1, tl);
         ns.len[j * ns.stride] = l1;
         NameRef skip{0, 0};
         for (uint32_t q = 1; q < nlanes && more; ++q) more = next_node(t, ln.pe, ln.oriented, pos, skip);
