@@ -1071,7 +1071,8 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         // the exact path, the number of deferred lines read on the device: one wave per line for up to wave_limit lines, one lane per
         // line beyond it (each kernel works only when the number lies in its range: a few microseconds otherwise).  So whatever a shard
         // defers is counted before the pass's all-reduce; only a LIST that overflowed makes the pass repeat (svjg_pass.h).  (One block per CU
-        // for the wave kernel: three would triple its rate and cost every pass that defers nothing 4 us: gpurun j32.)
+        // for the wave kernel: three would triple its rate and cost every pass that defers nothing 4 us; the lane kernel's 2 304 idle blocks
+        // cost such a pass 10 us, 0.85 % of the headline step — the price of never repeating a pass for deferred lines: gpurun j32 / j33.)
         hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)c->n_cu), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, 0ull, wave_limit);
         const uint64_t lane_blocks = (uint64_t)c->n_cu * (160u * 1024u / (SLOW_LANE_LDS + 1024u));
         hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)lane_blocks), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, wave_limit, ~0ull - 1);
