@@ -362,6 +362,18 @@ static int staged_upload(svjg_ctx *c, int fd, uint64_t offset, uint64_t n, uint6
     return 0;
 }
 
+// blocks of k_classify_slow a CU holds at a time (LDS and registers decide; asked of the runtime once, 5 on gfx950 today)
+static uint32_t lane_blocks_per_cu(svjg_ctx *c) {
+    static int per_cu = 0;
+    if (!per_cu) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_classify_slow, (int)SLOW_TPB, 0) != hipSuccess || n < 1) n = 4;
+        per_cu = n;
+    }
+    (void)c;
+    return (uint32_t)per_cu;
+}
+
 static int gaf_finish(svjg_ctx *c, uint64_t n, uint64_t need) {
     HIPCHK(c, hipMemsetAsync(c->d_gaf + n, 0, need - n, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -526,7 +538,7 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         if (n_def && !(c->hs().overflow & 1u)) {
             HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
             const uint64_t max_blocks = (uint64_t)c->n_cu * 4;              // (53 KB of LDS each: three at a time per CU)
-            const uint64_t lane_blocks = (uint64_t)c->n_cu * (160u * 1024u / (SLOW_LANE_LDS + 1024u));   // the lane-per-line kernel: as many as its staging buffer admits
+            const uint64_t lane_blocks = (uint64_t)c->n_cu * 9;           // the lane-per-line kernel: more blocks than the CUs hold at a time (5 each): the queue evens out the blocks' different times
             if (n_def <= 30 * max_blocks) {
                 // one wave per line: ~52 ns a line with every CU busy (10 k ordinary lines 0.53 ms); the lane-per-line kernel needs ~1.6 ms
                 // for any number of lines (sixty-four lines with sixty-four control flows share a wave) and ~4 ns for every further one:
@@ -1074,7 +1086,7 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         // for the wave kernel: three would triple its rate and cost every pass that defers nothing 4 us; the lane kernel's 2 304 idle blocks
         // cost such a pass 10 us, 0.85 % of the headline step — the price of never repeating a pass for deferred lines: gpurun j32 / j33.)
         hipLaunchKernelGGL(k_classify_slow_wave, dim3((uint32_t)c->n_cu), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, 0ull, wave_limit);
-        const uint64_t lane_blocks = (uint64_t)c->n_cu * (160u * 1024u / (SLOW_LANE_LDS + 1024u));
+        const uint64_t lane_blocks = (uint64_t)c->n_cu * lane_blocks_per_cu(c);   // (here as many as the CUs hold at a time: idle blocks cost every pass)
         hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)lane_blocks), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, wave_limit, ~0ull - 1);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(r.ev[2], c->stream));
