@@ -137,3 +137,8 @@ def test_random_graphs(seed):
     for tables in (True, False):
         counts, n_lines = sim.classify(g, text, tables=tables)
         assert n_lines == n and _as_dict(g, counts) == wd
+    # ... and so do the forms the kernels run it in: 64 cooperating lanes, the two-phase wave routine with its tables of path pieces (one
+    # candidate position per piece, asked of the eight bytes around the colons first) and without them, one lane with its per-node results kept
+    for wave in (1, 2, 3, 4):
+        counts, n_lines = sim.classify(g, text, True, wave)
+        assert n_lines == n and _as_dict(g, counts) == wd, wave
