@@ -950,6 +950,51 @@ def test_lines_longer_than_the_look_ahead(ctx, tmp_path):
         ctx.classify(np.frombuffer(cr, dtype=np.uint8))
 
 
+def test_exact_path_per_line_part_at_every_alignment(tmp_path):
+    """The one-wave-per-line kernel shares the line's per-line part out over its lanes, 16 bytes a lane and 1 KB a step (r04): the twelfth
+    tab, the last "id:f:" and the line's end are put at every position across a step's and a lane's boundary — read names of growing length
+    in front, tags of growing length behind —, with tags the reference accepts and tags it dies on.  Every line takes the exact path
+    (SVJG_GRAPH_ALL_SLOW); counts, line counts and exception classes are the C oracle's."""
+    import synth
+    from svjg import capi
+    from svjg.graph import Graph
+    pre = str(tmp_path / "c")
+    inf = synth.generate(pre, 4000, 300, 2, "mixed", 61, write_gaf=False, return_gaf=True)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", all_slow=True)
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    lines = [l for l in inf["gaf"].tobytes().split(b"\n")[:-1] if l.count(b">") + l.count(b"<") >= 3]
+    good, fatal = [], []
+    for k in range(0, 1100, 3):
+        base = lines[k % len(lines)]
+        name, rest = base.split(b"\t", 1)
+        for form in range(6):
+            if form == 0:   l = name + b"N" * k + b"\t" + rest                                   # everything shifted by k bytes
+            elif form == 1: l = base + b"\tzz:Z:" + b"A" * k + b"\tid:f:0.93"                     # the tag at the line's end, k bytes out
+            elif form == 2: l = base + b"\tid:f:0.93\tzz:Z:" + b"C" * k                          # ... in front of a long tag
+            elif form == 3: l = base + b"\tzz:Z:" + b"i" * k + b"\tid:f:1e-2" + b" " * (k % 5)   # many 'i', an exponent, trailing blanks
+            elif form == 4: l = base + b"\tzz:Z:" + b"G" * k + b"\tid:f:0.5\tid:f:x"             # the LAST tag decides: float("x")
+            else:           l = b"\t".join([name + b"M" * k] + base.split(b"\t")[1:12])              # twelve columns and no tag: eleven tabs, the last column ends the line
+            (fatal if form == 4 else good).append(l)
+    text = b"\n".join(good) + b"\n"
+    want, _, n_lines = orc.filter(text, want_hits=False)
+    c = capi.Context(0)
+    try:
+        c.load_graph(g)
+        c.classify(np.frombuffer(text, dtype=np.uint8))
+        assert _counts_dict(g, c.counts()) == _oracle_dict(orc, want) and want.sum() > 1000
+        st = c.stats()
+        assert st["n_lines"] == n_lines == st["n_deferred"]
+        for l in fatal[:: 7]:
+            one = good[0] + b"\n" + l + b"\n" + good[1] + b"\n"
+            with pytest.raises(ValueError):
+                orc.filter(one, want_hits=False)
+            c.reset_counts()
+            with pytest.raises(ValueError):
+                c.classify(np.frombuffer(one, dtype=np.uint8))
+    finally:
+        c.close()
+
+
 def test_sharded_and_chunked_ingest_is_the_same_file(golden, tmp_path, monkeypatch):
     """The drop-in filter cuts the GAF into one byte range per GPU and streams each range in chunks: two shards on one
     GPU and 64 KB chunks must give the same counts and the same _informative_aln.json, byte for byte, as one piece."""
