@@ -898,10 +898,19 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             // ---- node passes: up to 64 consecutive marks that cover whole lines; one mark (path node) per lane ----------------
             const wmask ok_lines = m_eq(status, ST_OK);                  // (lanes beyond cnt: ST_NONE)
             const uint32_t relend = rel + kall;
-            // a line of more than 64 nodes (wave-uniform state; the line is lane i0's): lsub = 0: none, else sub-pass number + 1 | sweep << 8 |
-            // "the line's last sub-pass" << 16; lS = length of the path in front of the sub-pass's first node (behind its last one once the
-            // sub-pass has its lengths), lTOT = the path's total length (after sweep 0), lD0 = which way its ids run (3: they turn)
-            uint32_t lsub = 0, lS = 0, lTOT = 0, lD0 = 0;
+            // A line of more than 64 nodes (wave-uniform state, all of it in three scalars; the line is lane i0's).  lsub = 0: none in hand; else
+            // bit 0 set, L_SWEEP1 the line's second sweep, L_MEASURE its first sweep only measures any more, L_FINAL the line's last
+            // sub-pass, bits 4-6 lD0 (which way its ids run: 1 / 2 rise / fall, 3 they turn, 4 a name comes twice), bits 8-15 lP (index of
+            // the sub-pass's first node), bits 16-23 lR (the first link not counted yet when the line went over to two sweeps); lS = length
+            // of the path in front of the sub-pass's first node; lTOT = the path's total length (second sweep).
+            constexpr uint32_t L_SWEEP1 = 2u, L_MEASURE = 4u, L_FINAL = 8u;
+            uint32_t lsub = 0, lS = 0, lTOT = 0;
+#define lD0 ((lsub >> 4) & 7u)
+#define lP ((lsub >> 8) & 0xFFu)
+#define lR ((lsub >> 16) & 0xFFu)
+#define SET_D0(v) (lsub = (lsub & ~0x70u) | ((uint32_t)(v) << 4))
+#define SET_P(v) (lsub = (lsub & ~0xFF00u) | ((uint32_t)(v) << 8))
+#define SET_R(v) (lsub = (lsub & ~0xFF0000u) | ((uint32_t)(v) << 16))
             for (uint32_t i0 = 0;;) {
                 uint32_t p0, n_pass;
                 wmask okl;
@@ -919,10 +928,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     i0 = i1;
                     if (!okl) continue;                                  // no line of the pass has a path to look at
                 } else {
-                    const uint32_t t63 = ((lsub & 0xFFu) - 1u) * 63u, K = rdlane(kall, i0);
-                    p0 = rdlane(rel, i0) + t63;
-                    n_pass = K - t63 < 64u ? K - t63 : 64u;
-                    lsub = (lsub & 0xFFFFu) | (K - t63 <= 64u ? 0x10000u : 0u);
+                    const uint32_t K = rdlane(kall, i0);
+                    p0 = rdlane(rel, i0) + lP;
+                    n_pass = K - lP < 64u ? K - lP : 64u;
+                    lsub = (lsub & ~L_FINAL) | (K - lP <= 64u ? L_FINAL : 0u);
                     okl = 1ull << i0;
                 }
                 __builtin_amdgcn_s_setprio(P_LOAD);
@@ -1009,23 +1018,20 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t dir = idr > id ? 1u : idr < id ? 2u : 0u;
                 bool l_dup = false, l_fail = false;
                 if (RARELY(lsub)) {
-                    // -- a sub-pass of a long line: the path's length in front of it and its total come from the sub-passes before;
-                    //    sweep 0 only measures (total length, does a name come twice, is every name known), sweep 1 counts --
+                    // -- a sub-pass of a long line: the path's length in front of it comes from the sub-passes before; the first sweep counts
+                    //    as it goes while no name has come twice (below), else it only measures (total length, is every name known) and a
+                    //    second sweep counts --
                     pre = gsum + lS; tot = lTOT;
-                    {
-                        const uint32_t inc = rdlane(gsum, (lsub & 0x10000u) ? n_pass - 1u : n_pass - 2u);   // (the last node of a sub-pass that is not the last is the next one's first)
-                        l_fail = lS + inc < lS;                          // (a path of 4 Gbp and more: the sums here are 32 bits wide)
-                        lS += inc;
-                    }
-                    if (!(lsub & 0x100u)) {
+                    l_fail = lS + rdlane(gsum, n_pass - 1u) < lS;        // (a path of 4 Gbp and more: the sums here are 32 bits wide)
+                    if (!(lsub & L_SWEEP1)) {
                         // Does a name come twice?  While the ids rise (or fall) all the way, no.  Once they turn, every node is held against
                         // the nodes of the sub-passes before it (their ids wait where the tab bitmap was: the line phase is over) and, further
                         // down, against those of its own sub-pass (the search every pass has for lines whose ids turn).  lD0: 1 / 2 the ids
                         // rise / fall, 3 they turn, 4 a name comes twice (sweep 1 then looks every first occurrence up).
-                        const uint32_t t63 = ((lsub & 0xFFu) - 1u) * 63u;
+                        const uint32_t t63 = lP;
                         uint32_t *IDS = tbm;
-                        if (t63 == 0u) lD0 = rdlane(dir, 0);
-                        if (lD0 < 3u && (step_m & (m_ne(dir, lD0) | m_eq(dir, 0u))) != 0ull) lD0 = 3u;
+                        if (t63 == 0u) SET_D0(rdlane(dir, 0));
+                        if (lD0 < 3u && (step_m & (m_ne(dir, lD0) | m_eq(dir, 0u))) != 0ull) SET_D0(3u);
                         if (live) {
                             IDS[t63 + lane] = id | (oribit << 31);
                             a.long_pre[(size_t)blockIdx.x * LONG_WORDS + t63 + lane] = pre;
@@ -1058,17 +1064,28 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
                 const bool revisits = m_ne(f, lane) != 0;                // wave-uniform: some line of the pass comes back to a node
-                if (RARELY(lsub) && !(lsub & 0x100u)) {
-                    // sweep 0 of a long line ends here: a name the table does not hold (its record says so already) -> the exact path; else on
-                    // to the next sub-pass, or to sweep 1 with the path's total length
+                bool one_sweep = false;
+                if (RARELY(lsub) && !(lsub & L_SWEEP1)) {
+                    // the first sweep over a long line.  A name the table does not hold (its record says so already) -> the exact path.
+                    // While the ids run one way and no name has come twice, the links are counted as the sweep goes (one_sweep): the path's
+                    // total length is not known yet, but the part measured so far is a lower bound of it, and a link whose right-hand overlap
+                    // holds against the bound holds; the next sub-pass begins at the first link that cannot be decided yet.  Once the ids turn,
+                    // or such a link is the sub-pass's first, the rest of the sweep only measures (0x200) and a second sweep counts what the
+                    // first has not (from link lR on).
                     if (live_m == 0ull || l_fail) {
                         if (live_m != 0ull) { if (lane == 0) ((uint32_t *)&RL[i0])[2] = (rdlane(meta, 0) & 0x00FFFFFFu) | ((ST_DEFER + DC_LONG_PATH) << 24); wave_sync(); }
                         ++i0; lsub = 0;
                         continue;
                     }
-                    if (revisits || l_dup) lD0 = 4u;
-                    if (lsub & 0x10000u) { lTOT = lS; lS = 0; lsub = 0x101u; } else ++lsub;
-                    continue;
+                    if (revisits || l_dup) SET_D0(4u);
+                    one_sweep = !(lsub & L_MEASURE) && lD0 < 4u;     // (3: the ids turn, but every node so far has been held against all nodes before it)
+                    if (one_sweep) tot = lS + rdlane(gsum, n_pass - 1u);
+                    else {
+                        if (!(lsub & L_MEASURE)) { lsub |= L_MEASURE; SET_R(lP); }
+                        if (lsub & L_FINAL) { lTOT = lS + rdlane(gsum, n_pass - 1u); lS = 0; lsub = (lsub & 0xFF0070u) | 1u | L_SWEEP1; }   // (the second sweep begins at the line's first node; lR and lD0 stay)
+                        else { lS += rdlane(gsum, n_pass - 2u); SET_P(lP + n_pass - 1u); }
+                        continue;
+                    }
                 }
                 // -- the link this node -> next node: the reference evaluates name and strand of the FIRST occurrence of both
                 //    (str.split / list.index, filter-alignments.py:206, :269-271); equal names have equal ids and hashes --
@@ -1085,7 +1102,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     // sweep 1 of a long line that comes back to a node: every node's first occurrence over the WHOLE line (list.index), its
                     // orientation there and the path length in front of it — the ids of all nodes wait in LDS, the running lengths in the
                     // worker's words of global memory (written in sweep 0 by this wave; read past the L1)
-                    const uint32_t t63 = ((lsub & 0xFFu) - 1u) * 63u, K = rdlane(kall, i0), upto = K < t63 + 64u ? K : t63 + 64u;
+                    const uint32_t t63 = lP, K = rdlane(kall, i0), upto = K < t63 + 64u ? K : t63 + 64u;
                     const uint32_t *IDS = tbm;
                     const uint32_t jg = t63 + lane;
                     uint32_t fg = jg;
@@ -1103,7 +1120,22 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // overlap test of the step (a lane without a step fails it); then the link is looked for among the (up to four)
                 // that sit in the left node's record — straight selects, no branches —; the link table is asked only if it is not
                 // there and the node has more links, or for a revisited node (the link between the first occurrences)
-                const wmask go_m = step_m & m_ge(pre_l, need_l) & m_ge(tot - ((int32_t)fr > (int32_t)lnb ? pre_rx : 0u), need_r);   // (lnb < 0: a sub-pass inside a long line)
+                wmask go_m = step_m & m_ge(pre_l, need_l) & m_ge(tot - ((int32_t)fr > (int32_t)lnb ? pre_rx : 0u), need_r);   // (lnb < 0: a sub-pass inside a long line)
+                if (RARELY(lsub)) {
+                    uint32_t adv = n_pass - 1u;                          // how far the line's next sub-pass begins behind this one
+                    if (one_sweep && !(lsub & L_FINAL)) {
+                        const wmask und_m = step_m & m_ge(pre_l, need_l) & ~go_m;   // the bound did not do: the rest of the path decides
+                        if (und_m) adv = (uint32_t)__builtin_ctzll(und_m);
+                        if (adv == 0u) {                                 // the sub-pass's first link: sixty-four nodes shorter than the overlap asked for — two sweeps
+                            lsub |= L_MEASURE; SET_R(lP);
+                            lS += rdlane(gsum, n_pass - 2u); SET_P(lP + n_pass - 1u);
+                            continue;
+                        }
+                        go_m &= low_bits64(adv);
+                    }
+                    if (lsub & L_SWEEP1) go_m &= m_ge(lP + lane, lR);      // (the second sweep: what the first has counted stays counted)
+                    if (!(lsub & L_FINAL)) { lS += rdlane(gsum, adv - 1u); SET_P(lP + adv); }   // (nothing below looks at lS or lP again)
+                }
                 const uint32_t want = (idr << 2) | orl | (orr << 1);
                 const wmask le24 = m_le(len, 24u), le32 = m_le(len, 32u);   // (a longer name's bytes sit where the first links would)
                 const wmask m0 = le24 & m_eq(r2.x, want), m1 = le32 & m_eq(r2.z, want), m2 = le32 & m_eq(r3.x, want), m3 = m_eq(r3.z, want);
@@ -1163,8 +1195,14 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     for (uint32_t jj = hp ? 0u : 1u; jj < n; ++jj) emit(hp ? hp[jj] : h1, jj);
                 }
                 tick(6);
-                if (RARELY(lsub)) { if (lsub & 0x10000u) { ++i0; lsub = 0; } else ++lsub; }   // (sweep 1 of a long line: its next sub-pass, or the next line)
+                if (RARELY(lsub) && (lsub & L_FINAL)) { ++i0; lsub = 0; }   // (a long line's last sub-pass: on to the next line)
             }
+#undef lD0
+#undef lP
+#undef lR
+#undef SET_D0
+#undef SET_P
+#undef SET_R
             wave_sync();
             // ---- R6: lines for the exact path ------------------------------------------------------------------
             {

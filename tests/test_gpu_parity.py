@@ -806,7 +806,7 @@ def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
 
 def test_paths_of_65_to_216_nodes(ctx, tmp_path):
     """Paths longer than one node pass (64 nodes) stay in the main kernel up to what a stripe's list of marks holds (216): sub-passes of
-    64 nodes that overlap by one, walked twice (total length and "does a name come twice" first, then the counts).  Lengths around every
+    64 nodes, counted in one sweep while no name has come twice (r04; else walked twice: total length first, then the counts).  Lengths around every
     sub-pass boundary, both directions, through insertion nodes, with margins that fail the overlap test at either end; paths whose ids
     turn without a name coming twice; paths that do come back to a node — mid-way, at a sub-pass boundary, right at the end, a whole
     stretch walked back the other way round (the reference takes name, strand and position of the FIRST occurrence: list.index /
@@ -878,6 +878,28 @@ def test_paths_of_65_to_216_nodes(ctx, tmp_path):
         w = ref[a0: a0 + lead + 1] + ref[100 + lead: 100 + lead + 80]
         for rev in (False, True):
             lines.append(line(f"jump{lead}r{int(rev)}", w, rev))
+    # r04: the first sweep counts as it goes — a link is counted once the part of the path measured so far proves its right-hand overlap,
+    # and the next sub-pass begins at the first link that is not proven yet.  Margins at the path's far end that leave the last 1, 2, 5,
+    # 20, 63, 64 and more nodes of every sub-pass undecided (up to "no link of a sub-pass can be decided": then two sweeps), at the near
+    # end too, in both directions, with a turn or a name twice behind the point where counting has begun
+    for k in (66, 128, 129, 190, 216):
+        w = walk(k, int(rng.integers(0, 300)))
+        tails = np.cumsum([nlen(n) for n in reversed(w)])
+        for back_nodes in (1, 2, 5, 20, 62, 63, 64, 65, k - 2):
+            if back_nodes >= k:
+                continue
+            for rev in (False, True):
+                ends = tails if not rev else np.cumsum([nlen(n) for n in w])
+                lines.append(line(f"m{k}b{back_nodes}r{int(rev)}", w, rev, te_back=int(ends[back_nodes - 1]) - 90))     # Tlen - Te - 1 + 100 ~ the last back_nodes nodes
+                lines.append(line(f"m{k}b{back_nodes}r{int(rev)}s", w, rev, ts=int(ends[min(back_nodes, 30) - 1]) // 2 + 3, te_back=int(ends[back_nodes - 1]) + 40))
+    for k, at in ((150, 100), (200, 140), (140, 70)):
+        w = walk(k, int(rng.integers(0, 300)))
+        dup = w[:at + 1] + [w[at - 1]] + w[at + 1:]                                                          # a name twice, far behind the first sub-pass
+        jmp = w[:at] + ref[20:20 + (k - at)]                                                                 # the ids turn there
+        for rev in (False, True):
+            for nm_, ww in (("late_dup", dup), ("late_jump", jmp)):
+                tl_tail = int(np.cumsum([nlen(n) for n in (reversed(ww) if not rev else ww)])[9])
+                lines.append(line(f"{nm_}{k}at{at}r{int(rev)}", ww, rev, te_back=tl_tail))
     body = inf["gaf"].tobytes()
     data = body[:150000].rsplit(b"\n", 1)[0] + b"\n" + b"".join(lines) + body[150000:].split(b"\n", 1)[1]
     want, hits, n_lines = orc.filter(data, want_hits=True)
