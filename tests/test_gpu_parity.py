@@ -584,7 +584,7 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
     names = [n for n in g.node_names if "." not in n.split(":")[-1]]          # reference nodes in genome order
     lens = {n: int(n.split(":")[1].split("-")[1]) - int(n.split(":")[1].split("-")[0]) + 1 for n in names}
     lines = []
-    for k, start in ((17, 3), (25, 40), (60, 100), (16, 200), (33, 300), (128, 350), (129, 10), (150, 500), (216, 420), (217, 30), (250, 333)):
+    for k, start in ((17, 3), (25, 40), (60, 100), (16, 200), (33, 300), (128, 350), (129, 10), (150, 500), (216, 420), (217, 30), (250, 333), (736, 5), (737, 9), (780, 2)):   # (beyond 736 nodes the one-wave-per-line kernel has no tables for the path: its older routine)
         path = names[start:start + k]
         tlen = sum(lens[n] for n in path)
         fwd = "".join(">" + n for n in path)
@@ -602,7 +602,7 @@ def test_long_paths_many_nodes_and_short_lines(ctx, tmp_path):
     # 217 / 250 nodes in both directions: more marks than a stripe's list holds (up to 216 nodes stay in the main kernel: sub-passes);
     # the line with the 9 KB tag has no stripe
     cause = ctx.defer_causes()
-    assert st["n_lines"] == n_lines and 4 <= st["n_deferred"] <= 8 and cause["long_path"] == 0, (st, cause)
+    assert st["n_lines"] == n_lines and 10 <= st["n_deferred"] <= 14 and cause["long_path"] == 0, (st, cause)
     # a stripe of lines shorter than any valid GAF line
     dense = b"x\t1\n" * 20000
     with pytest.raises(ValueError):
