@@ -86,10 +86,39 @@ __global__ __launch_bounds__(256) void k2_tables(A2 a) {
     if (acc == 0x12345678u) a.sink[0] = acc;
 }
 
-struct Workload { const char *name; uint64_t text; uint32_t rec_slots, buckets, count_slots; double nodes, hits; };
+// K3: "follow the path" with light waves — one ALIGNMENT per lane at a time: 8 bytes of a per-alignment stream read, the FIRST node through
+// the displacement array and its record, every further node of the path through its predecessor's record (records in walk order: the
+// next record lies right behind; the address still comes out of the record just read: a chain of k dependent 64-byte reads), a count
+// update for 76 % of the nodes.  k = 1 + (hash & 7) clipped so that the mean is the workload's nodes per alignment.
+struct A3 { const uint2 *stream; uint64_t n_aln; const uint16_t *disp; uint32_t n_buckets; const uint4 *recs; uint32_t n_recs;
+            unsigned int *counts; uint32_t n_counters; const uint32_t *hits; uint64_t n_hits; uint32_t hit_frac; uint32_t zero; uint32_t k_mean16; unsigned long long *sink; };
+__global__ __launch_bounds__(256) void k3_follow(A3 a) {
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_aln; i += stride) {
+        const uint2 al = a.stream[i];
+        const uint32_t d = a.disp[mulhi(al.x, a.n_buckets)];
+        uint32_t slot = mulhi(mix(al.x ^ 0x5bd1e995u), a.n_recs - 16u) + (d & a.zero);
+        const uint32_t k = 1u + ((mix(al.x + 9u) % 16u) * a.k_mean16 >> 7);     // 1 .. ~2 * mean - 1
+        for (uint32_t j = 0; j < k; ++j) {
+            const uint4 *e = a.recs + (size_t)slot * 4;
+            const uint4 r0 = e[0], r1 = e[1], r2 = e[2], r3 = e[3];
+            const uint32_t x = r0.x ^ r0.w ^ r1.z ^ r2.x ^ r2.z ^ r3.x ^ r3.z;
+            acc ^= x;
+            if ((mix(al.x + 77u + j) & 1023u) < a.hit_frac) {
+                const uint32_t hv = a.hits ? a.hits[(i * 7 / 2 + j) % a.n_hits] : mulhi(mix(al.x + 0x27D4EB2Fu + j), a.n_counters);
+                atomicAdd(&a.counts[hv + (x & a.zero)], 1u);
+            }
+            slot = slot + 1u + (x & a.zero);                                 // the successor: named by the record just read
+        }
+    }
+    if (acc == 0x12345678u) a.sink[0] = acc;
+}
+
+struct Workload { const char *name; uint64_t text; uint32_t rec_slots, buckets, count_slots; double nodes, hits, aln; };
 static const Workload WL[] = {
-    {"c3", 2133165175ull, 247631, 24763, 104881, 46.63e6, 35.53e6},        // (displacement buckets at eight names each, as shipped)
-    {"c4shard", 2693024596ull, 1237826, 123783, 524826, 58.22e6, 44.34e6},
+    {"c3", 2133165175ull, 247631, 24763, 104881, 46.63e6, 35.53e6, 10e6},  // (displacement buckets at eight names each, as shipped)
+    {"c4shard", 2693024596ull, 1237826, 123783, 524826, 58.22e6, 44.34e6, 12.5e6},
 };
 
 int main(int argc, char **argv) {
@@ -136,8 +165,12 @@ int main(int argc, char **argv) {
     hipEvent_t b1, e1, b2, e2; CHECK(hipEventCreate(&b1)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&b2)); CHECK(hipEventCreate(&e2));
     printf("split %s: %.3f GB of text, %llu stripes x %u nodes = %.1f M nodes (%.0f MB of node stream); K1 %d workers per CU, K2 %d waves per CU; %s count updates\n",
            w->name, w->text / 1e9, (unsigned long long)n_stripes, nps, n_nodes / 1e6, n_nodes * 8 / 1e6, w1, w2, hits_path ? "real" : "uniform");
-    for (int what = 0; what < 4; ++what) {
-        const bool run1 = what == 0 || what >= 2, run2 = what == 1 || what >= 2;
+    const uint64_t n_aln = (uint64_t)(w->aln);
+    A3 a3{}; a3.stream = stream_b; a3.n_aln = n_aln < n_nodes ? n_aln : n_nodes; a3.disp = disp; a3.n_buckets = w->buckets; a3.recs = recs; a3.n_recs = w->rec_slots;
+    a3.counts = counts; a3.n_counters = w->count_slots * 2; a3.hits = a2.hits; a3.n_hits = a2.n_hits; a3.hit_frac = a2.hit_frac; a3.sink = sink;
+    a3.k_mean16 = (uint32_t)((w->nodes / w->aln - 1.0) * 2.0 / 15.0 * 128.0 + 0.5);
+    for (int what = 0; what < 6; ++what) {
+        const bool run1 = what == 0 || what == 2 || what == 3 || what == 5, run2 = what == 1 || what == 2 || what == 3, run3 = what == 4 || what == 5;
         a2.mode = what == 3 ? 1u : 0u;
         float best = 1e9f, sum = 0, s1sum = 0, s2sum = 0;
         for (int i = 0; i < reps + 2; ++i) {
@@ -145,16 +178,18 @@ int main(int argc, char **argv) {
             CHECK(hipDeviceSynchronize());
             if (run1) { CHECK(hipEventRecord(b1, s1)); hipLaunchKernelGGL(k1_text, dim3(grid1), dim3(WG), LDS_WORKER, s1, a1); CHECK(hipEventRecord(e1, s1)); }
             if (run2) { CHECK(hipEventRecord(b2, s2)); hipLaunchKernelGGL(k2_tables, dim3(grid2), dim3(256), 0, s2, a2); CHECK(hipEventRecord(e2, s2)); }
+            if (run3) { CHECK(hipEventRecord(b2, s2)); hipLaunchKernelGGL(k3_follow, dim3(grid2), dim3(256), 0, s2, a3); CHECK(hipEventRecord(e2, s2)); }
             CHECK(hipDeviceSynchronize());
             float m1 = 0, m2 = 0, span = 0;
             if (run1) CHECK(hipEventElapsedTime(&m1, b1, e1));
-            if (run2) CHECK(hipEventElapsedTime(&m2, b2, e2));
-            if (run1 && run2) { float x; CHECK(hipEventElapsedTime(&x, b1, e2)); float y; CHECK(hipEventElapsedTime(&y, b1, e1)); span = x > y ? x : y; }
+            if (run2 || run3) CHECK(hipEventElapsedTime(&m2, b2, e2));
+            if (run1 && (run2 || run3)) { float x; CHECK(hipEventElapsedTime(&x, b1, e2)); float y; CHECK(hipEventElapsedTime(&y, b1, e1)); span = x > y ? x : y; }
             else span = run1 ? m1 : m2;
             if (i >= 2) { sum += span; best = span < best ? span : best; s1sum += m1; s2sum += m2; }
         }
         static const char *names[] = {"K1 alone (text -> node stream)", "K2 alone (node stream -> displacement -> record -> count update)", "both at once",
-                                      "both at once, K2 with a 32-byte record (two loads)"};
+                                      "both at once, K2 with a 32-byte record (two loads)",
+                                      "K3 alone (one alignment per lane: first node by name, the rest through the record before)", "K1 and K3 at once"};
         printf("  %-68s  span mean %.4f ms  best %.4f ms   (K1 %.4f, K2 %.4f)\n", names[what], sum / reps, best, s1sum / reps, s2sum / reps);
     }
     return 0;
