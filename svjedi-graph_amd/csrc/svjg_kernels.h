@@ -52,8 +52,9 @@ constexpr uint32_t KLONG = KMAX;                 // (measurement variant: the pe
 #else
 constexpr uint32_t KLONG = CAP_O < 255u ? CAP_O : 255u;
 #endif
-constexpr uint32_t LONG_WORDS = 256;             // per worker, in global memory: the running path length behind every node of a long line (ClassifyArgs::long_pre)
-static_assert(KLONG <= LONG_WORDS && KLONG * 4 <= TEXT / 8 + 16, "a long line's per-node words fit their places");
+constexpr uint32_t LONG_LOG = 256;               // per worker, in global memory: [0, LONG_LOG) the running path length behind every node of a long line,
+constexpr uint32_t LONG_WORDS = 3 * LONG_LOG;    // [LONG_LOG, 3 * LONG_LOG) two words per link: the hits a first sweep has found and holds back (ClassifyArgs::long_pre)
+static_assert(KLONG <= LONG_LOG && KLONG * 4 <= TEXT / 8 + 16, "a long line's per-node words fit their places");
 constexpr uint32_t LRW = MAXL;                   // lines per round
 static_assert(TEXT + 1 < 65535, "text offsets are kept in 16 bits, 0xFFFF = none");
 
@@ -116,7 +117,7 @@ struct ClassifyArgs {
     uint64_t *host_lines; uint64_t host_cap;
     DevStatus *st;
     unsigned long long *dbg;             // measurement only (SVJG_DIAG & 16): per-phase cycle sums of lane 0 of every worker
-    uint32_t *long_pre;                  // LONG_WORDS words per worker: running path length behind every node of a long line (written in sweep 0, read in sweep 1 by a line that comes back to a node)
+    uint32_t *long_pre;                  // LONG_WORDS words per worker: running path length behind every node of a long line (written in sweep 0, read in sweep 1 by a line that comes back to a node), and the hits of its links, held back until the line's last name is known
 };
 
 // (the exact-path kernels look for a line's end with these)
@@ -245,6 +246,14 @@ __device__ inline bool name_match(const uint4 r0, const uint4 r1, const uint4 r2
 }
 
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in order, the fences only pin the compiler
+// A worker's words in global memory (ClassifyArgs::long_pre) are written by some lanes of the wave and read later by others: worker = wave =
+// workgroup, so workgroup scope orders them (the stores have left the wave before the loads are issued; both meet in the CU's L1 / the L2).
+// (Agent-scope fences write the XCD's L2 back and invalidate it: +3.5 ms a launch on the long-read block, measured.)
+__device__ inline void long_words_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ inline void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -901,9 +910,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
             // A line of more than 64 nodes (wave-uniform state, all of it in three scalars; the line is lane i0's).  lsub = 0: none in hand; else
             // bit 0 set, L_SWEEP1 the line's second sweep, L_MEASURE its first sweep only measures any more, L_FINAL the line's last
             // sub-pass, bits 4-6 lD0 (which way its ids run: 1 / 2 rise / fall, 3 they turn, 4 a name comes twice), bits 8-15 lP (index of
-            // the sub-pass's first node), bits 16-23 lR (the first link not counted yet when the line went over to two sweeps); lS = length
-            // of the path in front of the sub-pass's first node; lTOT = the path's total length (second sweep).
-            constexpr uint32_t L_SWEEP1 = 2u, L_MEASURE = 4u, L_FINAL = 8u;
+            // the sub-pass's first node), bits 16-23 lR (the first link not counted yet when the line went over to two sweeps), L_ONE this
+            // sub-pass of the first sweep decides links as it goes; lS = length of the path in front of the sub-pass's first node; lTOT =
+            // the path's total length (second sweep).
+            constexpr uint32_t L_SWEEP1 = 2u, L_MEASURE = 4u, L_FINAL = 8u, L_ONE = 1u << 24;
             uint32_t lsub = 0, lS = 0, lTOT = 0;
 #define lD0 ((lsub >> 4) & 7u)
 #define lP ((lsub >> 8) & 0xFFu)
@@ -931,7 +941,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t K = rdlane(kall, i0);
                     p0 = rdlane(rel, i0) + lP;
                     n_pass = K - lP < 64u ? K - lP : 64u;
-                    lsub = (lsub & ~L_FINAL) | (K - lP <= 64u ? L_FINAL : 0u);
+                    lsub = (lsub & ~(L_FINAL | L_ONE)) | (K - lP <= 64u ? L_FINAL : 0u);
                     okl = 1ull << i0;
                 }
                 __builtin_amdgcn_s_setprio(P_LOAD);
@@ -989,7 +999,8 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = r1.w >> 31; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
                 // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
-                // (all nodes of a line sit in this pass).  Ordinary text never gets here.
+                // (all nodes of a line sit in this pass — or the line is a long one, none of whose links has been counted yet: what its
+                // earlier sub-passes found waits in the worker's log).  Ordinary text never gets here.
                 {
                     const wmask bad = live_m & (m_eq(id, NONE32) | m_ge(lbp, 1u << 25));
                     if (RARELY(bad)) {
@@ -1034,7 +1045,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         if (lD0 < 3u && (step_m & (m_ne(dir, lD0) | m_eq(dir, 0u))) != 0ull) SET_D0(3u);
                         if (live) {
                             IDS[t63 + lane] = id | (oribit << 31);
-                            a.long_pre[(size_t)blockIdx.x * LONG_WORDS + t63 + lane] = pre;
+                            __hip_atomic_store(a.long_pre + (size_t)blockIdx.x * LONG_WORDS + t63 + lane, pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         if (lD0 == 3u) {
                             wave_sync();
@@ -1064,25 +1075,26 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                 }
                 const bool revisits = m_ne(f, lane) != 0;                // wave-uniform: some line of the pass comes back to a node
-                bool one_sweep = false;
                 if (RARELY(lsub) && !(lsub & L_SWEEP1)) {
                     // the first sweep over a long line.  A name the table does not hold (its record says so already) -> the exact path.
                     // While the ids run one way and no name has come twice, the links are counted as the sweep goes (one_sweep): the path's
                     // total length is not known yet, but the part measured so far is a lower bound of it, and a link whose right-hand overlap
                     // holds against the bound holds; the next sub-pass begins at the first link that cannot be decided yet.  Once the ids turn,
                     // or such a link is the sub-pass's first, the rest of the sweep only measures (0x200) and a second sweep counts what the
-                    // first has not (from link lR on).
+                    // first has not (from link lR on).  Whatever the first sweep finds is held back (the worker's log) until the line's last
+                    // name is known: the line may still turn out to be the exact path's, as a whole.
                     if (live_m == 0ull || l_fail) {
                         if (live_m != 0ull) { if (lane == 0) ((uint32_t *)&RL[i0])[2] = (rdlane(meta, 0) & 0x00FFFFFFu) | ((ST_DEFER + DC_LONG_PATH) << 24); wave_sync(); }
                         ++i0; lsub = 0;
                         continue;
                     }
                     if (revisits || l_dup) SET_D0(4u);
-                    one_sweep = !(lsub & L_MEASURE) && lD0 < 4u;     // (3: the ids turn, but every node so far has been held against all nodes before it)
-                    if (one_sweep) tot = lS + rdlane(gsum, n_pass - 1u);
-                    else {
+                    if (!(lsub & L_MEASURE) && lD0 < 4u) {          // (3: the ids turn, but every node so far has been held against all nodes before it)
+                        lsub |= L_ONE;
+                        tot = lS + rdlane(gsum, n_pass - 1u);
+                    } else {
                         if (!(lsub & L_MEASURE)) { lsub |= L_MEASURE; SET_R(lP); }
-                        if (lsub & L_FINAL) { lTOT = lS + rdlane(gsum, n_pass - 1u); lS = 0; lsub = (lsub & 0xFF0070u) | 1u | L_SWEEP1; }   // (the second sweep begins at the line's first node; lR and lD0 stay)
+                        if (lsub & L_FINAL) { lTOT = lS + rdlane(gsum, n_pass - 1u); lS = 0; lsub = (lsub & 0xFF0070u) | 1u | L_SWEEP1; }   // (the second sweep begins at the line's first node; lR and lD0 stay; what the first sweep has found — links [0, lR) — waits in the log until the second is through)
                         else { lS += rdlane(gsum, n_pass - 2u); SET_P(lP + n_pass - 1u); }
                         continue;
                     }
@@ -1110,10 +1122,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t fgr = lane_above(fg);
                     moved_m = step_m & (m_ne(fg, jg) | m_ne(fgr, jg + 1u));
                     pre_l = pre; pre_rx = pre; orl = oribit; orr = nxv & 1u; fr = lane + 1u;
+                    if (moved_m) long_words_sync();
                     if (in_mask(moved_m)) {
                         const uint32_t *P = a.long_pre + (size_t)blockIdx.x * LONG_WORDS;
-                        pre_l = __hip_atomic_load(P + fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pre_rx = fgr ? __hip_atomic_load(P + fgr - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                        pre_l = __hip_atomic_load(P + fg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        pre_rx = fgr ? __hip_atomic_load(P + fgr - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
                         orl = IDS[fg] >> 31; orr = IDS[fgr] >> 31;
                     }
                 }
@@ -1121,9 +1134,10 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // that sit in the left node's record — straight selects, no branches —; the link table is asked only if it is not
                 // there and the node has more links, or for a revisited node (the link between the first occurrences)
                 wmask go_m = step_m & m_ge(pre_l, need_l) & m_ge(tot - ((int32_t)fr > (int32_t)lnb ? pre_rx : 0u), need_r);   // (lnb < 0: a sub-pass inside a long line)
+                uint32_t hold = 0;                                       // (wave-uniform; a first sweep's sub-pass in front of the line's last: its first link << 8 | links decided — their hits wait in the log)
                 if (RARELY(lsub)) {
                     uint32_t adv = n_pass - 1u;                          // how far the line's next sub-pass begins behind this one
-                    if (one_sweep && !(lsub & L_FINAL)) {
+                    if ((lsub & L_ONE) && !(lsub & L_FINAL)) {
                         const wmask und_m = step_m & m_ge(pre_l, need_l) & ~go_m;   // the bound did not do: the rest of the path decides
                         if (und_m) adv = (uint32_t)__builtin_ctzll(und_m);
                         if (adv == 0u) {                                 // the sub-pass's first link: sixty-four nodes shorter than the overlap asked for — two sweeps
@@ -1132,8 +1146,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                             continue;
                         }
                         go_m &= low_bits64(adv);
+                        hold = (lP << 8) | adv;
                     }
-                    if (lsub & L_SWEEP1) go_m &= m_ge(lP + lane, lR);      // (the second sweep: what the first has counted stays counted)
+                    if (lsub & L_SWEEP1) go_m &= m_ge(lP + lane, lR);      // (the second sweep: what the first has found stays found)
                     if (!(lsub & L_FINAL)) { lS += rdlane(gsum, adv - 1u); SET_P(lP + adv); }   // (nothing below looks at lS or lP again)
                 }
                 const uint32_t want = (idr << 2) | orl | (orr << 1);
@@ -1168,31 +1183,69 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         }
                     }
                 }
-                // hit records: one aggregated atomic per wave reserves the slots
-                unsigned long long rbase = 0;
-                if (RARELY(a.want_hits)) {
-                    uint32_t wtot2, ex = wave_excl_scan(nh & 0x7FFFFFFFu, wtot2);
-                    if (wtot2) {
-                        if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot2);
-                        rbase = __shfl(rbase, 0) + ex;
+                // A long line's first sweep counts nothing before the line's LAST name is known (r05): a later sub-pass may still hand the
+                // whole line to the exact path (a name the table does not hold, a path of 4 Gbp), which counts every link of it.  What the
+                // sweep finds on its way waits in the worker's words of global memory, two per link — (0xFFFFFFFF, -): no hit; (hit,
+                // 0x7FFFFFFF): one; (hit, hit): two; (offset, 1 << 31 | list << 30 | n): n hits in g.hits / g.name_ihits — and is counted
+                // behind the line's last sub-pass (of its only sweep: links [0, lP); of its second sweep: links [0, lR)) by the code that
+                // counts any pass's hits, which comes round again for it.  (A select here, not a branch, and ONE copy of the counting code:
+                // a flush of its own — wherever it stood — cost ordinary text 3 % through the registers it took, measured.)
+                const uint32_t nh_all = nh;
+                nh = hold ? 0u : nh;
+                for (uint32_t fb = 0;;) {
+                    // hit records: one aggregated atomic per wave reserves the slots
+                    unsigned long long rbase = 0;
+                    if (RARELY(a.want_hits)) {
+                        uint32_t wtot2, ex = wave_excl_scan(nh & 0x7FFFFFFFu, wtot2);
+                        if (wtot2) {
+                            if (lane == 0) rbase = atomicAdd(&a.st->n_recs, (unsigned long long)wtot2);
+                            rbase = __shfl(rbase, 0) + ex;
+                        }
                     }
-                }
-                auto emit = [&](uint32_t hv, uint32_t jj) {
-                    // counts[slot] = ref | alt << 32 is, in memory, the pair of 32-bit counters [2 * slot + allele] = [hv]: a 32-bit atomic
-                    // (the memory-side atomic units take ~14 % more of those per second than 64-bit ones: profiles/r01_ubench_atomics.txt)
-                    if (!DIAG(8u)) atomicAdd(&((unsigned int *)a.counts)[DIAG(4u) ? (hv & 1023u) : DIAG(64u) ? ((hv & 63u) | ((blockIdx.x & 1023u) << 6)) : hv], 1u);   // (4 / 64, ablation builds: all updates into 4 KB / into 256 B per worker)
-                    if (a.want_hits) {
-                        if (rbase + jj < a.rec_cap) {
-                            svjg_hitrec r; r.line_start = a.base_offset + c0 + (LINE[lbase + ln] & 0xFFFFu); r.slot = hv >> 1;
-                            r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
-                            a.recs[rbase + jj] = r;
-                        } else atomicOr(&a.st->overflow, 2u);
+                    auto emit = [&](uint32_t hv, uint32_t jj) {
+                        // counts[slot] = ref | alt << 32 is, in memory, the pair of 32-bit counters [2 * slot + allele] = [hv]: a 32-bit atomic
+                        // (the memory-side atomic units take ~14 % more of those per second than 64-bit ones: profiles/r01_ubench_atomics.txt)
+                        if (!DIAG(8u)) atomicAdd(&((unsigned int *)a.counts)[DIAG(4u) ? (hv & 1023u) : DIAG(64u) ? ((hv & 63u) | ((blockIdx.x & 1023u) << 6)) : hv], 1u);   // (4 / 64, ablation builds: all updates into 4 KB / into 256 B per worker)
+                        if (a.want_hits) {
+                            if (rbase + jj < a.rec_cap) {
+                                svjg_hitrec r; r.line_start = a.base_offset + c0 + (LINE[lbase + ln] & 0xFFFFu); r.slot = hv >> 1;
+                                r.n_ref = (hv & 1u) ? 0 : 1; r.n_alt = (hv & 1u) ? 1 : 0;
+                                a.recs[rbase + jj] = r;
+                            } else atomicOr(&a.st->overflow, 2u);
+                        }
+                    };
+                    if (in_mask(m_le(nh - 1u, 1u))) emit(h0, 0);        // the usual case: one hit (or two), held in registers
+                    if (RARELY(m_gt(nh, 1u))) {
+                        const uint32_t n = nh & 0x7FFFFFFFu;
+                        for (uint32_t jj = hp ? 0u : 1u; jj < n; ++jj) emit(hp ? hp[jj] : h1, jj);
                     }
-                };
-                if (in_mask(m_le(nh - 1u, 1u))) emit(h0, 0);            // the usual case: one hit (or two), held in registers
-                if (RARELY(m_gt(nh, 1u))) {
-                    const uint32_t n = nh & 0x7FFFFFFFu;
-                    for (uint32_t jj = hp ? 0u : 1u; jj < n; ++jj) emit(hp ? hp[jj] : h1, jj);
+                    if (!RARELY(lsub)) break;
+                    uint32_t *LG = a.long_pre + (size_t)blockIdx.x * LONG_WORDS + LONG_LOG;
+                    if (hold) {                                          // this sub-pass's links [hold >> 8, + hold & 0xFF) -> the log
+                        uint32_t w0 = 0xFFFFFFFFu, w1 = 0u;
+                        if (nh_all & 0x80000000u) { w0 = (uint32_t)(hp - (ask ? g.hits : g.name_ihits)); w1 = 0x80000000u | (ask ? 0u : 0x40000000u) | (nh_all & 0x3FFFFFFFu); }   // (a list from the link table / from the left node's record)
+                        else if (nh_all) { w0 = h0; w1 = nh_all == 1u ? 0x7FFFFFFFu : h1; }
+                        if (lane < (hold & 0xFFu)) {
+                            __hip_atomic_store(LG + 2u * ((hold >> 8) + lane), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(LG + 2u * ((hold >> 8) + lane) + 1u, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        break;
+                    }
+                    if (!(lsub & L_FINAL)) break;
+                    const uint32_t upto = (lsub & L_SWEEP1) ? lR : (lsub & L_ONE) ? lP : 0u;   // the line's last sub-pass: the held-back hits of its links [0, upto), 64 links a turn
+                    if (fb >= upto) break;
+                    if (fb == 0u) long_words_sync();
+                    nh = 0; hp = nullptr;
+                    if (fb + lane < upto) {
+                        const uint32_t w0 = __hip_atomic_load(LG + 2u * (fb + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t w1 = __hip_atomic_load(LG + 2u * (fb + lane) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (w0 != 0xFFFFFFFFu) {
+                            if (w1 & 0x80000000u) { hp = ((w1 & 0x40000000u) ? g.name_ihits : g.hits) + w0; nh = (w1 & 0x3FFFFFFFu) | 0x80000000u; }
+                            else { h0 = w0; h1 = w1; nh = w1 == 0x7FFFFFFFu ? 1u : 2u; }
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the log's words are there before the loop comes round — else the compiler puts that wait at the loop's head, where every pass of ordinary text would wait for its predecessors' count updates (3 %)
+                    fb += WG;
                 }
                 tick(6);
                 if (RARELY(lsub) && (lsub & L_FINAL)) { ++i0; lsub = 0; }   // (a long line's last sub-pass: on to the next line)

@@ -142,3 +142,32 @@ def test_random_graphs(seed):
     for wave in (1, 2, 3, 4):
         counts, n_lines = sim.classify(g, text, True, wave)
         assert n_lines == n and _as_dict(g, counts) == wd, wave
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_long_path_fuzz(seed):
+    """tests/longpath_fuzz.py: graphs of >= 2 000 nodes, walks of 65..216 nodes that stay clean for 64 nodes and meet ONE late event (a
+    name the graph lacks — of positive, negative, 5 Gbp length —, a name of 49+ bytes, a hazard name, a 40 Mbp node, a revisit, ids that
+    turn, another contig, a stretch walked back): the two oracles agree, the exact routine in every form the kernels run it in counts the
+    same, and dies with the same exception on a line with an insertion node the GFA lacks."""
+    from tests import longpath_fuzz
+    edges, alt, lines, fatal = longpath_fuzz.make_case(seed, 30, 3)
+    g = Graph(edges, alt)
+    assert sim.check_tables(g) == 0 and g.n_nodes >= 2000
+    text = "".join(lines).encode()
+    orc = OC.COracle(edges, alt)
+    want, _, n = orc.filter(text, want_hits=False)
+    wd = {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
+    assert wd == {k: list(v) for k, v in O.counts_of(O.classify(lines, edges, alt)).items()} and sum(map(sum, wd.values())) > 2000
+    for wave in (0, 2, 3):
+        counts, n_lines = sim.classify(g, text, True, wave)
+        assert n_lines == n and _as_dict(g, counts) == wd, wave
+    for f in fatal:
+        bad = "".join(lines[:4] + [f] + lines[4:8])
+        with pytest.raises(KeyError):
+            O.classify(bad.splitlines(True), edges, alt)
+        with pytest.raises(KeyError):
+            orc.filter(bad.encode(), want_hits=False)
+        for wave in (0, 2):
+            with pytest.raises(KeyError):
+                sim.classify(g, bad.encode(), True, wave)

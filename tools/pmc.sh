@@ -9,7 +9,7 @@ GROUPS_DEFAULT=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_
 if [ -n "$PMC_GROUPS" ]; then IFS=';' read -ra GROUPS_DEFAULT <<< "$PMC_GROUPS"; fi
 for grp in "${GROUPS_DEFAULT[@]}"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --kernel-trace --pmc $grp -d $out/g$i -o p --output-format csv -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $out/g$i.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $grp -d $out/g$i -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-e2e --no-north-star --no-long-read --steps 2 --warmup 1 > $out/g$i.log 2>&1
   f=$(ls -t $out/g$i/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -8,7 +8,7 @@ IFS=';' read -ra GROUPS_ <<< "${PASSES:-SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_
 i=0
 for g in "${GROUPS_[@]}"; do
   i=$((i+1)); rm -rf $O/p$i
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $g -d $O/p$i -o p --output-format csv -- python3 bench.py --workload $W --no-cpu-baseline --no-e2e --steps 2 --warmup 1 > $O/p$i.log 2>&1 || { echo "pass $i ($g): failed: $(grep -m1 -i 'error\|invalid\|not found' $O/p$i.log)"; continue; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $g -d $O/p$i -o p --output-format csv -- python3 bench.py --workload $W --no-cpu-baseline --no-e2e --no-north-star --no-long-read --steps 2 --warmup 1 > $O/p$i.log 2>&1 || { echo "pass $i ($g): failed: $(grep -m1 -i 'error\|invalid\|not found' $O/p$i.log)"; continue; }
   f=$(ls -t $O/p$i/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys, collections
