@@ -384,6 +384,7 @@ static int gaf_finish(svjg_ctx *c, uint64_t n, uint64_t need) {
 
 extern "C" int svjg_gaf_upload(svjg_ctx *c, const char *gaf, uint64_t n) {
     if (!c || (n && !gaf)) return SVJG_E_ARG;
+    if (c->run_inflight) { c->err = "svjg_gaf_upload with a pass in flight (svjg_run_end first: a repeat of that pass would read the new text)"; return SVJG_E_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t need;
     int rc = gaf_reserve(c, n, &need);
@@ -395,6 +396,7 @@ extern "C" int svjg_gaf_upload(svjg_ctx *c, const char *gaf, uint64_t n) {
 
 extern "C" int svjg_gaf_upload_part(svjg_ctx *c, const char *gaf, uint64_t n, uint64_t offset, uint64_t capacity, int last) {
     if (!c || (n && !gaf) || n > capacity || offset > capacity - n) return SVJG_E_ARG;
+    if (c->run_inflight) { c->err = "svjg_gaf_upload_part with a pass in flight (svjg_run_end first)"; return SVJG_E_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     if (offset == 0) {
         int rc = gaf_reserve(c, capacity, &c->part_need);
@@ -411,6 +413,7 @@ extern "C" int svjg_gaf_upload_part(svjg_ctx *c, const char *gaf, uint64_t n, ui
 
 extern "C" int svjg_gaf_upload_file(svjg_ctx *c, const char *path, uint64_t offset, uint64_t n) {
     if (!c || !path) return SVJG_E_ARG;
+    if (c->run_inflight) { c->err = "svjg_gaf_upload_file with a pass in flight (svjg_run_end first)"; return SVJG_E_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     uint64_t need;
     int rc = gaf_reserve(c, n, &need);

@@ -252,6 +252,31 @@ def _classify_on_device(ctx, graph, data, ranges, want_hits, out, r, path=None):
         out[r] = e
 
 
+class _CommInit(threading.Thread):
+    """RCCL communicators for the contexts of this process (ncclCommInitAll), created in a thread of its own WHILE the GPUs upload and
+    classify: over eight ranks that call takes seconds — the order of the whole run at BASELINE configs[2] — and nothing it does needs
+    the contexts to be idle (it sets ctx->comm, which only the all-reduce behind the classification reads).  join_or_raise() before that
+    all-reduce; `seconds` = how long the call took."""
+
+    def __init__(self, ctxs):
+        super().__init__(daemon=True)
+        self.ctxs, self.error, self.seconds = ctxs, None, None
+
+    def run(self):
+        t = time.perf_counter()
+        try:
+            capi.comm_init_all(self.ctxs)
+        except BaseException as e:                # noqa: BLE001 (re-raised by join_or_raise)
+            self.error = e
+        self.seconds = time.perf_counter() - t
+
+    def join_or_raise(self):
+        self.join()
+        if self.error is not None:
+            raise self.error
+        return self.seconds
+
+
 def classify_file(ctx, graph, gaf_path, want_hits=True):
     """One GPU, one context that keeps the counts (fused driver, tests): -> (counts[n_slots, 2], hit records, the file's bytes)."""
     data = read_gaf(gaf_path)
@@ -291,6 +316,10 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
     try:
         for d in distinct:
             ctxs.append(capi.Context(d))
+        comm = None
+        if len(ctxs) > 1:                          # the communicators come to be beside upload + classify, not behind them
+            comm = _CommInit(ctxs)
+            comm.start()
         errs = [None] * len(distinct)
         if len(distinct) == 1:
             _classify_on_device(ctxs[0], graph, data, ranges[distinct[0]], want_hits, errs, 0, gaf_path)
@@ -314,8 +343,13 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
         _stamp(t, f"tables -> device, upload + classify on {len(distinct)} GPU(s)")
         if any(c.stats()["non_ascii"] for c in ctxs):
             check_utf8(data)
-        if len(ctxs) > 1:
-            capi.comm_init_all(ctxs)
+        if comm is not None:
+            t_wait = time.perf_counter()
+            t_init = comm.join_or_raise()
+            if os.environ.get("SVJG_VERBOSE"):
+                sys.stderr.write(f"[svjg] RCCL communicators for {len(ctxs)} GPUs (ncclCommInitAll): {t_init:.2f} s beside upload + classify, "
+                                 f"{time.perf_counter() - t_wait:.2f} s of it waited for here\n")
+            comm = None
         capi.allreduce_counts_all(ctxs)           # (one GPU: only the overflow guard)
         total = ctxs[0].counts()
         recs = None
@@ -324,6 +358,8 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
         _stamp(t, "count all-reduce, counts + hit records -> host")
         return total, recs, data
     finally:
+        if comm is not None:                       # (an error on the way: the communicator call must have returned before its contexts go)
+            comm.join()
         for c in ctxs:
             c.close()
 

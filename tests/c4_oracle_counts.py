@@ -5,6 +5,9 @@ stream, each cut into one contiguous share per forked worker (the oracle keeps s
 process never touches the GPU).  Writes counts (sv ids in the oracle's order) to an .npz.
 
     python tests/c4_oracle_counts.py PREFIX OUT.npz [n_shards] [lines_per_shard]
+    python tests/c4_oracle_counts.py --golden          # tests/golden/synth/c4_oracle.json: what bench.py's north_star / e2e_north_star blocks
+                                                       # are checked against on the GPU box — the digest (tools/digest.py) of the C oracle's
+                                                       # count vector over all 100 M lines and the sha256 of the Python oracle's VCF for it
 """
 import multiprocessing as mp
 import os
@@ -25,6 +28,38 @@ def _share(rng):
     lo, hi = rng
     c, _, n = _S["orc"].filter(_S["gaf"][lo:hi], want_hits=False)
     return c, n
+
+
+def golden():
+    import hashlib
+    import json
+    import shutil
+    import tempfile
+    import time
+    import digest
+    work = tempfile.mkdtemp(prefix="svjg_c4gold_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        pre = os.path.join(work, "c4")
+        n_aln, n_sv, n_chrom, mix, seed = synth.CONFIGS["c4"]
+        inf = synth.generate(pre, 0, n_sv, n_chrom, mix, seed, write_gaf=False)
+        synth.save_tables(inf["tables"], pre)
+        t0 = time.time()
+        sys.argv[1:] = [pre, pre + "_oracle.npz"]
+        main()
+        z = np.load(pre + "_oracle.npz")
+        want, ids = z["counts"], [str(x) for x in z["sv_ids"]]
+        D = {sv: [["x"] * int(want[i, 0]), ["y"] * int(want[i, 1])] for i, sv in enumerate(ids) if want[i].sum()}
+        text, n_geno = oracle_py.genotype_vcf(open(pre + ".vcf").readlines(), D)
+        out = {"config": "BASELINE configs[3]: synth.CONFIGS['c4'] (100 M alignments x 500 k mixed SVs on 24 chromosomes)",
+               "lines": int(z["lines"][0]), "hits": int(want.sum()), "svs_with_counts": int((want.sum(axis=1) > 0).sum()),
+               "counts_digest": digest.counts_digest(ids, want), "genotyped": int(n_geno),
+               "vcf_sha256": hashlib.sha256(text.encode()).hexdigest(), "vcf_bytes": len(text.encode()),
+               "by": "oracle/svjg_oracle.c (counts, all lines) + oracle/oracle_py.py (VCF) — tests/c4_oracle_counts.py --golden", "seconds": round(time.time() - t0)}
+        with open(os.path.join(ROOT, "tests", "golden", "synth", "c4_oracle.json"), "w") as fh:
+            json.dump(out, fh, indent=1)
+        print(out)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def main():
@@ -51,4 +86,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    golden() if sys.argv[1:2] == ["--golden"] else main()

@@ -20,6 +20,8 @@ Fixture groups:
   synth/     G6  medium synthetic case from tools/svjg_synth (inputs regenerated from the seed):
                  sha256 of the reference JSON/VCF + the full count vector
   utf8order/ G8  GAFs that are not UTF-8 and hold a malformed line: which exception the reference dies with
+  longpath/  G9  tests/longpath_fuzz.py: long walks (65..216 nodes) with one late event on graphs of >= 2 000 nodes
+  contigs/   G10 GRCh38 analysis-set contig names (HLA-DRB1*15:03:01:01, chrUn_JTFH01001998v1_decoy, chr6_GL000250v2_alt, chrEBV)
   realshape/ G7  lines shaped like real minigraph output (read names, cg:Z: / ds:Z: tags, paths of up to 300 nodes,
                  UCSC contig names) on a 600-SV graph, with the reference's JSON and VCF
              full  c2_full.json / c3_full.json / c4slice_full.json: sha256 of the reference's JSON and VCF for the
@@ -893,6 +895,157 @@ def make_graphfuzz():
     print("graphfuzz:", len(cases), "cases,", sum(sum(map(sum, c["counts"].values())) for c in cases), "informative alignments in all")
 
 
+def _write_graph_files(tdir, edges, alt):
+    with open(f"{tdir}/g_svs_edges.json", "w") as fh:
+        fh.write(json.dumps(edges, indent=4))
+    with open(f"{tdir}/g.gfa", "w") as fh:
+        fh.write("H\tVN:Z:1.0\n")
+        for n in sorted({x for k in edges for x in (k.split("@")[0], k.split("@")[2])} | set(alt)):
+            fh.write(f"S\t{n}\t{'ACGT' * (alt[n] // 4) + 'A' * (alt[n] % 4) if n in alt else '*'}\n")
+
+
+def make_longpath():
+    """golden/longpath/cases.json: tests/longpath_fuzz.py's graphs (>= 2 000 nodes) and long walks (65..216 nodes, clean for 64 nodes, ONE
+    late event) through the reference's filter-alignments.py — seeds 7000..7003, 10 long lines each (40 in all, with the short lines the
+    generator puts between them): per case the sha256 of the inputs, the per-SV list lengths and the sha256 of the JSON the reference
+    wrote; and for every `fatal` line of the generator (an insertion node the GFA lacks) the class of the exception it died with."""
+    import hashlib
+    sys.path.insert(0, os.path.dirname(HERE))
+    import longpath_fuzz
+    out = f"{HERE}/longpath"
+    os.makedirs(out, exist_ok=True)
+    tdir = tempfile.mkdtemp()
+    cases = []
+    for seed in range(7000, 7004):
+        edges, alt, lines, fatal = longpath_fuzz.make_case(seed, 10, 3)
+        _write_graph_files(tdir, edges, alt)
+        with open(f"{tdir}/g.gaf", "w") as fh:
+            fh.write("".join(lines))
+        js = f"{tdir}/g_informative_aln.json"
+        if os.path.exists(js):
+            os.remove(js)
+        rc, err = run_ref_filter(f"{tdir}/g.gaf", f"{tdir}/g.gfa", f"{tdir}/g")
+        assert rc == 0, err
+        text = open(js).read()
+        d = json.loads(text)
+        errs = []
+        for f in fatal:
+            with open(f"{tdir}/f.gaf", "w") as fh:
+                fh.write("".join(lines[:4] + [f] + lines[4:6]))
+            rc, err = run_ref_filter(f"{tdir}/f.gaf", f"{tdir}/g.gfa", f"{tdir}/g")
+            assert rc == 1, (rc, err)
+            errs.append(err.split(":")[0])
+        h_in = hashlib.sha256((json.dumps(edges, sort_keys=True) + json.dumps(alt, sort_keys=True) + "".join(lines) + "".join(fatal)).encode()).hexdigest()
+        cases.append({"seed": seed, "n_long": 10, "n_fatal": 3, "n_lines": len(lines), "inputs_sha256": h_in, "json_sha256": hashlib.sha256(text.encode()).hexdigest(),
+                      "counts": {k: [len(v[0]), len(v[1])] for k, v in d.items()}, "fatal_errors": errs,
+                      "events": [l.split("\t", 1)[0] for l in lines if "_k" in l.split("\t", 1)[0]]})
+    with open(f"{out}/cases.json", "w") as fh:
+        json.dump(cases, fh, indent=0, sort_keys=True)
+    print("longpath:", len(cases), "cases,", sum(len(c["events"]) for c in cases), "long lines,", sum(sum(map(sum, c["counts"].values())) for c in cases), "informative alignments in all;",
+          "fatal:", sorted({e for c in cases for e in c["fatal_errors"]}))
+
+
+def make_contigs():
+    """golden/contigs: contig names shaped like the GRCh38 analysis set's — HLA-DRB1*15:03:01:01 and HLA-A*01:01:01:01 (':', '*' and '-'
+    INSIDE the contig part: the reference takes the LAST ':' field of a node name, filter-alignments.py:328-349), chrUn_JTFH01001998v1_decoy,
+    chr6_GL000250v2_alt, chrEBV, chr6 — on two small graphs, `hla` (all six contigs) and `ucsc` (the four without a colon), with walks in
+    both directions over reference and insertion nodes, links between contigs, names the graph lacks on contigs it has and on contigs it
+    has not, single-node paths; the reference's JSON for both is committed."""
+    import random
+    out = f"{HERE}/contigs"
+    os.makedirs(out, exist_ok=True)
+    for tag, chroms in (("hla", ["chr6", "chr6_GL000250v2_alt", "chrUn_JTFH01001998v1_decoy", "chrEBV", "HLA-DRB1*15:03:01:01", "HLA-A*01:01:01:01"]),
+                        ("ucsc", ["chr6", "chr6_GL000250v2_alt", "chrUn_JTFH01001998v1_decoy", "chrEBV"])):
+        rng = random.Random(len(chroms))
+        edges, alt, ref, length = {}, {}, {}, {}
+        n_sv = [0]
+
+        def add(l, sl, r, sr, ents):
+            edges.setdefault("@".join((l, sl, r, sr)), []).extend(ents)
+
+        def sv(c, kind, pos):
+            n_sv[0] += 1
+            return f"{c}:INS-{pos}-{n_sv[0] % 4 + 1}" if kind == "INS" else f"{c}:{kind}-{pos}-{pos + 300 + n_sv[0]}"
+        for c in chroms:
+            cuts = sorted(rng.sample(range(300, 40000 if c != "chr6" else 31_000_000), 9))
+            starts, ends = [1] + [x + 1 for x in cuts], cuts + [cuts[-1] + 2500]
+            ref[c] = [f"{c}:{a}-{b}" for a, b in zip(starts, ends)]
+            for n, a, b in zip(ref[c], starts, ends):
+                length[n] = b - a + 1
+            for i in range(9):
+                add(ref[c][i], "+", ref[c][i + 1], "+", [[sv(c, "DEL", starts[i + 1]), 0]])
+                if i % 3 == 0 and i + 2 < 10:
+                    add(ref[c][i], "+", ref[c][i + 2], "+", [[sv(c, "DEL", starts[i + 1]), 1]])
+                if i % 3 == 1:
+                    an = f"{c}:{starts[i + 1]}.1"
+                    alt[an] = length[an] = 120 + 10 * i
+                    s_id = sv(c, "INS", starts[i + 1])
+                    add(ref[c][i], "+", an, "+", [[s_id, 1]])
+                    add(an, "+", ref[c][i + 1], "+", [[s_id, 1]])
+                if i % 4 == 2:
+                    add(ref[c][i], "+", ref[c][i + 1], "-", [[sv(c, "INV", starts[i + 1]), 1]])
+        for a, b in zip(chroms, chroms[1:] + chroms[:1]):                 # breakends between the contigs
+            add(ref[a][4], "+", ref[b][6], "+", [[f"{a}:BND-{ref[a][4].rsplit('-', 1)[1]}[{b}:{ref[b][6].rsplit(':', 1)[1].split('-')[0]}[", 1]])
+        lines = []
+        order = {}
+        for c in chroms:
+            seq = []
+            for i, n in enumerate(ref[c]):
+                pos = n.rsplit(":", 1)[1].split("-")[0]
+                if f"{c}:{pos}.1" in alt:
+                    seq.append(f"{c}:{pos}.1")
+                seq.append(n)
+            order[c] = seq
+        absent = ["HLA-B*07:02:01:1-3000", "HLA-C*04:01:01:01:100-900", "chr6_GL000251v2_alt:5-4000", "chrUn_KN707606v1_decoy:1-2200", "HLA-DRB1*15:03:01:02:1-500"]
+
+        def nlen(n):
+            if n in length:
+                return length[n]
+            a, b = n.rsplit(":", 1)[1].split("-")
+            return int(b) - int(a) + 1
+        for i in range(90):
+            c = chroms[i % len(chroms)]
+            seq = order[c]
+            k = rng.choice((1, 2, 3, 4, 5, 8, len(seq)))
+            a0 = rng.randrange(0, len(seq) - k + 1)
+            w = seq[a0:a0 + k]
+            if i % 7 == 3 and k >= 3:                                 # over a deletion's link: leave a reference node out
+                w = [x for j, x in enumerate(w) if j != 1 or "." in x] or w
+            if i % 9 == 4:                                            # on to the next contig over the breakend
+                c2 = chroms[(chroms.index(c) + 1) % len(chroms)]
+                w = order[c][: order[c].index(ref[c][4]) + 1][-3:] + order[c2][order[c2].index(ref[c2][6]):][:3]
+            if i % 11 == 5:
+                w = w + [absent[i % len(absent)]]
+            if i % 13 == 6:
+                w = [absent[(i + 1) % len(absent)]] + w
+            if i % 17 == 7:
+                w = [absent[i % len(absent)]]                         # a single-node path on a contig the graph does not have
+            rev = i % 2 == 1
+            tl = sum(nlen(n) for n in w)
+            p = "".join(("<" if rev else ">") + n for n in (reversed(w) if rev else w))
+            ts, back = rng.choice((0, 5, 99, 100, 101, 250)), rng.choice((0, 7, 99, 100, 101, 250))
+            te = max(tl - back, ts + 1)
+            tags = "tp:A:P\tcm:i:9\ts1:i:77\ts2:i:0\tdv:f:0.0312" + ("\tcg:Z:30M2I40M" if i % 5 == 0 else "")
+            lines.append(f"m64011_190830_220126/{i}/ccs\t{tl + 30}\t2\t{tl + 10}\t{'+-'[i % 2]}\t{p}\t{tl}\t{ts}\t{te}\t{max(te - ts - 9, 1)}\t{max(te - ts, 1)}\t{60 - i % 3}\t{tags}\n")
+        pre = f"{out}/{tag}"
+        with open(pre + "_svs_edges.json", "w") as fh:
+            fh.write(json.dumps(edges, sort_keys=True, indent=4))
+        with open(pre + ".gfa", "w") as fh:
+            fh.write("H\tVN:Z:1.0\n")
+            for n in sorted({x for k in edges for x in (k.split("@")[0], k.split("@")[2])} | set(alt)):
+                fh.write(f"S\t{n}\t{'ACGT' * (alt[n] // 4) + 'A' * (alt[n] % 4) if n in alt else '*'}\n")
+        with open(pre + ".gaf", "w") as fh:
+            fh.write("".join(lines))
+        js = pre + "_informative_aln.json"
+        if os.path.exists(js):
+            os.remove(js)
+        rc, err = run_ref_filter(pre + ".gaf", pre + ".gfa", pre)
+        assert rc == 0, err
+        os.replace(js, pre + ".ref.json")
+        d = json.load(open(pre + ".ref.json"))
+        print(f"contigs/{tag}:", len(lines), "lines,", len(d), "SVs with informative alignments,", sum(len(v[0]) + len(v[1]) for v in d.values()), "hits")
+
+
 # ----------------------------------------------------------------------------------------------
 # G6 medium synthetic (needs tools/svjg_synth built)
 # ----------------------------------------------------------------------------------------------
@@ -1168,7 +1321,7 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz", "dover"]
+    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz", "dover", "longpath", "contigs"]
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))

@@ -100,6 +100,52 @@ def test_graphfuzz_through_the_reference(ctx, golden, tmp_path):
         assert hashlib.sha256(open(tmp_path / "o.json", "rb").read()).hexdigest() == c["json_sha256"], c["seed"]
 
 
+def test_longpath_through_the_reference(ctx, golden, tmp_path):
+    """golden/longpath (r05): 40 walks of 65..216 nodes with one late event each (tests/longpath_fuzz.py) whose _informative_aln.json the
+    REFERENCE wrote: the HIP path counts the same, its JSON has the reference's sha256, main kernel and exact path; the generator's
+    fatal lines (an insertion node the GFA lacks) die with the reference's exception."""
+    import hashlib
+    from svjg import capi
+    from svjg.graph import Graph
+    from tests.test_oracle_golden import _longpath_case
+    for c in json.load(open(f"{golden}/longpath/cases.json")):
+        edges, alt, lines, fatal = _longpath_case(c)
+        data = np.frombuffer("".join(lines).encode(), dtype=np.uint8)
+        for all_slow in (False, True):
+            g = Graph(edges, alt, all_slow=all_slow)
+            ctx.load_graph(g)
+            ctx.reset_counts()
+            ctx.classify(data, want_hits=True)
+            assert _counts_dict(g, ctx.counts()) == c["counts"], c["seed"]
+            capi.write_informative_json(str(tmp_path / "o.json"), data, ctx.hits(), g.sv_ids)
+            assert hashlib.sha256(open(tmp_path / "o.json", "rb").read()).hexdigest() == c["json_sha256"], c["seed"]
+            for f, err in zip(fatal, c["fatal_errors"]):
+                ctx.reset_counts()
+                with pytest.raises(Exception) as ei:
+                    ctx.classify(np.frombuffer("".join(lines[:4] + [f] + lines[4:6]).encode(), dtype=np.uint8), want_hits=True)
+                assert type(ei.value).__name__ == err
+
+
+@pytest.mark.parametrize("all_slow", [False, True])
+@pytest.mark.parametrize("tag", ["hla", "ucsc"])
+def test_contig_names_of_the_grch38_analysis_set(ctx, golden, tag, all_slow, tmp_path):
+    """golden/contigs (r05): node names on HLA-DRB1*15:03:01:01 / HLA-A*01:01:01:01 (':' '*' '-' inside the contig part; the reference
+    takes a name's LAST ':' field), chrUn_JTFH01001998v1_decoy, chr6_GL000250v2_alt, chrEBV: counts and JSON text are the reference's.
+    Without a colon in a contig name every line stays in the main kernel but those with a name the graph lacks."""
+    from svjg import capi, filter as flt
+    from svjg.graph import Graph
+    pre = f"{golden}/contigs/{tag}"
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", all_slow=all_slow)
+    counts, recs, data = flt.classify_file(ctx, g, pre + ".gaf")
+    ref_text = open(pre + ".ref.json").read()
+    assert _counts_dict(g, counts) == {k: [len(v[0]), len(v[1])] for k, v in json.loads(ref_text).items()}
+    capi.write_informative_json(str(tmp_path / "o.json"), data, recs, g.sv_ids)
+    assert open(tmp_path / "o.json").read() == ref_text
+    if tag == "ucsc" and not all_slow:
+        st, cause = ctx.stats(), ctx.defer_causes()
+        assert st["n_deferred"] == cause["node_name"] <= 20, (st, cause)
+
+
 UNICODE = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "unicode")) if f.endswith(".gaf"))
 
 
@@ -1586,6 +1632,10 @@ def test_run_resident_is_the_three_calls(tmp_path):
         c.run_begin(3, 0.00005); c.run_begin(3, 0.00005)
         with pytest.raises(capi.SvjgError):
             c.run_begin(3, 0.00005)
+        with pytest.raises(capi.SvjgError):                    # (r05: nor may the resident text change under a pass in flight — a repeat of that pass would read it)
+            c.upload(gaf)
+        with pytest.raises(capi.SvjgError):
+            c.upload_parts([gaf[:1000]], 4096)
         for _ in range(3):
             got = [np.array(x) for x in c.run_end()]
             assert np.array_equal(got[0], want[2]) and np.array_equal(got[1], want[3]) and np.array_equal(got[2], want[4])

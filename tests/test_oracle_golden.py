@@ -268,3 +268,63 @@ def test_graphfuzz_through_the_reference(golden):
         orc = OC.COracle(edges, alt)
         want, _, n = orc.filter("".join(lines).encode(), want_hits=False)
         assert {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()} == c["counts"] and n == c["n_lines"]
+
+
+def _longpath_case(c):
+    import hashlib
+    from tests import longpath_fuzz
+    edges, alt, lines, fatal = longpath_fuzz.make_case(c["seed"], c["n_long"], c["n_fatal"])
+    h = hashlib.sha256((json.dumps(edges, sort_keys=True) + json.dumps(alt, sort_keys=True) + "".join(lines) + "".join(fatal)).encode()).hexdigest()
+    if h != c["inputs_sha256"]:
+        pytest.skip("this interpreter's random module does not reproduce the generator's stream")
+    return edges, alt, lines, fatal
+
+
+def test_longpath_through_the_reference(golden):
+    """golden/longpath (r05): 40 walks of 65..216 nodes over graphs of >= 2 000 nodes — clean for 64 nodes, then one late event (a name
+    the graph lacks, of positive / negative / 5 Gbp length; a name of 49+ bytes; a hazard name; a 40 Mbp node; a revisit; ids that turn;
+    another contig; a stretch walked back) — through the reference's filter-alignments.py: both oracles count what it counted, the
+    Python oracle's JSON text has its sha256, and a line with an insertion node the GFA lacks kills both with the reference's KeyError."""
+    import hashlib
+    from oracle import oracle_c as OC
+    for c in json.load(open(f"{golden}/longpath/cases.json")):
+        edges, alt, lines, fatal = _longpath_case(c)
+        D = O.classify(lines, edges, alt)
+        assert {k: list(v) for k, v in O.counts_of(D).items()} == c["counts"], c["seed"]
+        assert hashlib.sha256(O.dump_informative(D).encode()).hexdigest() == c["json_sha256"], c["seed"]
+        orc = OC.COracle(edges, alt)
+        want, _, n = orc.filter("".join(lines).encode(), want_hits=False)
+        assert {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()} == c["counts"] and n == c["n_lines"]
+        for f, err in zip(fatal, c["fatal_errors"]):
+            bad = lines[:4] + [f] + lines[4:6]
+            for run in (lambda: O.classify(bad, edges, alt), lambda: orc.filter("".join(bad).encode(), want_hits=False)):
+                with pytest.raises(Exception) as ei:
+                    run()
+                assert type(ei.value).__name__ == err
+
+
+@pytest.mark.parametrize("tag", ["hla", "ucsc"])
+def test_contig_names_of_the_grch38_analysis_set(golden, tag):
+    """golden/contigs (r05): HLA-DRB1*15:03:01:01, HLA-A*01:01:01:01 (':' '*' '-' inside the contig part), chrUn_JTFH01001998v1_decoy,
+    chr6_GL000250v2_alt, chrEBV — the reference's JSON for 90 walks per graph; both oracles, both graph loaders and the exact routine
+    (host build) reproduce it."""
+    from oracle import oracle_c as OC
+    from svjg.graph import Graph
+    from tests.hostsim import sim
+    pre = f"{golden}/contigs/{tag}"
+    ref_text = open(pre + ".ref.json").read()
+    ref = {k: [len(v[0]), len(v[1])] for k, v in json.loads(ref_text).items()}
+    edges, alt = O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa")
+    lines = open(pre + ".gaf").read().splitlines(True)
+    D = O.classify(lines, edges, alt)
+    assert {k: list(v) for k, v in O.counts_of(D).items()} == ref and O.dump_informative(D) == ref_text
+    orc = OC.COracle(edges, alt)
+    want, _, n = orc.filter(open(pre + ".gaf", "rb").read(), want_hits=False)
+    assert {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()} == ref and n == len(lines)
+    for native in (False, True):
+        g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", native=native)
+        assert sim.check_tables(g) == 0
+        assert (g.n_hazard == g.n_nodes) == (tag == "hla")        # a ':' inside a contig name: every node name takes the exact routine
+        for wave in (0, 2):
+            counts, n_lines = sim.classify(g, open(pre + ".gaf", "rb").read(), True, wave)
+            assert n_lines == n and {g.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(g.n_slots) if counts[i].sum()} == ref

@@ -25,10 +25,13 @@ n = capi.device_count()
 ctxs = [capi.Context(i) for i in range(n)]
 for c in ctxs:
     c.load_graph(g); c.set_rows(rows.sv_type, rows.slot, rows.ok); c.upload(inf["gaf"])
+import time           # noqa: E402
+t_init = time.perf_counter()
 if n > 1:
     capi.comm_init_all(ctxs)
 else:
     shard.RcclGroup(ctxs[0], 1, 0, lambda uid: uid)
+print(f"init_s: {time.perf_counter() - t_init:.3f} (communicator of {n} rank(s): {'ncclCommInitAll' if n > 1 else 'ncclCommInitRank'})")
 dt, ms, out = bench.timed_steps(ctxs, 3, 1)
 print("passes ok:", dt, [m[-1] for m in ms])
 import glob, re
