@@ -12,7 +12,13 @@
 // counter-based hash of (worker, stripe, pass, lane): a dozen integer instructions per pass, no byte work, no lists, no LDS
 // round trips beyond the staging.  The table sizes and per-launch operation counts are the main kernel's (bench.py config block and
 // profiles/r04: SQ / TCC counters).
-//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/skeleton tools/ubench/skeleton.hip ; tools/ubench/skeleton c3|c4shard [reps]
+// r05: the one division of the work without an atomic per hit — mode bit 6 — measured on its memory AND LDS side:
+//   a worker stages its hits by slot range in LDS (bins of 32 768 counters: 7 at configs[2], 33 at the configs[3] shard; two halves of 32
+//   16-bit entries per bin, one LDS atomic per hit for its place), a lane that fills a half writes its 64 bytes to the worker's own
+//   segment of that bin's log (no global atomic, one full 64-byte line per 32 hits); k_histogram then counts every bin in LDS
+//   (128 KB of counters per workgroup, LDS atomics) and adds them to the count vector, coalesced.  The LDS the staging takes is
+//   deducted from the workers per CU (11 520 B + 132 B a bin, in the hardware's 1 280-byte granules).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/skeleton tools/ubench/skeleton.hip ; tools/ubench/skeleton c3|c4shard [reps] [hits.u32] [workers per CU] [log]
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -39,7 +45,13 @@ struct Args {
     uint32_t zero;             // 0 (keeps the dependent addresses dependent)
     const uint32_t *hits; uint64_t n_hits;   // the real kernel's count updates in file order (tools/sol_hits.py), or null: uniform counters
     unsigned long long *sink;
+    // mode bit 6: hits -> binned logs instead of atomics
+    uint32_t n_bins;           // bins of BIN counters
+    uint16_t *log;             // [bin][worker][seg_cap] 16-bit entries (counter index inside its bin)
+    uint32_t *log_fill;        // [bin][worker] entries written
+    uint32_t seg_cap;
 };
+constexpr uint32_t BIN_SHIFT = 15, BIN = 1u << BIN_SHIFT, STAGE_HALF = 32;
 
 __device__ inline uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16; return x; }
 __device__ inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
@@ -59,6 +71,19 @@ __global__ __launch_bounds__(WG, 4) void k_skeleton(Args a) {
         for (uint32_t i = 0; i < 4; ++i) { const u32x4 v = __builtin_nontemporal_load((const u32x4 *)(src + i * WG)); pf[i] = make_uint4(v.x, v.y, v.z, v.w); }
     };
     uint64_t hit_at = a.n_hits ? (uint64_t)blockIdx.x * (a.n_hits / gridDim.x) : 0;
+    // staging of the hits by bin (mode bit 6), behind the main kernel's 11 520 bytes: per bin a fill counter, a write cursor and 2 x 32 entries
+    uint32_t *fill = (uint32_t *)(lds + LDS_BYTES_14), *wr = fill + a.n_bins;
+    uint16_t *stage = (uint16_t *)(wr + a.n_bins);
+    if (a.mode & 64u) { for (uint32_t b = lane; b < a.n_bins; b += WG) { fill[b] = 0; wr[b] = 0; } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    auto flush_half = [&](uint32_t b, uint32_t half, uint32_t n_valid) {        // 64 bytes of bin b's staged entries -> the worker's segment of the bin's log
+        const uint4 *src = (const uint4 *)(stage + (size_t)b * 2 * STAGE_HALF + half * STAGE_HALF);
+        const uint32_t w = wr[b];
+        if (w + STAGE_HALF <= a.seg_cap) {
+            uint4 *dst = (uint4 *)(a.log + ((size_t)b * gridDim.x + blockIdx.x) * a.seg_cap + w);
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+        }
+        wr[b] = w + n_valid;
+    };
   uint32_t s = 0;
   for (;;) {                                                             // chunks: a fixed first one, then small ones from one counter (as the main kernel)
     if (!(a.mode & 1u)) fetch_half(pos);
@@ -126,6 +151,15 @@ __global__ __launch_bounds__(WG, 4) void k_skeleton(Args a) {
                     if ((mix(r ^ 0x165667B1u) & 1023u) < a.pair_frac) hv = below;
                 }
                 // (the real kernel counts a hit only after the record has arrived: so does this)
+                if (a.mode & 64u) {
+                    // one LDS atomic per hit for its place among its bin's staged entries; the lane that fills a half sends it off
+                    const bool on = lane < a.a_act;
+                    const uint32_t hx = hv + (acc & a.zero), b = hx >> BIN_SHIFT;
+                    uint32_t pos = 0;
+                    if (on) { pos = atomicAdd(&fill[b], 1u); stage[(size_t)b * 2 * STAGE_HALF + (pos & (2 * STAGE_HALF - 1))] = (uint16_t)(hx & (BIN - 1)); }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (on && (pos & (STAGE_HALF - 1)) == STAGE_HALF - 1) flush_half(b, (pos / STAGE_HALF) & 1u, STAGE_HALF);
+                } else
                 if (lane < a.a_act) atomicAdd(&a.counts[hv + (acc & a.zero)], 1u);
             }
             if ((a.mode & 8u) && p + 1 < n_pass) ++p;
@@ -139,7 +173,39 @@ __global__ __launch_bounds__(WG, 4) void k_skeleton(Args a) {
     if (pos >= a.n_bytes) break;
     end = pos + a.small < a.n_bytes ? pos + a.small : a.n_bytes;
   }
+    if (a.mode & 64u) {                                                  // what is left in the stage: partial halves (padded), then the segments' fills
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t b = lane; b < a.n_bins; b += WG) {
+            const uint32_t f = fill[b], rest = f & (STAGE_HALF - 1);
+            if (rest) flush_half(b, (f / STAGE_HALF) & 1u, rest);
+            a.log_fill[(size_t)b * gridDim.x + blockIdx.x] = wr[b] < a.seg_cap ? wr[b] : a.seg_cap;
+        }
+    }
     if (acc == 0x12345678u) a.sink[0] = acc;
+}
+
+// bin = blockIdx.y; the workers' segments of the bin are shared out over gridDim.x workgroups; every workgroup counts its segments in LDS
+// (BIN counters) and adds what it has to the count vector (consecutive lanes, consecutive counters)
+__global__ __launch_bounds__(256) void k_histogram(const uint16_t *log, const uint32_t *log_fill, uint32_t n_workers, uint32_t seg_cap, unsigned int *counts, uint32_t n_counters) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t b = blockIdx.y;
+    for (uint32_t i = threadIdx.x; i < BIN; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t w = blockIdx.x; w < n_workers; w += gridDim.x) {
+        const uint32_t n = log_fill[(size_t)b * n_workers + w];
+        const uint16_t *seg = log + ((size_t)b * n_workers + w) * seg_cap;
+        for (uint32_t i = threadIdx.x * 8; i < n; i += 256 * 8) {         // 16 bytes per lane
+            const uint4 v = *(const uint4 *)(seg + i);
+            const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) if (i + k < n) atomicAdd(&hist[(e[k >> 1] >> (16 * (k & 1))) & 0xFFFFu], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < BIN; i += 256) {
+        const uint32_t c = hist[i], at = b * BIN + i;
+        if (c && at < n_counters) atomicAdd(&counts[at], c);
+    }
 }
 
 struct Workload { const char *name; uint64_t text; uint32_t rec_slots, buckets, count_slots; double passes, nodes, hits, hit_txn; };
@@ -205,7 +271,9 @@ int main(int argc, char **argv) {
         {"tables only, one 16-byte load per record instead of four (same lines asked of the L2)", 21u},
         {"tables only, the four lanes of a quad read one record per instruction (16 lines per instruction instead of 64)", 37u},
         {"everything, quad layout of the record loads", 32u}};
+    const bool with_log = argc > 5 && !strcmp(argv[5], "log");
     for (const auto &r : runs) {
+        if (with_log) break;
         a.mode = r.mode;
         float best = 1e9f, sum = 0;
         for (int i = 0; i < reps + 2; ++i) {
@@ -217,6 +285,58 @@ int main(int argc, char **argv) {
             if (i >= 2) { sum += ms; best = ms < best ? ms : best; }
         }
         printf("  %-82s  mean %.4f ms  best %.4f ms\n", r.what, sum / reps, best);
+    }
+    if (with_log) {
+        // ---- the division without an atomic per hit: staged by bin in LDS -> per-worker log segments -> k_histogram ----
+        a.n_bins = (a.n_counters + BIN - 1) / BIN;
+        const uint32_t lds_bytes = (LDS_BYTES_14 + a.n_bins * (8 + 2 * STAGE_HALF * 2) + 1279) / 1280 * 1280;
+        const int fit = (int)(160 * 1024 / lds_bytes), pc = fit < per_cu ? fit : per_cu;
+        const uint32_t g2 = (uint32_t)(n_cu * pc);
+        a.region = (uint64_t)((double)((w->text + g2 - 1) / g2) * 0.85) / TEXT * TEXT;
+        const double per_seg = w->hits / (double)a.n_bins / (double)g2;
+        a.seg_cap = ((uint32_t)(per_seg * 2.0) + 4 * STAGE_HALF + 63) / 64 * 64;     // (uniform bins: twice the mean and a little; a full segment drops what does not fit and says so)
+        const size_t log_entries = (size_t)a.n_bins * g2 * a.seg_cap;
+        CHECK(hipMalloc(&a.log, log_entries * 2)); CHECK(hipMalloc(&a.log_fill, (size_t)a.n_bins * g2 * 4));
+        printf("binned logs: %u bins of %u counters, %u B of LDS per worker -> %d workers per CU (%u in all), segments of %u entries (%.1f MB of log)\n",
+               a.n_bins, BIN, lds_bytes, pc, g2, a.seg_cap, log_entries * 2 / 1e6);
+        CHECK(hipFuncSetAttribute((const void *)k_histogram, hipFuncAttributeMaxDynamicSharedMemorySize, BIN * 4));
+        const struct { const char *what; uint32_t mode; } lruns[] = {
+            {"text + tables + count updates, at this many workers (the shipped division, for comparison)", 0u},
+            {"text + tables, no counting at all, at this many workers", 4u},
+            {"text + tables + hits staged by bin in LDS and logged", 64u},
+            {"hits staged and logged only (no text, no tables)", 64u | 3u}};
+        for (const auto &r : lruns) {
+            a.mode = r.mode;
+            float sum = 0, best = 1e9f, hsum = 0, hbest = 1e9f;
+            for (int i = 0; i < reps + 2; ++i) {
+                CHECK(hipMemsetAsync(a.next_chunk, 0, 8));
+                CHECK(hipMemsetAsync(counts, 0, (size_t)w->count_slots * 8));
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_skeleton, dim3(g2), dim3(WG), lds_bytes, 0, a);
+                CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                float hms = 0;
+                if (r.mode & 64u) {
+                    const uint32_t split = 256 / a.n_bins + 1;                       // about one workgroup per CU
+                    CHECK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(k_histogram, dim3(split, a.n_bins), dim3(256), BIN * 4, 0, a.log, a.log_fill, g2, a.seg_cap, counts, a.n_counters);
+                    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                    CHECK(hipEventElapsedTime(&hms, e0, e1));
+                }
+                if (i >= 2) { sum += ms; best = ms < best ? ms : best; hsum += hms; hbest = hms < hbest ? hms : hbest; }
+            }
+            printf("  %-92s  mean %.4f ms  best %.4f ms", r.what, sum / reps, best);
+            if (r.mode & 64u) {
+                std::vector<unsigned int> hc((size_t)w->count_slots * 2);
+                CHECK(hipMemcpy(hc.data(), counts, hc.size() * 4, hipMemcpyDeviceToHost));
+                unsigned long long tot = 0; for (unsigned int v : hc) tot += v;
+                std::vector<uint32_t> lf((size_t)a.n_bins * g2);
+                CHECK(hipMemcpy(lf.data(), a.log_fill, lf.size() * 4, hipMemcpyDeviceToHost));
+                unsigned long long logged = 0, full = 0; for (uint32_t v : lf) { logged += v; full += v >= a.seg_cap; }
+                printf("  + k_histogram mean %.4f best %.4f ms = %.4f ms  (%llu hits logged, %llu counted, %llu full segments)", hsum / reps, hbest, sum / reps + hsum / reps, logged, tot, full);
+            }
+            printf("\n");
+        }
     }
     return 0;
 }
