@@ -1188,10 +1188,20 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // sweep finds on its way waits in the worker's words of global memory, two per link — (0xFFFFFFFF, -): no hit; (hit,
                 // 0x7FFFFFFF): one; (hit, hit): two; (offset, 1 << 31 | list << 30 | n): n hits in g.hits / g.name_ihits — and is counted
                 // behind the line's last sub-pass (of its only sweep: links [0, lP); of its second sweep: links [0, lR)) by the code that
-                // counts any pass's hits, which comes round again for it.  (A select here, not a branch, and ONE copy of the counting code:
-                // a flush of its own — wherever it stood — cost ordinary text 3 % through the registers it took, measured.)
-                const uint32_t nh_all = nh;
-                nh = hold ? 0u : nh;
+                // counts any pass's hits, which comes round again for it.  (ONE copy of the counting code, and the log's loads waited for
+                // inside their rarely taken block: a flush with code of its own — wherever it stood — or a wait the compiler placed where
+                // that block joins the pass cost ordinary text 3 %: profiles/r05/experiments/late_deferral_double_count.txt.)
+                if (RARELY(hold)) {                                      // this sub-pass's links [hold >> 8, + hold & 0xFF) -> the log; nothing is counted
+                    uint32_t *LGw = a.long_pre + (size_t)blockIdx.x * LONG_WORDS + LONG_LOG;
+                    uint32_t w0 = 0xFFFFFFFFu, w1 = 0u;
+                    if (nh & 0x80000000u) { w0 = (uint32_t)(hp - (ask ? g.hits : g.name_ihits)); w1 = 0x80000000u | (ask ? 0u : 0x40000000u) | (nh & 0x3FFFFFFFu); }   // (a list from the link table / from the left node's record)
+                    else if (nh) { w0 = h0; w1 = nh == 1u ? 0x7FFFFFFFu : h1; }
+                    if (lane < (hold & 0xFFu)) {
+                        __hip_atomic_store(LGw + 2u * ((hold >> 8) + lane), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(LGw + 2u * ((hold >> 8) + lane) + 1u, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    nh = 0;
+                }
                 for (uint32_t fb = 0;;) {
                     // hit records: one aggregated atomic per wave reserves the slots
                     unsigned long long rbase = 0;
@@ -1221,16 +1231,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                     if (!RARELY(lsub)) break;
                     uint32_t *LG = a.long_pre + (size_t)blockIdx.x * LONG_WORDS + LONG_LOG;
-                    if (hold) {                                          // this sub-pass's links [hold >> 8, + hold & 0xFF) -> the log
-                        uint32_t w0 = 0xFFFFFFFFu, w1 = 0u;
-                        if (nh_all & 0x80000000u) { w0 = (uint32_t)(hp - (ask ? g.hits : g.name_ihits)); w1 = 0x80000000u | (ask ? 0u : 0x40000000u) | (nh_all & 0x3FFFFFFFu); }   // (a list from the link table / from the left node's record)
-                        else if (nh_all) { w0 = h0; w1 = nh_all == 1u ? 0x7FFFFFFFu : h1; }
-                        if (lane < (hold & 0xFFu)) {
-                            __hip_atomic_store(LG + 2u * ((hold >> 8) + lane), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_store(LG + 2u * ((hold >> 8) + lane) + 1u, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        break;
-                    }
+                    if (hold) break;
                     if (!(lsub & L_FINAL)) break;
                     const uint32_t upto = (lsub & L_SWEEP1) ? lR : (lsub & L_ONE) ? lP : 0u;   // the line's last sub-pass: the held-back hits of its links [0, upto), 64 links a turn
                     if (fb >= upto) break;
