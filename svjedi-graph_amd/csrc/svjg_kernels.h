@@ -1192,13 +1192,15 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // inside their rarely taken block: a flush with code of its own — wherever it stood — or a wait the compiler placed where
                 // that block joins the pass cost ordinary text 3 %: profiles/r05/experiments/late_deferral_double_count.txt.)
                 if (RARELY(hold)) {                                      // this sub-pass's links [hold >> 8, + hold & 0xFF) -> the log; nothing is counted
-                    uint32_t *LGw = a.long_pre + (size_t)blockIdx.x * LONG_WORDS + LONG_LOG;
+                    uint32_t hd = hold, lane_c = lane;
+                    asm volatile("" : "+s"(hd), "+v"(lane_c));           // (as below: nothing of this block is to be computed in front of it)
+                    uint32_t *LGw = a.long_pre + (size_t)blockIdx.x * LONG_WORDS + LONG_LOG + 2u * ((hd >> 8) + lane_c);
                     uint32_t w0 = 0xFFFFFFFFu, w1 = 0u;
                     if (nh & 0x80000000u) { w0 = (uint32_t)(hp - (ask ? g.hits : g.name_ihits)); w1 = 0x80000000u | (ask ? 0u : 0x40000000u) | (nh & 0x3FFFFFFFu); }   // (a list from the link table / from the left node's record)
                     else if (nh) { w0 = h0; w1 = nh == 1u ? 0x7FFFFFFFu : h1; }
-                    if (lane < (hold & 0xFFu)) {
-                        __hip_atomic_store(LGw + 2u * ((hold >> 8) + lane), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_store(LGw + 2u * ((hold >> 8) + lane) + 1u, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (lane_c < (hd & 0xFFu)) {
+                        __hip_atomic_store(LGw, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(LGw + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     nh = 0;
                 }
@@ -1230,16 +1232,20 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         for (uint32_t jj = hp ? 0u : 1u; jj < n; ++jj) emit(hp ? hp[jj] : h1, jj);
                     }
                     if (!RARELY(lsub)) break;
-                    uint32_t *LG = a.long_pre + (size_t)blockIdx.x * LONG_WORDS + LONG_LOG;
                     if (hold) break;
-                    if (!(lsub & L_FINAL)) break;
-                    const uint32_t upto = (lsub & L_SWEEP1) ? lR : (lsub & L_ONE) ? lP : 0u;   // the line's last sub-pass: the held-back hits of its links [0, upto), 64 links a turn
+                    // (what follows is a long line's business: its operands are taken through empty asm statements so that the compiler cannot
+                    //  compute them in front of the loop, on every pass of ordinary text — it did: +21 scalar instructions a pass)
+                    uint32_t ls = lsub, lane_c = lane;
+                    asm volatile("" : "+s"(ls), "+v"(lane_c));
+                    if (!(ls & L_FINAL)) break;
+                    const uint32_t upto = (ls & L_SWEEP1) ? ((ls >> 16) & 0xFFu) : (ls & L_ONE) ? ((ls >> 8) & 0xFFu) : 0u;   // (lR : lP) the line's last sub-pass: the held-back hits of its links [0, upto), 64 links a turn
                     if (fb >= upto) break;
                     if (fb == 0u) long_words_sync();
+                    const uint32_t *LG = a.long_pre + (size_t)blockIdx.x * LONG_WORDS + LONG_LOG + 2u * (fb + lane_c);
                     nh = 0; hp = nullptr;
-                    if (fb + lane < upto) {
-                        const uint32_t w0 = __hip_atomic_load(LG + 2u * (fb + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint32_t w1 = __hip_atomic_load(LG + 2u * (fb + lane) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (fb + lane_c < upto) {
+                        const uint32_t w0 = __hip_atomic_load(LG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t w1 = __hip_atomic_load(LG + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (w0 != 0xFFFFFFFFu) {
                             if (w1 & 0x80000000u) { hp = ((w1 & 0x40000000u) ? g.name_ihits : g.hits) + w0; nh = (w1 & 0x3FFFFFFFu) | 0x80000000u; }
                             else { h0 = w0; h1 = w1; nh = w1 == 0x7FFFFFFFu ? 1u : 2u; }
