@@ -393,8 +393,31 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
         bool colon_in_chrom = false;
         for (auto &c : chroms) if (memchr(c.p, ':', c.n)) colon_in_chrom = true;
         std::vector<uint8_t> hz(n_nodes, 0);
-        if (colon_in_chrom) std::fill(hz.begin(), hz.end(), 1);
-        else {
+        if (colon_in_chrom) {
+            // any contig names (svjg/graph.py: _hazards_general): wherever a node name X = Cx:Tx occurs inside a name Y, X's LAST colon
+            // meets one of Y's colons — Cx is a suffix of what stands in front of that colon, Tx a prefix of what follows it.  For every Y
+            // and every colon of Y: the contigs that end there x the prefixes behind it that spell a tail (digits, '-' or '.', digits).
+            std::string cand;
+            for (uint32_t y = 0; y < n_nodes; ++y) {
+                const Str Y = info[y].name;
+                for (uint32_t c = 0; c < Y.n; ++c) {
+                    if (Y.p[c] != ':') continue;
+                    const uint8_t *rest = Y.p + c + 1; const uint32_t rn = Y.n - c - 1;
+                    uint32_t i = 0;
+                    while (i < rn && rest[i] >= '0' && rest[i] <= '9') ++i;
+                    if (i == 0 || i >= rn || (rest[i] != '-' && rest[i] != '.')) continue;
+                    for (auto &cx : chroms) {
+                        if (cx.n > c || memcmp(Y.p + c - cx.n, cx.p, cx.n)) continue;
+                        for (uint32_t j = i + 1; j < rn && rest[j] >= '0' && rest[j] <= '9'; ++j) {
+                            cand.assign((const char *)cx.p, cx.n); cand.push_back(':'); cand.append((const char *)rest, j + 1);
+                            const Str X{(const uint8_t *)cand.data(), (uint32_t)cand.size()};
+                            if (X.n == Y.n && !memcmp(X.p, Y.p, X.n)) continue;
+                            if (uint32_t *q = name_ix.find(X)) hz[*q] = 1;
+                        }
+                    }
+                }
+            }
+        } else {
             // suffix[c][d] : chromosome d ends with chromosome c
             const size_t nc = chroms.size();
             std::vector<std::vector<uint32_t>> suffix_of(nc);

@@ -190,7 +190,7 @@ class Graph:
         """Node names X for which another node name Y contains X as a proper substring."""
         out = set()
         if any(":" in c for c in chroms):
-            return set(info)                  # structure argument below does not hold: be safe, all exact path
+            return Graph._hazards_general(info, chroms)   # (a ':' inside a contig name, e.g. HLA-DRB1*15:03:01:01: the grouping below does not hold)
         suffix_of = {}                        # chrom -> chroms that end with it (incl. itself)
         for c in chroms:
             suffix_of[c] = [d for d in chroms if d.endswith(c)]
@@ -208,6 +208,34 @@ class Graph:
                     for n2, tail2 in by_chrom.get(d, ()):
                         if n2 != n and tail2.startswith(tail):
                             out.add(n)
+        return out
+
+    @staticmethod
+    def _hazards_general(info, chroms):
+        """The same set for any contig names (r05; before, a ':' in a contig name sent every line of the graph to the exact routine).
+        A node name X = Cx:Tx holds at least one ':' and its tail Tx none, so wherever X occurs inside a name Y its LAST colon
+        meets one of Y's colons: Cx is a suffix of what stands in front of that colon and Tx a prefix of what follows it.  For every
+        Y and every colon of Y: the contigs that end there x the prefixes behind it that spell a tail (digits, '-' or '.', digits)."""
+        out = set()
+        for y in info:
+            for c in (i for i, ch in enumerate(y) if ch == ":"):
+                head, rest = y[:c], y[c + 1:]
+                i = 0
+                while i < len(rest) and rest[i].isdigit() and rest[i].isascii():
+                    i += 1
+                if i == 0 or i >= len(rest) or rest[i] not in "-.":
+                    continue
+                j = i + 1
+                ends = []
+                while j < len(rest) and rest[j].isdigit() and rest[j].isascii():
+                    j += 1
+                    ends.append(j)
+                for cx in chroms:
+                    if head.endswith(cx):
+                        for e in ends:
+                            x = cx + ":" + rest[:e]
+                            if x != y and x in info:
+                                out.add(x)
         return out
 
     def __getattr__(self, name):

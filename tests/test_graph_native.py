@@ -111,3 +111,61 @@ def test_random_graphs(tmp_path, seed):
     _same(py, nat)
     _same(py, Graph(edges, alt))
     assert py.n_hazard > 0 or seed >= 0
+
+
+def _brute_hazards(names):
+    return {x for x in names for y in names if x != y and x in y}
+
+
+def test_hazard_names_with_colons_in_contig_names(tmp_path):
+    """r05: which node names are proper substrings of other node names (the strand quirk of filter-alignments.py:206 — such names take the
+    exact routine) is now decided exactly for ANY contig names: a ':' inside a contig name (HLA-DRB1*15:03:01:01) used to mark every node
+    of the graph.  Both loaders against the brute-force definition on graphs whose contig names nest in every way the rule has to see —
+    a contig that is the tail of another's name, a node name that sits at an INNER colon of a longer contig name — and on golden/contigs."""
+    import json
+    import random
+    from svjg.graph import Graph
+    rng = random.Random(5)
+    chroms = ["7", "y:7", "HLA-A*01:01:01:01", "01", "p", "p:3-4q", "q:12", "12", "chr6", "chr6:1-2x:chr6", "1", "11", "x:1"]
+    edges, alt = {}, {}
+    for c in chroms:
+        cuts = sorted(rng.sample(range(2, 60), 4))
+        if c in ("p", "7", "12", "1", "chr6"):
+            cuts = [4, 9, 20, 33]                                   # (the same breakpoints on the contigs that nest: "7:5-9" inside "y:7:5-9")
+        if c in ("y:7", "q:12", "11", "x:1", "chr6:1-2x:chr6"):
+            cuts = [4, 9, 20, 33]
+        starts, ends = [1] + [x + 1 for x in cuts], cuts + [cuts[-1] + 50]
+        nodes = [f"{c}:{a}-{b}" for a, b in zip(starts, ends)]
+        if c == "p":
+            nodes[1] = "p:3-4"                                       # "p:3-4" stands inside "p:3-4q:..." at an inner colon
+            nodes[0] = "p:1-2"
+        for i in range(len(nodes) - 1):
+            edges[f"{nodes[i]}@+@{nodes[i + 1]}@+"] = [[f"{c}:DEL-{i}-{i + 60}", 0]]
+        an = f"{c}:{starts[2]}.1"
+        alt[an] = 77
+        edges[f"{nodes[1]}@+@{an}@+"] = [[f"{c}:INS-{starts[2]}-1", 1]]
+        edges[f"{an}@+@{nodes[2]}@+"] = [[f"{c}:INS-{starts[2]}-1", 1]]
+    names = {x for k in edges for x in (k.split("@")[0], k.split("@")[2])} | set(alt)
+    want = _brute_hazards(names)
+    assert {"7:5-9", "p:3-4", "12:5-9", "1:5-9", "chr6:5-9", "1:10.1"} <= want and len(want) < len(names) / 2
+    with open(tmp_path / "g_svs_edges.json", "w") as fh:
+        fh.write(json.dumps(edges, indent=4))
+    with open(tmp_path / "g.gfa", "w") as fh:
+        fh.write("H\tVN:Z:1.0\n" + "".join(f"S\t{n}\t{'A' * alt[n] if n in alt else '*'}\n" for n in sorted(names)))
+    for native in (False, True):
+        g = Graph.from_files(str(tmp_path / "g_svs_edges.json"), str(tmp_path / "g.gfa"), native=native)
+        got = {g.node_names[i] for i in range(g.n_nodes) if int(g.nodes["row"][i]) & 0x80000000}
+        assert got == want, (native, sorted(got ^ want))
+    # the fixture with GRCh38 analysis-set names: no node name of it stands inside another
+    gold = os.path.join(os.path.dirname(__file__), "golden", "contigs")
+    for native in (False, True):
+        g = Graph.from_files(f"{gold}/hla_svs_edges.json", f"{gold}/hla.gfa", native=native)
+        assert g.n_hazard == len(_brute_hazards(set(g.node_names))) == 0
+    # ... and without a colon in a contig name the general rule is the grouped one (random hazard-prone graphs)
+    from tests import graph_fuzz
+    for seed in range(6):
+        e2, a2, _ = graph_fuzz.make_case(seed, 1)
+        g = Graph(e2, a2)
+        info = {n: None for n in g.node_names}
+        got = {g.node_names[i] for i in range(g.n_nodes) if int(g.nodes["row"][i]) & 0x80000000}
+        assert got == _brute_hazards(set(g.node_names)) == Graph._hazards_general(info, g.chroms)
