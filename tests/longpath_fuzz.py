@@ -198,3 +198,71 @@ def make_case(seed, n_lines=60, n_fatal=6):
             p = "".join(("<" if rv else ">") + n for n in (reversed(w) if rv else w))
             mixed.append(f"s{seed}_{i}_o{j}\t{tl}\t0\t{tl}\t+\t{p}\t{tl}\t{rng.choice((0, 50, 150))}\t{tl - rng.choice((0, 60, 170))}\t{tl}\t{tl}\t60\ttp:A:P\n")
     return edges, alt, mixed, fatal
+
+
+def make_tail_case(seed, base_lines, n_mut=400):
+    """Lines LONGER than the main kernel's 8 KB stage (r04: such a line stays in the main kernel when its columns and path lie in its first
+    8 KB and what runs past the stage is a plain tail; the worker walks the tail 4 KB a step, 16 bytes a lane): `base_lines` (bytes, no
+    terminator) get tails of 6..40 KB made of tag text in which ONE thing happens at a position chosen to sit on / next to a 16-byte, 64-byte,
+    4 KB or 8 KB boundary of the LINE or of the FILE — nothing; a carriage return (the reference's universal newlines end the line there: what
+    follows is a line of its own — kept well-formed here); the byte pair "d:" outside a tag, split across a boundary or not; an id:f: tag
+    with a plain / a malformed value (the malformed ones are FATAL: returned apart); bytes >= 0x80 (valid UTF-8); a tab-separated tail of many
+    short tags; the terminator itself at a boundary; no terminator at all (last line).  -> (accepted text: bytes, [fatal texts: bytes])"""
+    rng = random.Random(seed)
+    out, fatal = [], []
+    pos = 0
+    alphabet = b"ACGTacgtMIDNSHP=X0123456789"
+
+    def filler(n):
+        return bytes(rng.choice(alphabet) for _ in range(min(n, 64))) * (n // 64 + 1)
+
+    picks = set(rng.sample(range(len(base_lines)), min(n_mut, len(base_lines))))
+    for i, l in enumerate(base_lines):
+        if i not in picks:
+            out.append(l + b"\n")
+            pos += len(l) + 1
+            continue
+        tail_len = rng.choice((6000, 8100, 8192, 9000, 12288, 16384, 20000, 40000)) + rng.randint(-40, 40)
+        kind = rng.choice(("plain", "plain", "cr", "dcolon", "dcolon_split", "idf_ok", "idf_bad", "utf8", "many_tags", "end_on_boundary"))
+        head = l + b"\tcg:Z:"
+        body = bytearray(filler(tail_len)[:tail_len])
+        # a position whose offset in the line or in the file sits on / next to a boundary
+        b = rng.choice((16, 64, 4096, 8192))
+        target = rng.choice((b * rng.randint(1, max(1, (len(head) + tail_len) // b)), len(head) + rng.randint(0, tail_len - 1)))
+        if rng.random() < 0.5:
+            target = target - ((pos + target) % b) + rng.choice((-1, 0, 0, 1))          # on a boundary of the FILE offset
+        at = min(max(target - len(head), 8), tail_len - 24)
+        extra = b""
+        if kind == "cr":
+            body[at:at + 1] = b"\r"
+            # what follows the CR is a line of its own for the reference: make it one it accepts (a short well-formed line)
+            rest = b"r\t9\t0\t9\t+\t>nonode\t9\t0\t9\t9\t9\t60"
+            body = body[:at + 1] + rest
+        elif kind == "dcolon":
+            body[at:at + 4] = b"\txd:"[:4]
+        elif kind == "dcolon_split":
+            body[at:at + 2] = b"d:"
+        elif kind == "idf_ok":
+            body[at:at + 18] = b"\tid:f:0.9875\tzz:Z:"
+        elif kind == "idf_bad":
+            body[at:at + 18] = b"\tid:f:0.9x75\tzz:Z:"
+        elif kind == "utf8":
+            body[at:at + 4] = "éè".encode()
+        elif kind == "many_tags":
+            for q in range(8, len(body) - 8, rng.choice((40, 97, 513))):
+                body[q:q + 1] = b"\t"
+        elif kind == "end_on_boundary":
+            want_len = ((pos + len(head) + tail_len) // b) * b + rng.choice((-1, 0, 1, 15, 16)) - pos - len(head)
+            body = body[:max(16, min(want_len, len(body)))]
+        line = head + bytes(body) + extra
+        if kind == "idf_bad":
+            fatal.append(b"".join(out[-3:]) + line + b"\n")
+            out.append(l + b"\n")
+            pos += len(l) + 1
+            continue
+        out.append(line + b"\n")
+        pos += len(line) + 1
+    text = b"".join(out)
+    if rng.random() < 0.5:
+        text = text[:-1]                                             # the file's last line without a terminator
+    return text, fatal

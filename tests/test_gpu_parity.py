@@ -1163,6 +1163,45 @@ def test_lines_longer_than_the_look_ahead(ctx, tmp_path):
         ctx.classify(np.frombuffer(cr, dtype=np.uint8))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SVJG_TAIL_SEEDS", "6"))))     # (SVJG_TAIL_SEEDS=80: a campaign)
+def test_long_tail_fuzz(ctx, seed, tmp_path):
+    """tests/longpath_fuzz.py: make_tail_case — lines longer than the 8 KB stage whose tails (6..40 KB) hold ONE thing at a position on or next
+    to a 16-byte / 64-byte / 4 KB / 8 KB boundary of the line or of the file: a carriage return, the byte pair "d:", an id:f: tag with a plain
+    value, bytes >= 0x80, many short tags, the terminator itself, no terminator.  Counts, line counts and hit records are the C oracle's,
+    with hit records the JSON text is the Python oracle's; an id:f: tag with a malformed value in such a tail is fatal as in the reference."""
+    import synth
+    from tests import longpath_fuzz
+    from svjg import capi
+    from svjg.graph import Graph
+    pre = str(tmp_path / "c")
+    inf = synth.generate(pre, 1500, 300, 2, "mixed", 500 + seed, write_gaf=False, return_gaf=True)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    edges, alt = O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa")
+    orc = OC.COracle(edges, alt)
+    base = inf["gaf"].tobytes().split(b"\n")[:-1]
+    text, fatal = longpath_fuzz.make_tail_case(900 + seed, base, 300)
+    want, _, n_lines = orc.filter(text, want_hits=False)
+    arr = np.frombuffer(text, dtype=np.uint8)
+    ctx.load_graph(g)
+    for want_hits in (False, True):
+        ctx.reset_counts()
+        ctx.classify(arr, want_hits=want_hits)
+        assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 2000
+        st = ctx.stats()
+        assert st["n_lines"] == n_lines and 20 < st["n_deferred"] < 200, st       # (a carriage return, a "d:" or an id:f: tag in the tail: the exact path's; plain tails stay)
+        if want_hits:
+            assert st["n_hitrecs"] == int(want.sum())
+            capi.write_informative_json(str(tmp_path / "o.json"), arr, ctx.hits(), g.sv_ids)
+            assert open(tmp_path / "o.json").read() == O.dump_informative(O.classify(text.decode().splitlines(True), edges, alt))
+    assert fatal
+    for f in fatal[:6]:
+        with pytest.raises(ValueError):
+            orc.filter(f, want_hits=False)
+        ctx.reset_counts()
+        with pytest.raises(ValueError):
+            ctx.classify(np.frombuffer(f, dtype=np.uint8))
+
+
 def test_exact_path_per_line_part_at_every_alignment(tmp_path):
     """The one-wave-per-line kernel shares the line's per-line part out over its lanes, 16 bytes a lane and 1 KB a step (r04): the twelfth
     tab, the last "id:f:" and the line's end are put at every position across a step's and a lane's boundary — read names of growing length
