@@ -21,6 +21,7 @@ Fixture groups:
                  sha256 of the reference JSON/VCF + the full count vector
   utf8order/ G8  GAFs that are not UTF-8 and hold a malformed line: which exception the reference dies with
   longpath/  G9  tests/longpath_fuzz.py: long walks (65..216 nodes) with one late event on graphs of >= 2 000 nodes
+  longtail/  G11 lines longer than 8 KB with one event in the tail at boundary positions (tests/longpath_fuzz.py: make_tail_case)
   contigs/   G10 GRCh38 analysis-set contig names (HLA-DRB1*15:03:01:01, chrUn_JTFH01001998v1_decoy, chr6_GL000250v2_alt, chrEBV)
   realshape/ G7  lines shaped like real minigraph output (read names, cg:Z: / ds:Z: tags, paths of up to 300 nodes,
                  UCSC contig names) on a 600-SV graph, with the reference's JSON and VCF
@@ -945,6 +946,47 @@ def make_longpath():
           "fatal:", sorted({e for c in cases for e in c["fatal_errors"]}))
 
 
+def make_longtail():
+    """golden/longtail/cases.json: tests/longpath_fuzz.py: make_tail_case — lines longer than the main kernel's 8 KB stage with ONE event in
+    a 6..40 KB tail at a boundary position (a carriage return, "d:", an id:f: tag, bytes >= 0x80, the terminator, none) — on a synthetic
+    graph (tools/synth.py, 800 alignments x 200 SVs), seeds 0..3 with 120 mutated lines each, through the reference's filter-alignments.py:
+    sha256 of the inputs, per-SV list lengths, sha256 of its JSON, and the exception class for each of the case's fatal texts."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, f"{ROOT}/tools")
+    import longpath_fuzz
+    import synth
+    out = f"{HERE}/longtail"
+    os.makedirs(out, exist_ok=True)
+    cases = []
+    for seed in range(4):
+        tmp = tempfile.mkdtemp()
+        pre = f"{tmp}/s"
+        inf = synth.generate(pre, 800, 200, 2, "mixed", 700 + seed, write_gaf=False, return_gaf=True)
+        base = inf["gaf"].tobytes().split(b"\n")[:-1]
+        text, fatal = longpath_fuzz.make_tail_case(300 + seed, base, 120)
+        with open(pre + ".gaf", "wb") as fh:
+            fh.write(text)
+        rc, err = run_ref_filter(pre + ".gaf", pre + ".gfa", pre)
+        assert rc == 0, err
+        js = open(pre + "_informative_aln.json").read()
+        d = json.loads(js)
+        errs = []
+        for f in fatal[:5]:
+            with open(f"{tmp}/f.gaf", "wb") as fh:
+                fh.write(f)
+            rc, err = run_ref_filter(f"{tmp}/f.gaf", pre + ".gfa", pre)
+            assert rc == 1, (rc, err)
+            errs.append(err.split(":")[0])
+        cases.append({"seed": seed, "synth": [800, 200, 2, "mixed", 700 + seed], "tail_seed": 300 + seed, "n_mut": 120,
+                      "inputs_sha256": hashlib.sha256(text + b"".join(fatal[:5])).hexdigest(), "json_sha256": hashlib.sha256(js.encode()).hexdigest(),
+                      "counts": {k: [len(v[0]), len(v[1])] for k, v in d.items()}, "fatal_errors": errs, "gaf_bytes": len(text)})
+        shutil.rmtree(tmp)
+    with open(f"{out}/cases.json", "w") as fh:
+        json.dump(cases, fh, indent=0, sort_keys=True)
+    print("longtail:", len(cases), "cases,", sum(c["gaf_bytes"] for c in cases), "bytes of GAF,", sum(sum(map(sum, c["counts"].values())) for c in cases), "informative alignments;",
+          "fatal:", sorted({e for c in cases for e in c["fatal_errors"]}))
+
+
 def make_contigs():
     """golden/contigs: contig names shaped like the GRCh38 analysis set's — HLA-DRB1*15:03:01:01 and HLA-A*01:01:01:01 (':', '*' and '-'
     INSIDE the contig part: the reference takes the LAST ':' field of a node name, filter-alignments.py:328-349), chrUn_JTFH01001998v1_decoy,
@@ -1321,7 +1363,7 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz", "dover", "longpath", "contigs"]
+    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz", "dover", "longpath", "contigs", "longtail"]
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))

@@ -147,6 +147,32 @@ def test_contig_names_of_the_grch38_analysis_set(ctx, golden, tag, all_slow, tmp
         assert st["n_deferred"] == cause["node_name"] <= 20, (st, cause)
 
 
+def test_longtail_through_the_reference(ctx, golden, tmp_path):
+    """golden/longtail (r05): lines longer than the 8 KB stage with one event in the tail at a boundary position, whose JSON the REFERENCE
+    wrote: the HIP path counts the same and its JSON has the reference's sha256, main kernel and exact path; a malformed id:f: value in a
+    tail dies with the reference's exception."""
+    import hashlib
+    from svjg import capi
+    from svjg.graph import Graph
+    from tests.test_oracle_golden import _longtail_case
+    for c in json.load(open(f"{golden}/longtail/cases.json")):
+        pre, text, fatal = _longtail_case(c, tmp_path)
+        data = np.frombuffer(text, dtype=np.uint8)
+        for all_slow in (False, True):
+            g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", all_slow=all_slow)
+            ctx.load_graph(g)
+            ctx.reset_counts()
+            ctx.classify(data, want_hits=True)
+            assert _counts_dict(g, ctx.counts()) == c["counts"], c["seed"]
+            capi.write_informative_json(str(tmp_path / "o.json"), data, ctx.hits(), g.sv_ids)
+            assert hashlib.sha256(open(tmp_path / "o.json", "rb").read()).hexdigest() == c["json_sha256"], c["seed"]
+            for f, err in zip(fatal, c["fatal_errors"]):
+                ctx.reset_counts()
+                with pytest.raises(Exception) as ei:
+                    ctx.classify(np.frombuffer(f, dtype=np.uint8))
+                assert type(ei.value).__name__ == err
+
+
 UNICODE = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden", "unicode")) if f.endswith(".gaf"))
 
 

@@ -328,3 +328,46 @@ def test_contig_names_of_the_grch38_analysis_set(golden, tag):
         for wave in (0, 2):
             counts, n_lines = sim.classify(g, open(pre + ".gaf", "rb").read(), True, wave)
             assert n_lines == n and {g.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(g.n_slots) if counts[i].sum()} == ref
+
+
+def _longtail_case(c, tmp_path):
+    import hashlib
+    import synth
+    from tests import longpath_fuzz
+    pre = str(tmp_path / f"s{c['seed']}")
+    n_aln, n_sv, n_chrom, mix, seed = c["synth"]
+    inf = synth.generate(pre, n_aln, n_sv, n_chrom, mix, seed, write_gaf=False, return_gaf=True)
+    base = inf["gaf"].tobytes().split(b"\n")[:-1]
+    text, fatal = longpath_fuzz.make_tail_case(c["tail_seed"], base, c["n_mut"])
+    fatal = fatal[:5]
+    if hashlib.sha256(text + b"".join(fatal)).hexdigest() != c["inputs_sha256"]:
+        pytest.skip("this interpreter's random module does not reproduce the generator's stream")
+    return pre, text, fatal
+
+
+def test_longtail_through_the_reference(golden, tmp_path):
+    """golden/longtail (r05): lines longer than 8 KB with one event in a 6..40 KB tail at a boundary position (a carriage return — the
+    reference's universal newlines end the line there —, "d:", an id:f: tag, bytes >= 0x80, the terminator, none) through the reference's
+    filter-alignments.py: both oracles and the exact routine (host build) count what it counted, the Python oracle's JSON has its sha256,
+    an id:f: tag with a malformed value in a tail kills all three with the reference's ValueError."""
+    import hashlib
+    from oracle import oracle_c as OC
+    from svjg.graph import Graph
+    from tests.hostsim import sim
+    for c in json.load(open(f"{golden}/longtail/cases.json")):
+        pre, text, fatal = _longtail_case(c, tmp_path)
+        edges, alt = O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa")
+        D = O.classify(text.decode().splitlines(True), edges, alt)
+        assert {k: list(v) for k, v in O.counts_of(D).items()} == c["counts"], c["seed"]
+        assert hashlib.sha256(O.dump_informative(D).encode()).hexdigest() == c["json_sha256"], c["seed"]
+        orc = OC.COracle(edges, alt)
+        want, _, n = orc.filter(text, want_hits=False)
+        assert {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()} == c["counts"]
+        g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+        counts, n2 = sim.classify(g, text, True, 2)
+        assert n2 == n and {g.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(g.n_slots) if counts[i].sum()} == c["counts"]
+        for f, err in zip(fatal, c["fatal_errors"]):
+            for run in (lambda: O.classify(f.decode().splitlines(True), edges, alt), lambda: orc.filter(f, want_hits=False), lambda: sim.classify(g, f, True, 0)):
+                with pytest.raises(Exception) as ei:
+                    run()
+                assert type(ei.value).__name__ == err
