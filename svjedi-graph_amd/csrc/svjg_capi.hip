@@ -1021,7 +1021,7 @@ extern "C" int svjg_set_rows(svjg_ctx *c, const uint8_t *sv_type, const uint32_t
         }
         if ((rc = ensure(c, (void **)&r.counts, &r.counts_cap, (uint64_t)c->n_slots + GUARD_WORDS, sizeof(unsigned long long), false))) return rc;
         for (auto &e : r.ev) if (!e) HIPCHK(c, hipEventCreate(&e));
-        if (!r.computed) HIPCHK(c, hipEventCreateWithFlags(&r.computed, hipEventDisableTiming));
+        if (!r.computed) HIPCHK(c, hipEventCreate(&r.computed));          // (with a time stamp: it also ends the exact-path kernels' interval, below)
         if (!r.copied) HIPCHK(c, hipEventCreateWithFlags(&r.copied, hipEventDisableTiming));
     }
     if (!c->copy_stream) {                                    // (the lowest priority there is: what runs on it must not take issue slots from the classify kernel)
@@ -1097,7 +1097,8 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         const uint64_t lane_blocks = (uint64_t)c->n_cu * lane_blocks_per_cu(c);   // (here as many as the CUs hold at a time: idle blocks cost every pass)
         hipLaunchKernelGGL(k_classify_slow, dim3((uint32_t)lane_blocks), dim3(SLOW_TPB), 0, c->stream, a, SLOW_ASK_DEVICE, wave_limit, ~0ull - 1);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(r.ev[2], c->stream));
+        // (no event of their own behind the two: `computed`, a few lines down, ends their interval — an event record is a barrier packet,
+        //  6 us of every pass: profiles/r05/experiments/pass_overhead.txt)
     }
     // The count all-reduce of this pass — every rank issues its collectives in the same order, one per pass — runs on the compute
     // stream, between this pass's kernels and the next pass's: the classify kernel fills every CU (fourteen workers take 126 of a
@@ -1161,7 +1162,7 @@ extern "C" int svjg_run_end(svjg_ctx *c, const uint8_t **gt, const int32_t **pl,
     c->ms_slow = 0;
     if (r.had_text) {
         HIPCHK(c, hipEventElapsedTime(&c->ms_main, r.ev[0], r.ev[1]));
-        if (c->hs().n_deferred) HIPCHK(c, hipEventElapsedTime(&c->ms_slow, r.ev[1], r.ev[2]));
+        if (c->hs().n_deferred) HIPCHK(c, hipEventElapsedTime(&c->ms_slow, r.ev[1], r.computed));   // (under a communicator with the all-reduce on the compute stream: the guard kernel and the all-reduce are in it)
     }
     if (n_rows) HIPCHK(c, hipEventElapsedTime(&c->ms_geno, r.ev[4], r.ev[5]));
     bool again = false;
