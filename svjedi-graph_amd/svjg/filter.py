@@ -31,7 +31,11 @@ def output_names(prefix, output_dir=None):
 
 
 CHUNK_BYTES = 1 << 30          # GAF bytes uploaded and classified per call (bounds device memory for the text)
-MIN_BYTES_PER_DEVICE = 64 << 20
+# A further GPU must save more than its communicator costs: ncclCommInitRank / ncclCommInitAll takes ~5.6 s (measured for one rank on the
+# one-GPU box, tools/rccl_probe.py; it runs beside upload + classify, which hides only as much of it as they last), and one GPU takes a file
+# in at ~8 GB/s (21.6 GB in 2.7 s, profiles/r05/experiments/ingest_record_buffer.txt): below ~32 GB of text per GPU a second GPU makes the run
+# LONGER.  (r04: 64 MB — on an eight-GPU node the 2.1 GB of configs[2] would have been cut eight ways.)  SVJG_DEVICES=all | 0,1,... overrides.
+MIN_BYTES_PER_DEVICE = 32 << 30
 
 
 def read_gaf(path):
@@ -221,7 +225,8 @@ def _stamp(t, what):
 
 def pick_devices(n_bytes, device=None):
     """GPUs the alignments are sharded over.  SVJG_DEVICES = "all" | comma-separated indices (an index may repeat: two
-    shards on one GPU, used by the tests); unset: every visible GPU that gets at least MIN_BYTES_PER_DEVICE of text."""
+    shards on one GPU, used by the tests); unset: as many of the visible GPUs as get at least MIN_BYTES_PER_DEVICE of text each (one GPU
+    for anything below 64 GB: see there)."""
     if device is not None:
         return [device]
     spec = os.environ.get("SVJG_DEVICES", "").strip()
