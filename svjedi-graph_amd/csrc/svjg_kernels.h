@@ -1662,8 +1662,19 @@ __global__ __launch_bounds__(SLOW_TPB) void k_classify_slow_wave(ClassifyArgs a,
                         __syncthreads();
                     }
                     wtick(2);
+                    // every node's id and length first, then the strands: by id where the line allows it (svjg_line.h: slow_wave_strands)
+                    slow_wave_resolve(a.g, t, ln, ns, lane, 64u, (const SVJG_TAB_AS uint32_t *)n_piece);
+                    __syncthreads();
+                    bool clean = ln.oriented, rises = true;
+                    for (uint32_t i = lane; i < ln.k; i += 64) {
+                        const uint32_t x = n_id[i];
+                        clean = clean && slow_node_clean(a.g, x);
+                        rises = rises && x != NONE32 && (i == 0 || (n_id[1] > n_id[0] ? x > n_id[i - 1] : x < n_id[i - 1]));
+                    }
+                    clean = __ballot(!clean) == 0ull;
+                    rises = __ballot(!rises) == 0ull;
                     // (the call fills `order`: result and order are separate statements, not two arguments of one call)
-                    const int r1 = slow_wave_phase1(a.g, t, ln, ns, lane, 64u, &order, (const SVJG_TAB_AS uint32_t *)n_piece, (const SVJG_TAB_AS uint16_t *)n_colon, (const SVJG_TAB_AS uint64_t *)n_key);
+                    const int r1 = slow_wave_strands(t, ln, ns, lane, 64u, &order, (const SVJG_TAB_AS uint32_t *)n_piece, (const SVJG_TAB_AS uint16_t *)n_colon, (const SVJG_TAB_AS uint64_t *)n_key, clean, rises);
                     rc = wave_min(r1, order);
                     __syncthreads();
                     wtick(3);

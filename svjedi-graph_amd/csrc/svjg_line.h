@@ -625,6 +625,49 @@ SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeSc
     return 0;
 }
 
+// Phase 1 in two steps (r05, the one-wave-per-line kernel): every node is resolved FIRST (slow_wave_resolve: id, get_node_len or the
+// exception it raises), then the strands (slow_wave_strands).  When the line is `clean` — an oriented path all of whose names are nodes of
+// the graph that stand inside no other node's name (no hazard flag: svjg/graph.py: _hazards) — the search over the path's pieces is not
+// needed: such a name occurs in the path's text only as a whole node (a name holds no separator, so an occurrence lies inside ONE piece,
+// i.e. inside one node's name, which it then equals), so its first occurrence is the first node with the same id and the char in front of
+// it that node's orientation mark (filter-alignments.py:206).  A line with ANY other name keeps the search (that name may hold a node's
+// name).  A path of 200 nodes: 45 % of the kernel's time was this search.
+template <class P>
+SVJG_HD void slow_wave_resolve(const GraphView &g, P t, const SlowLine &ln, NodeScratch &ns, uint32_t lane, uint32_t nlanes, const SVJG_TAB_AS uint32_t *pieces) {
+    for (uint32_t j = lane; j < ln.k; j += nlanes) {
+        NameRef nm;
+        nm.s = pieces[j] & 0xFFFFu; nm.e = nm.s + (pieces[j] >> 16) - (ln.oriented ? 0u : 1u);
+        int64_t l1 = 0;
+        bool alt;
+        int64_t tl;
+        const uint32_t id = resolve_name(g, t, nm, &alt, &tl);
+        ns.id[j * ns.stride] = id;
+        ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1, tl);
+        ns.len[j * ns.stride] = l1;
+    }
+}
+// is node j's name one that can be taken by its id (see above)?
+SVJG_HD bool slow_node_clean(const GraphView &g, uint32_t id) { return id != NONE32 && !(g.nodes[id].row >> 31); }
+template <class P>
+SVJG_HD int slow_wave_strands(P t, const SlowLine &ln, NodeScratch &ns, uint32_t lane, uint32_t nlanes, uint64_t *order, const SVJG_TAB_AS uint32_t *pieces,
+                              const SVJG_TAB_AS uint16_t *colons, const SVJG_TAB_AS uint64_t *keys, bool clean, bool oneway) {
+    for (uint32_t j = lane; j < ln.k; j += nlanes) {
+        uint32_t st = 0;
+        if (clean) {
+            uint32_t f = j;
+            if (!oneway) { const uint32_t x = ns.id[j * ns.stride]; f = 0; while (ns.id[f * ns.stride] != x) ++f; }
+            st = t[(pieces[f] & 0xFFFFu) - 1u] == '>' ? 0u : 1u;       // (an oriented path: a mark stands in front of every piece)
+        } else {
+            NameRef nm;
+            nm.s = pieces[j] & 0xFFFFu; nm.e = nm.s + (pieces[j] >> 16) - (ln.oriented ? 0u : 1u);
+            const int rc = strand_of_pieces(t, ln.ps, pieces, colons, keys, j, nm, st);
+            if (rc) { *order = (1ull << 32) | j; return rc; }
+        }
+        ns.strand[j * ns.stride] = (uint8_t)st;
+    }
+    return 0;
+}
+
 template <class Emit>
 SVJG_HD int slow_wave_phase2(const GraphView &g, const SlowLine &ln, const NodeScratch &ns, Emit &emit, uint32_t lane, uint32_t nlanes, uint64_t *order) {
     const uint32_t S = ns.stride;

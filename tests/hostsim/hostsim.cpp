@@ -78,6 +78,21 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
                     if (pieces.size() != ln.k) { *exc = 7; *err_off = pos; return SVJG_E_INPUT; }   // (harness self-check: pieces == nodes)
                 }
                 uint64_t best = ~0ull;
+                if ((g->flags & 128u) && !pieces.empty()) {
+                    // flag 128, harness only: phase 1 as k_classify_slow_wave runs it since r05 — every node resolved first, then the strands,
+                    // by id where the line is clean (svjg_line.h: slow_wave_strands)
+                    for (uint32_t lane = 0; lane < 64; ++lane) slow_wave_resolve(v, tl, ll, ns, lane, 64u, pieces.data());
+                    bool clean = ll.oriented, rises = true;
+                    for (uint32_t i = 0; i < ll.k; ++i) {
+                        clean = clean && slow_node_clean(v, id[i]);
+                        rises = rises && id[i] != NONE32 && (i == 0 || (id[1] > id[0] ? id[i] > id[i - 1] : id[i] < id[i - 1]));
+                    }
+                    for (uint32_t lane = 0; lane < 64; ++lane) {
+                        uint64_t order = 0;
+                        int r = slow_wave_strands(tl, ll, ns, lane, 64u, &order, pieces.data(), colons.empty() ? nullptr : colons.data(), keys.empty() ? nullptr : keys.data(), clean, rises);
+                        if (r && ((order << 3) | (uint64_t)r) < best) best = (order << 3) | (uint64_t)r;
+                    }
+                } else
                 for (uint32_t lane = 0; lane < 64; ++lane) {
                     uint64_t order = 0;
                     int r = pieces.empty() ? slow_wave_phase1(v, t, ln, ns, lane, 64u, &order) : slow_wave_phase1(v, tl, ll, ns, lane, 64u, &order, pieces.data(), colons.empty() ? nullptr : colons.data(), keys.empty() ? nullptr : keys.data());

@@ -46,7 +46,8 @@ def classify(graph, gaf, tables=True, wave=False):
     if wave:
         # 2 = the two-phase routine of k_classify_slow_wave (64 lanes), 1 = its fallback for very long paths (64 lanes), 3 = one lane with its
         # per-node results kept (k_classify_slow), 4 = the two-phase routine without the table of the pieces' colons (every offset of every piece is tried)
-        cg.flags |= {1: 4, 2: 8, 3: 32, 4: 8 | 64}[wave]
+        # 5 = the two-phase routine with every node resolved first and the strands taken by id where the line allows it (k_classify_slow_wave since r05)
+        cg.flags |= {1: 4, 2: 8, 3: 32, 4: 8 | 64, 5: 8 | 128}[wave]
     buf = np.frombuffer(gaf, dtype=np.uint8) if not isinstance(gaf, np.ndarray) else gaf
     counts = np.zeros((max(graph.n_slots, 1), 2), dtype=np.uint32)
     nl, eo = ctypes.c_uint64(0), ctypes.c_uint64(0)

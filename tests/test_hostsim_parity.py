@@ -20,7 +20,7 @@ def _as_dict(graph, counts):
     return {graph.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(graph.n_slots) if counts[i].sum()}
 
 
-@pytest.mark.parametrize("tables,wave", [(True, 0), (False, 0), (True, 1), (True, 2), (True, 3), (True, 4)], ids=["name_table", "sorted_table", "wave_lanes", "wave_two_phase", "lane_cached", "wave_two_phase_every_offset"])
+@pytest.mark.parametrize("tables,wave", [(True, 0), (False, 0), (True, 1), (True, 2), (True, 3), (True, 4), (True, 5)], ids=["name_table", "sorted_table", "wave_lanes", "wave_two_phase", "lane_cached", "wave_two_phase_every_offset", "wave_strands_by_id"])
 @pytest.mark.parametrize("name", QUIRKS)
 def test_quirks(golden, name, tables, wave):
     q = f"{golden}/quirks"
@@ -60,7 +60,7 @@ def test_dover_flag(golden, name, wave):
         assert type(ei.value).__name__ == man["error"]
 
 
-@pytest.mark.parametrize("tables,wave", [(True, 0), (True, 2), (True, 3)], ids=["name_table", "wave_two_phase", "lane_cached"])
+@pytest.mark.parametrize("tables,wave", [(True, 0), (True, 2), (True, 3), (True, 5)], ids=["name_table", "wave_two_phase", "lane_cached", "wave_strands_by_id"])
 def test_realshape_lines(golden, tables, wave):
     """the exact per-line routine on the lines shaped like real minigraph output (paths of up to 300 nodes, kilobyte tags)"""
     import gzip
@@ -139,7 +139,7 @@ def test_random_graphs(seed):
         assert n_lines == n and _as_dict(g, counts) == wd
     # ... and so do the forms the kernels run it in: 64 cooperating lanes, the two-phase wave routine with its tables of path pieces (one
     # candidate position per piece, asked of the eight bytes around the colons first) and without them, one lane with its per-node results kept
-    for wave in (1, 2, 3, 4):
+    for wave in (1, 2, 3, 4, 5):
         counts, n_lines = sim.classify(g, text, True, wave)
         assert n_lines == n and _as_dict(g, counts) == wd, wave
 
@@ -159,7 +159,7 @@ def test_long_path_fuzz(seed):
     want, _, n = orc.filter(text, want_hits=False)
     wd = {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()}
     assert wd == {k: list(v) for k, v in O.counts_of(O.classify(lines, edges, alt)).items()} and sum(map(sum, wd.values())) > 2000
-    for wave in (0, 2, 3):
+    for wave in (0, 2, 3, 5):
         counts, n_lines = sim.classify(g, text, True, wave)
         assert n_lines == n and _as_dict(g, counts) == wd, wave
     for f in fatal:
@@ -168,6 +168,6 @@ def test_long_path_fuzz(seed):
             O.classify(bad.splitlines(True), edges, alt)
         with pytest.raises(KeyError):
             orc.filter(bad.encode(), want_hits=False)
-        for wave in (0, 2):
+        for wave in (0, 2, 5):
             with pytest.raises(KeyError):
                 sim.classify(g, bad.encode(), True, wave)

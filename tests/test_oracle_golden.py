@@ -325,7 +325,7 @@ def test_contig_names_of_the_grch38_analysis_set(golden, tag):
         g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", native=native)
         assert sim.check_tables(g) == 0
         assert g.n_hazard == 0                                    # (r05: a ':' inside a contig name no longer marks every node name hazard-prone)
-        for wave in (0, 2):
+        for wave in (0, 2, 5):
             counts, n_lines = sim.classify(g, open(pre + ".gaf", "rb").read(), True, wave)
             assert n_lines == n and {g.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(g.n_slots) if counts[i].sum()} == ref
 
@@ -364,7 +364,7 @@ def test_longtail_through_the_reference(golden, tmp_path):
         want, _, n = orc.filter(text, want_hits=False)
         assert {sv: [int(want[i, 0]), int(want[i, 1])] for i, sv in enumerate(orc.sv_ids) if want[i].sum()} == c["counts"]
         g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
-        counts, n2 = sim.classify(g, text, True, 2)
+        counts, n2 = sim.classify(g, text, True, 5)
         assert n2 == n and {g.sv_ids[i]: [int(counts[i, 0]), int(counts[i, 1])] for i in range(g.n_slots) if counts[i].sum()} == c["counts"]
         for f, err in zip(fatal, c["fatal_errors"]):
             for run in (lambda: O.classify(f.decode().splitlines(True), edges, alt), lambda: orc.filter(f, want_hits=False), lambda: sim.classify(g, f, True, 0)):
