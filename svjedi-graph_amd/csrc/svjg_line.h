@@ -583,6 +583,10 @@ SVJG_FN int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
 // stride: node j's entries sit at index j * stride (1: one line per array; 64: the lanes of a wave interleaved, one line per lane)
 struct NodeScratch { SVJG_TAB_AS uint32_t *id; SVJG_TAB_AS int64_t *len; SVJG_TAB_AS uint8_t *rc; SVJG_TAB_AS uint8_t *strand; uint32_t cap; uint32_t stride = 1; };
 
+// can a node's name be taken by its id where its strand is asked for?  (a node of the graph whose name stands inside no other node's name:
+// slow_wave_strands has the argument)
+SVJG_HD bool slow_node_clean(const GraphView &g, uint32_t id) { return id != NONE32 && !(g.nodes[id].row >> 31); }
+
 // pieces: table of the path's pieces (strand_of_pieces; colons, keys: where each has its ':' and what stands around it, optional), or
 // nullptr: the path is searched byte by byte
 template <class P>
@@ -603,6 +607,42 @@ SVJG_HD int slow_wave_phase1(const GraphView &g, P t, const SlowLine &ln, NodeSc
             ns.id[j * ns.stride] = id;
             ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1, tl);
             ns.len[j * ns.stride] = l1;
+        }
+        return 0;
+    }
+    if (nlanes == 1u && ln.oriented) {
+        // one lane, the whole line (k_classify_slow; r05): every node is resolved in ONE walk, which also notes the node's own orientation
+        // mark; if the line is clean (every name a graph node that stands inside no other node's name: slow_wave_strands has the
+        // argument) a node's strand is the mark of the first node with the same id — filled in place, front to back — and the search
+        // through the path's text is not needed; else a second walk searches as before.
+        bool clean = true;
+        uint32_t j = 0;
+        for (; next_node(t, ln.pe, true, pos, nm); ++j) {
+            int64_t l1 = 0;
+            bool alt;
+            int64_t tl;
+            const uint32_t id = resolve_name(g, t, nm, &alt, &tl);
+            ns.id[j * ns.stride] = id;
+            ns.rc[j * ns.stride] = (uint8_t)node_len_resolved(g, t, nm, id, alt, l1, tl);
+            ns.len[j * ns.stride] = l1;
+            ns.strand[j * ns.stride] = t[nm.s - 1] == '>' ? 0u : 1u;
+            clean = clean && slow_node_clean(g, id);
+        }
+        if (clean) {
+            for (uint32_t i = 1; i < j; ++i) {
+                const uint32_t x = ns.id[i * ns.stride];
+                uint32_t f = 0;
+                while (ns.id[f * ns.stride] != x) ++f;
+                if (f != i) ns.strand[i * ns.stride] = ns.strand[f * ns.stride];
+            }
+            return 0;
+        }
+        pos = ln.ps;
+        for (uint32_t i = 0; next_node(t, ln.pe, true, pos, nm); ++i) {
+            uint32_t st = 0;
+            int rc = strand_of(t, ln.ps, ln.pe, nm, st);
+            if (rc) { *order = (1ull << 32) | i; return rc; }
+            ns.strand[i * ns.stride] = (uint8_t)st;
         }
         return 0;
     }
@@ -646,8 +686,6 @@ SVJG_HD void slow_wave_resolve(const GraphView &g, P t, const SlowLine &ln, Node
         ns.len[j * ns.stride] = l1;
     }
 }
-// is node j's name one that can be taken by its id (see above)?
-SVJG_HD bool slow_node_clean(const GraphView &g, uint32_t id) { return id != NONE32 && !(g.nodes[id].row >> 31); }
 template <class P>
 SVJG_HD int slow_wave_strands(P t, const SlowLine &ln, NodeScratch &ns, uint32_t lane, uint32_t nlanes, uint64_t *order, const SVJG_TAB_AS uint32_t *pieces,
                               const SVJG_TAB_AS uint16_t *colons, const SVJG_TAB_AS uint64_t *keys, bool clean, bool oneway) {
