@@ -1047,7 +1047,7 @@ def test_long_paths_a_later_sub_pass_hands_to_the_exact_path(ctx, tmp_path):
         assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
         st, cause = ctx.stats(), ctx.defer_causes()
         assert st["n_lines"] == n_lines and st["n_deferred"] == len(lines) == cause["node_name"] + cause["columns"], (st, cause, len(lines))
-        assert cause["node_name"] >= 0.75 * len(lines)           # (a name of 60 bytes is told in the line phase)
+        assert cause["node_name"] >= 0.75 * len(lines)           # (the lines with the 5 Gbp name have ten-digit length columns: told in the line phase)
         if want_hits:
             capi.write_informative_json(str(tmp_path / "o.json"), arr, ctx.hits(), g.sv_ids)
             assert open(tmp_path / "o.json").read() == ref_text
