@@ -1024,11 +1024,12 @@ def test_long_paths_a_later_sub_pass_hands_to_the_exact_path(ctx, tmp_path):
                 ww = w[:at] + [nm] + w[at + 1:]
                 tails = np.cumsum([nlen(n) for n in reversed(ww)])
                 heads = np.cumsum([nlen(n) for n in ww])
+                tl = 999_999_999 if tag == "huge" else None     # (the length columns hold nine digits at most in the main kernel; Tlen need not be the path's length)
                 for rev in (False, True):
-                    lines.append(line(f"late_{tag}_k{k}a{at}r{int(rev)}", ww, rev))
+                    lines.append(line(f"late_{tag}_k{k}a{at}r{int(rev)}", ww, rev, tl=tl))
                     far = heads if rev else tails                # the 20 nodes at the line's far end stay undecided for long
                     if far[19] > 190:
-                        lines.append(line(f"late_{tag}_k{k}a{at}r{int(rev)}m", ww, rev, te_back=int(far[19]) - 90))
+                        lines.append(line(f"late_{tag}_k{k}a{at}r{int(rev)}m", ww, rev, te_back=int(far[19]) - 90, tl=tl))
             pos = int(w[at].split(":")[-1].replace(".", "-").split("-")[0])
             ww = w[:at] + [f"chr1:{pos}.7"] + w[at + 1:]                # an insertion node the GFA does not have
             for rev in (False, True):
@@ -1047,7 +1048,7 @@ def test_long_paths_a_later_sub_pass_hands_to_the_exact_path(ctx, tmp_path):
         assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want)
         st, cause = ctx.stats(), ctx.defer_causes()
         assert st["n_lines"] == n_lines and st["n_deferred"] == len(lines) == cause["node_name"] + cause["columns"], (st, cause, len(lines))
-        assert cause["node_name"] >= 0.75 * len(lines)           # (the lines with the 5 Gbp name have ten-digit length columns: told in the line phase)
+        assert cause["columns"] <= 4                               # (the 5 Gbp name at the far end of a line with a wide margin: a negative Te column)
         if want_hits:
             capi.write_informative_json(str(tmp_path / "o.json"), arr, ctx.hits(), g.sv_ids)
             assert open(tmp_path / "o.json").read() == ref_text
