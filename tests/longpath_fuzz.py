@@ -266,3 +266,32 @@ def make_tail_case(seed, base_lines, n_mut=400):
     if rng.random() < 0.5:
         text = text[:-1]                                             # the file's last line without a terminator
     return text, fatal
+
+
+def make_soup(seed, n_long=40):
+    """Everything at once on ONE graph (make_graph), shuffled into one file so that the main kernel's special cases meet at stripe
+    boundaries: long paths with one late event (make_case), the same lines with 6..30 KB tails of tag text in front of their terminator
+    (a plain cg:Z: string, a "d:" pair, an id:f: tag with a plain value), runs of 30..120 tiny lines of 28..40 bytes (more lines than a
+    stripe's list holds: the stripe is cut at a line start), ordinary short walks, and empty lines' worth of nothing in between.
+    -> (edges, alt, text: bytes)"""
+    edges, alt, lines, _fatal = make_case(seed, n_long, 0)
+    rng = random.Random(seed * 31 + 5)
+    out = []
+    alphabet = "ACGT0123456789MIDS="
+    some_node = next(iter(edges)).split("@")[0]
+    for l in lines:
+        r = rng.random()
+        body = l[:-1]
+        if r < 0.25:                                                  # a tail beyond the 8 KB stage
+            n = rng.choice((6000, 8192, 12000, 30000)) + rng.randint(-30, 30)
+            tail = "".join(rng.choice(alphabet) for _ in range(64)) * (n // 64 + 1)
+            kind = rng.choice(("plain", "plain", "dcolon", "idf"))
+            ins = {"plain": "", "dcolon": "\txd:Z:", "idf": "\tid:f:0.9911\tzz:Z:"}[kind]
+            at = rng.randint(8, n - 8)
+            body = body + "\tcg:Z:" + tail[:at] + ins + tail[at:n]
+        out.append(body + "\n")
+        if rng.random() < 0.3:                                        # a run of tiny lines: more line starts than a stripe's list holds
+            for i in range(rng.randint(30, 120)):
+                out.append(f"t{i}\t9\t0\t9\t+\t>{some_node}\t9\t0\t9\t9\t9\t{i % 61}\n" if rng.random() < 0.8 else f"u{i}\t1\t0\t1\t-\t<{some_node}\t1\t0\t1\t1\t1\t0\n")
+    rng.shuffle(out)
+    return edges, alt, "".join(out).encode()

@@ -1229,6 +1229,36 @@ def test_long_tail_fuzz(ctx, seed, tmp_path):
             ctx.classify(np.frombuffer(f, dtype=np.uint8))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SVJG_SOUP_SEEDS", "6"))))      # (SVJG_SOUP_SEEDS=100: a campaign)
+def test_everything_at_once(ctx, seed, tmp_path):
+    """tests/longpath_fuzz.py: make_soup — long paths with a late event, lines with tails beyond the stage, runs of tiny lines (more line starts
+    than a stripe's list holds) and ordinary walks on one graph, shuffled into one file: the main kernel's special cases meet at stripe
+    boundaries.  Counts == C oracle, JSON text == Python oracle, main kernel and exact path, step by step and as a fused pass."""
+    from tests import longpath_fuzz
+    from svjg import capi
+    from svjg.graph import Graph
+    edges, alt, text = longpath_fuzz.make_soup(3000 + seed)
+    data = np.frombuffer(text, dtype=np.uint8)
+    orc = OC.COracle(edges, alt)
+    want, _, n = orc.filter(data, want_hits=False)
+    ref_text = O.dump_informative(O.classify(text.decode().splitlines(True), edges, alt))
+    for all_slow in (False, True):
+        g = Graph(edges, alt, all_slow=all_slow)
+        ctx.load_graph(g)
+        ctx.reset_counts()
+        ctx.classify(data, want_hits=True)
+        assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and want.sum() > 3000
+        assert ctx.stats()["n_lines"] == n
+        capi.write_informative_json(str(tmp_path / "o.json"), data, ctx.hits(), g.sv_ids)
+        assert open(tmp_path / "o.json").read() == ref_text
+    g = Graph(edges, alt)
+    ctx.load_graph(g)
+    ctx.upload(data)
+    ctx.reset_counts()
+    ctx.classify_resident()                                             # (the whole text in one launch: other stripe boundaries than the piecewise call's)
+    assert _counts_dict(g, ctx.counts()) == _oracle_dict(orc, want) and ctx.stats()["n_lines"] == n
+
+
 def test_exact_path_per_line_part_at_every_alignment(tmp_path):
     """The one-wave-per-line kernel shares the line's per-line part out over its lanes, 16 bytes a lane and 1 KB a step (r04): the twelfth
     tab, the last "id:f:" and the line's end are put at every position across a step's and a lane's boundary — read names of growing length
