@@ -792,6 +792,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const uint32_t t9 = take_tab(wc, t8 + 1), t10 = take_tab(wc, t8 + 1), t11n = take_tab(wc, t8 + 1);
                     const uint32_t t11 = t11n < e ? t11n : e;
                     bool ok = t10 < e;                                   // eleven tabs inside the (stripped) line: twelve columns
+                    if (RARELY(long_line)) ok = ok && t11n < e;          // (r05; a line that runs past the staged text: its twelfth column must END in the stage — "60" staged, "x" in the tail is no number)
                     // the nine decimal columns: 1..9 characters each, nothing but digits in them
                     ok &= (t1 - t0 - 2u <= 8u) & (t2 - t1 - 2u <= 8u) & (t3 - t2 - 2u <= 8u);
                     ok &= (t6 - t5 - 2u <= 8u) & (t7 - t6 - 2u <= 8u) & (t8 - t7 - 2u <= 8u);
@@ -875,7 +876,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     uint32_t verdict = 2u;                               // 0: no tag in this line, 1: a tag with a plain value, 2: the exact path decides
                     if (!unsure && mine == 0u) verdict = 0u;
                     else if (!unsure && mine == 1u) {
-                        if (!(q > s && q + 4u <= e && text[q - 1u] == 'i' && text[q + 2u] == 'f' && text[q + 3u] == ':')) verdict = 0u;   // (inside the stripped line, like `in line`)
+                        // (r05) a line that runs past the staged text (long_line: its tail is walked apart, above) may hold a tag that the stage's end
+                        // cuts — its "id:f:" or its value continue in the tail, which only rules out a pair "d:" of its own —: the exact path decides
+                        if (!(q > s && q + 4u <= e && text[q - 1u] == 'i' && text[q + 2u] == 'f' && text[q + 3u] == ':')) verdict = (RARELY(long_line) && q + 4u > e) ? 2u : 0u;   // (inside the stripped line, like `in line`)
                         else {
                             const uint32_t v0 = q + 4u;                  // value = text[v0, first tab or end of the stripped line)
 #ifdef SVJG_W16
@@ -888,6 +891,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
 #ifdef SVJG_W16
                             n = 0u;
 #endif
+                            if (RARELY(long_line) && v0 + n >= e) n = 0u;    // (no tab in front of the stage's end: the value goes on in the tail)
                             if (n >= 1u && n <= 31u) {
                                 const uint32_t nd = nw & ((1u << n) - 1u);
                                 if (nd == 0u) verdict = 1u;

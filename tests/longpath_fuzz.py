@@ -231,6 +231,8 @@ def make_tail_case(seed, base_lines, n_mut=400):
         target = rng.choice((b * rng.randint(1, max(1, (len(head) + tail_len) // b)), len(head) + rng.randint(0, tail_len - 1)))
         if rng.random() < 0.5:
             target = target - ((pos + target) % b) + rng.choice((-1, 0, 0, 1))          # on a boundary of the FILE offset
+        if rng.random() < 0.25:
+            target = 8192 - (pos % 16) + rng.randint(-24, 8)                            # around the END OF THE STAGE of a stripe that begins with this line (seed 271 of r05's campaign: a tag cut there)
         at = min(max(target - len(head), 8), tail_len - 24)
         extra = b""
         if kind == "cr":

@@ -1229,6 +1229,84 @@ def test_long_tail_fuzz(ctx, seed, tmp_path):
             ctx.classify(np.frombuffer(f, dtype=np.uint8))
 
 
+def test_identity_tag_cut_by_the_end_of_the_stage(ctx, tmp_path):
+    """A line that runs past the main kernel's 8 KB stage keeps its place there when its tail is plain (r04).  Found by the long-tail fuzzer
+    in r05 (seed 271 of 400): an id:f: tag that the stage's END cuts — "id:" staged and "f:0.9x75" in the tail, or the value's first digit
+    staged and the rest of it in the tail — was read as "no tag" / "a tag with a plain value" and a line the reference dies on
+    (`float()`: ValueError, filter-alignments.py:193-196) was accepted.  Such a line now takes the exact path.  Here: the tag at every
+    offset from 40 bytes in front of the stage's end to 12 behind it, for every alignment of the line's start (the stage begins at the
+    16-byte block that holds it), with a plain value, a malformed one, a pair "d:" that is no tag, and Alen == 0 with a tag (no
+    ZeroDivisionError then) — counts or the exception class are the C oracle's every time."""
+    import synth
+    from svjg.graph import Graph
+    pre = str(tmp_path / "c")
+    inf = synth.generate(pre, 400, 100, 1, "mixed", 77, write_gaf=False, return_gaf=True)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    lines = inf["gaf"].tobytes().split(b"\n")[:-1]
+    only, _, _ = orc.filter(b"".join(l + b"\n" for l in lines), want_hits=False)
+    base = next(l for l in lines if orc.filter(l + b"\n", want_hits=False)[0].sum() >= 2)     # a line with hits
+    cols = base.split(b"\t")
+    zero = b"\t".join(cols[:10] + [b"0"] + cols[11:])                                       # Alen == 0
+    ctx.load_graph(g)
+    n_checked = n_fatal = 0
+    for shift in range(16):
+        head = b"x" * (15 + shift) + b"\t9\t0\t9\t+\t>n\t9\t0\t9\t9\t9\t6\n"            # a first line that puts the next line's start at every offset mod 16
+        line_at = len(head)
+        stage_end = 8192 - (line_at % 16)                                                    # offset in the line at which the staged text ends
+        for rel in range(-40, 13, 1):
+            for body, insert in ((base, b"\tid:f:0.9875\t"), (base, b"\tid:f:0.9x75\t"), (base, b"\txd:Z:AA\t"), (zero, b"\tid:f:1\t"), (zero, b"\tid:f:x\t")):
+                at = stage_end + rel                                                         # where the insert's first byte stands
+                fill = at - len(body) - 6
+                text = head + body + b"\tcg:Z:" + b"M" * fill + insert + b"zz:Z:" + b"C" * 900 + b"\n" + lines[3] + b"\n"
+                assert text[line_at + at:line_at + at + len(insert)] == insert
+                exp = got = None
+                try:
+                    want, _, n = orc.filter(text, want_hits=False)
+                    exp = ("ok", _oracle_dict(orc, want), n)
+                except Exception as e:                                                       # noqa: BLE001
+                    exp = ("died", type(e).__name__)
+                ctx.reset_counts()
+                try:
+                    ctx.classify(np.frombuffer(text, dtype=np.uint8))
+                    got = ("ok", _counts_dict(g, ctx.counts()), ctx.stats()["n_lines"])
+                except Exception as e:                                                       # noqa: BLE001
+                    got = ("died", type(e).__name__)
+                assert got == exp, (shift, rel, insert)
+                n_checked += 1
+                n_fatal += exp[0] == "died"
+    assert n_checked == 16 * 53 * 5 and n_fatal == 16 * 53 * 2
+    # ... and the TWELFTH COLUMN cut by the stage's end (a read name of 8 KB puts it there): "60" staged and "x" in the tail is no number
+    n_checked = n_fatal = 0
+    for shift in (0, 5, 15):
+        head = b"x" * (15 + shift) + b"\t9\t0\t9\t+\t>n\t9\t0\t9\t9\t9\t6\n"
+        line_at = len(head)
+        stage_end = 8192 - (line_at % 16)
+        rest = b"\t".join(cols[1:11])                                                        # columns 2..11
+        for rel in range(-6, 4):
+            for last in (b"60", b"6x", b"601x", b"60\ttp:A:P", b"6x\ttp:A:P", b"123456"):
+                name_len = stage_end + rel - len(rest) - 2                                   # the twelfth column starts at stage_end + rel
+                text = head + b"r" * name_len + b"\t" + rest + b"\t" + last + b"C" * 0 + (b"\tzz:Z:" + b"C" * 700 if b"tp" in last else b"") + b"\n" + lines[3] + b"\n"
+                line = text[line_at:].split(b"\n")[0]
+                if len(line) <= 8192:                                                        # (only lines that run past the stage are this section's business)
+                    text = head + b"r" * name_len + b"\t" + rest + b"\t" + last + b"\tzz:Z:" + b"C" * 900 + b"\n" + lines[3] + b"\n"
+                try:
+                    want, _, n = orc.filter(text, want_hits=False)
+                    exp = ("ok", _oracle_dict(orc, want), n)
+                except Exception as e:                                                       # noqa: BLE001
+                    exp = ("died", type(e).__name__)
+                ctx.reset_counts()
+                try:
+                    ctx.classify(np.frombuffer(text, dtype=np.uint8))
+                    got = ("ok", _counts_dict(g, ctx.counts()), ctx.stats()["n_lines"])
+                except Exception as e:                                                       # noqa: BLE001
+                    got = ("died", type(e).__name__)
+                assert got == exp, (shift, rel, last)
+                n_checked += 1
+                n_fatal += exp[0] == "died"
+    assert n_checked == 3 * 10 * 6 and n_fatal >= 3 * 10 * 3
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SVJG_SOUP_SEEDS", "6"))))      # (SVJG_SOUP_SEEDS=100: a campaign)
 def test_everything_at_once(ctx, seed, tmp_path):
     """tests/longpath_fuzz.py: make_soup — long paths with a late event, lines with tails beyond the stage, runs of tiny lines (more line starts
