@@ -83,9 +83,9 @@ def _name_len(n, length):
     return int(b) - int(a) + 1
 
 
-def make_case(seed, n_lines=60, n_fatal=6):
+def make_case(seed, n_lines=60, n_fatal=6, graph_seed=None):
     """-> (edges, alt, lines, fatal): `lines` the reference classifies, `fatal` lines it dies on (one per run)"""
-    edges, alt, ref, length = make_graph(seed)
+    edges, alt, ref, length = make_graph(seed if graph_seed is None else graph_seed)
     rng = random.Random(seed)
     nxt, ins_after = {}, {}
     for key in edges:
@@ -270,13 +270,13 @@ def make_tail_case(seed, base_lines, n_mut=400):
     return text, fatal
 
 
-def make_soup(seed, n_long=40):
+def make_soup(seed, n_long=40, graph_seed=None):
     """Everything at once on ONE graph (make_graph), shuffled into one file so that the main kernel's special cases meet at stripe
     boundaries: long paths with one late event (make_case), the same lines with 6..30 KB tails of tag text in front of their terminator
     (a plain cg:Z: string, a "d:" pair, an id:f: tag with a plain value), runs of 30..120 tiny lines of 28..40 bytes (more lines than a
     stripe's list holds: the stripe is cut at a line start), ordinary short walks, and empty lines' worth of nothing in between.
     -> (edges, alt, text: bytes)"""
-    edges, alt, lines, _fatal = make_case(seed, n_long, 0)
+    edges, alt, lines, _fatal = make_case(seed, n_long, 0, graph_seed)
     rng = random.Random(seed * 31 + 5)
     out = []
     alphabet = "ACGT0123456789MIDS="

@@ -1229,6 +1229,49 @@ def test_long_tail_fuzz(ctx, seed, tmp_path):
             ctx.classify(np.frombuffer(f, dtype=np.uint8))
 
 
+def test_everything_at_once_two_gigabytes(tmp_path):
+    """The special cases under the CHUNKED work distribution, which only texts of 1.9 GB and more get (a worker's first chunk is 85 % of an even
+    share, the rest goes in 64 KB chunks to whoever is free next): 24 files of tests/longpath_fuzz.py: make_soup on ONE graph — long paths with a
+    late event, tails beyond the stage, runs of tiny lines — tiled in a seeded random order to 2 GB, resident, one launch.  The counts are the sum
+    of the C oracle's counts of the files (each counted once, times how often it was tiled)."""
+    import random
+    from tests import longpath_fuzz
+    from svjg import capi
+    from svjg.graph import Graph
+    if os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") < (16 << 30):
+        pytest.skip("needs 16 GB of host memory")
+    files, want, n_lines = [], None, []
+    for i in range(24):
+        edges, alt, text = longpath_fuzz.make_soup(8000 + i, 30, graph_seed=8000)
+        if want is None:
+            orc = OC.COracle(edges, alt)
+            g = Graph(edges, alt)
+        c, _, n = orc.filter(text, want_hits=False)
+        files.append((text, c.astype(np.int64), n))
+    rng = random.Random(11)
+    order, size = [], 0
+    while size < (2 << 30):
+        k = rng.randrange(len(files))
+        order.append(k)
+        size += len(files[k][0])
+    data = np.frombuffer(b"".join(files[k][0] for k in order), dtype=np.uint8)
+    total = sum(files[k][1] for k in order)
+    lines = sum(files[k][2] for k in order)
+    c = capi.Context(0)
+    try:
+        c.load_graph(g)
+        c.upload(data)
+        for _ in range(2):
+            c.reset_counts()
+            c.classify_resident()
+            got = c.counts()
+            st = c.stats()
+            assert st["n_lines"] == lines
+            assert _counts_dict(g, got) == {sv: [int(total[i, 0]), int(total[i, 1])] for i, sv in enumerate(orc.sv_ids) if total[i].sum()}
+    finally:
+        c.close()
+
+
 def test_identity_tag_cut_by_the_end_of_the_stage(ctx, tmp_path):
     """A line that runs past the main kernel's 8 KB stage keeps its place there when its tail is plain (r04).  Found by the long-tail fuzzer
     in r05 (seed 271 of 400): an id:f: tag that the stage's END cuts — "id:" staged and "f:0.9x75" in the tail, or the value's first digit
