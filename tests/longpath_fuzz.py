@@ -270,7 +270,7 @@ def make_tail_case(seed, base_lines, n_mut=400):
     return text, fatal
 
 
-def make_soup(seed, n_long=40, graph_seed=None):
+def make_soup(seed, n_long=40, graph_seed=None, terminators=False):
     """Everything at once on ONE graph (make_graph), shuffled into one file so that the main kernel's special cases meet at stripe
     boundaries: long paths with one late event (make_case), the same lines with 6..30 KB tails of tag text in front of their terminator
     (a plain cg:Z: string, a "d:" pair, an id:f: tag with a plain value), runs of 30..120 tiny lines of 28..40 bytes (more lines than a
@@ -296,4 +296,9 @@ def make_soup(seed, n_long=40, graph_seed=None):
             for i in range(rng.randint(30, 120)):
                 out.append(f"t{i}\t9\t0\t9\t+\t>{some_node}\t9\t0\t9\t9\t9\t{i % 61}\n" if rng.random() < 0.8 else f"u{i}\t1\t0\t1\t-\t<{some_node}\t1\t0\t1\t1\t1\t0\n")
     rng.shuffle(out)
+    if terminators:                                                   # the reference reads in text mode: "\n", "\r\n" and a lone "\r" all end a line (and reach the JSON as "\n")
+        out = [l[:-1] + rng.choice(("\n",) * 8 + ("\r\n", "\r\n", "\r")) for l in out]
+        for i in range(len(out) - 1):                                 # (a lone "\r" in front of a line that begins with "\n"-less text only: "\r" + "\n..." would be ONE terminator)
+            if out[i].endswith("\r") and not out[i].endswith("\r\n") and out[i + 1].startswith("\n"):
+                out[i] = out[i][:-1] + "\n"
     return edges, alt, "".join(out).encode()
