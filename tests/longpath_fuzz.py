@@ -222,7 +222,7 @@ def make_tail_case(seed, base_lines, n_mut=400):
             out.append(l + b"\n")
             pos += len(l) + 1
             continue
-        tail_len = rng.choice((6000, 8100, 8192, 9000, 12288, 16384, 20000, 40000)) + rng.randint(-40, 40)
+        tail_len = rng.choice((6000, 8100, 8192, 9000, 12288, 16384, 20000, 40000, 53376 - len(l), 70000)) + rng.randint(-40, 40)   # (53 376 B: what the one-wave-per-line kernel stages of a line)
         kind = rng.choice(("plain", "plain", "cr", "dcolon", "dcolon_split", "idf_ok", "idf_bad", "utf8", "many_tags", "end_on_boundary"))
         head = l + b"\tcg:Z:"
         body = bytearray(filler(tail_len)[:tail_len])

@@ -1209,6 +1209,11 @@ def test_long_tail_fuzz(ctx, seed, tmp_path):
     text, fatal = longpath_fuzz.make_tail_case(900 + seed, base, 300)
     want, _, n_lines = orc.filter(text, want_hits=False)
     arr = np.frombuffer(text, dtype=np.uint8)
+    g_slow = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa", all_slow=True)
+    ctx.load_graph(g_slow)                                             # every line on the exact path (its own staging: 53 KB a line, longer lines from global memory)
+    ctx.reset_counts()
+    ctx.classify(arr)
+    assert _counts_dict(g_slow, ctx.counts()) == _oracle_dict(orc, want) and ctx.stats()["n_lines"] == n_lines
     ctx.load_graph(g)
     for want_hits in (False, True):
         ctx.reset_counts()
@@ -1224,9 +1229,11 @@ def test_long_tail_fuzz(ctx, seed, tmp_path):
     for f in fatal[:6]:
         with pytest.raises(ValueError):
             orc.filter(f, want_hits=False)
-        ctx.reset_counts()
-        with pytest.raises(ValueError):
-            ctx.classify(np.frombuffer(f, dtype=np.uint8))
+        for gx in (g, g_slow):
+            ctx.load_graph(gx)
+            ctx.reset_counts()
+            with pytest.raises(ValueError):
+                ctx.classify(np.frombuffer(f, dtype=np.uint8))
 
 
 def test_everything_at_once_two_gigabytes(tmp_path):
