@@ -280,13 +280,13 @@ def main():
             sys.stderr.write(f"[bench] copy rate not measured: {e}\n")
     # the untimed blocks must never cost the line its `value`: a failure in one of them is reported in its place
     ns = None
-    e2e_ns_dir = None                                            # the files of configs[3] for the e2e_north_star leg (rank 0 writes the text as it uploads it)
+    e2e_ns_dir = e2e_ns_skip = None                              # the files of configs[3] for the e2e_north_star leg (rank 0 writes the text as it uploads it), or why there are none
     if not args.no_north_star:
         if (not args.no_e2e_north_star and not args.no_e2e and rank == 0 and n_total_ranks == 1 and not os.environ.get("SVJG_BENCH_CAPI")
                 and args.north_star_aln == NORTH_STAR["aln"] and args.north_star_svs == NORTH_STAR["svs"]):
-            e2e_ns_dir = e2e_scratch(E2E_NS_BYTES)
+            e2e_ns_dir, e2e_ns_skip = e2e_scratch(E2E_NS_BYTES)
         try:
-            ns = north_star_block(capi, synth, genotype, Graph, ctxs, rank, world, n_local, dist, args, tmp, tee_dir=e2e_ns_dir if isinstance(e2e_ns_dir, str) else None)
+            ns = north_star_block(capi, synth, genotype, Graph, ctxs, rank, world, n_local, dist, args, tmp, tee_dir=e2e_ns_dir)
         except Exception as e:                                   # noqa: BLE001
             if world > 1:                                        # (a rank that leaves the block early leaves its peers in the block's collectives:
                 raise                                            #  under a launcher the failure ends the run, non-zero, instead of hanging it)
@@ -377,7 +377,9 @@ def main():
             for c in ctxs:
                 c.close()
             ctxs = []
-            res["e2e_north_star"] = end_to_end_north_star(e2e_ns_dir, ns) if isinstance(e2e_ns_dir, str) else e2e_ns_dir
+            res["e2e_north_star"] = end_to_end_north_star(e2e_ns_dir, ns)
+        elif e2e_ns_skip is not None:
+            res["e2e_north_star"] = {"skipped": e2e_ns_skip}
         print(json.dumps(res))
     for c in ctxs:
         c.close()
@@ -627,18 +629,18 @@ E2E_NS_BYTES = 160 << 30            # e2e_north_star: 21.6 GB of GAF + 117.3 GB 
 
 
 def e2e_scratch(need):
-    """-> a fresh directory on /dev/shm with `need` bytes free, or {"skipped": why}"""
+    """-> (a fresh directory on /dev/shm with `need` bytes free, None) or (None, why not)"""
     import shutil
     base = "/dev/shm"
     try:
         if not os.path.isdir(base):
-            return {"skipped": "no /dev/shm"}
+            return None, "no /dev/shm"
         free = shutil.disk_usage(base).free
         if free < need:
-            return {"skipped": f"/dev/shm has {free >> 30} GB free, the files of configs[3] need {need >> 30} GB"}
-        return tempfile.mkdtemp(prefix="svjg_e2e_ns_", dir=base)
+            return None, f"/dev/shm has {free >> 30} GB free, the files of configs[3] need {need >> 30} GB"
+        return tempfile.mkdtemp(prefix="svjg_e2e_ns_", dir=base), None
     except OSError as e:
-        return {"skipped": str(e)}
+        return None, str(e)
 
 
 def end_to_end_north_star(work, ns):
