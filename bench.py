@@ -499,7 +499,6 @@ def north_star_block(capi, synth, genotype, Graph, ctxs, rank, world, n_local, d
     spelling of the digest).  Reuses the run's contexts.  tee_dir: this rank's text is also written to <tee_dir>/c4.gaf as it is uploaded,
     and the graph files copied there (the e2e_north_star leg's inputs)."""
     import digest
-    import shutil
     t0 = time.time()
     total, n_sv = int(args.north_star_aln), int(args.north_star_svs)
     n_ranks = world * n_local
