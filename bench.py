@@ -496,8 +496,8 @@ def north_star_block(capi, synth, genotype, Graph, ctxs, rank, world, n_local, d
     (zero, classify, all-reduce, genotype all 500 k rows) as in the timed loop: alignments per second over all ranks, kernel times, the
     digest of the summed count vector (equal on every rank behind the all-reduce) — and, at the full size, equal to the C oracle's over
     all 100 M lines (tests/golden/synth/c4_oracle.json, written by tests/c4_oracle_counts.py --golden; tools/digest.py is the one
-    spelling of the digest).  Reuses the run's contexts.  tee_dir: this rank's text is also written to <tee_dir>/c4.gaf as it is uploaded,
-    and the graph files copied there (the e2e_north_star leg's inputs)."""
+    spelling of the digest).  Reuses the run's contexts.  tee_dir: the graph files are generated there and this rank's text is also written to
+    <tee_dir>/c4.gaf as it is uploaded (the e2e_north_star leg's inputs)."""
     import digest
     t0 = time.time()
     total, n_sv = int(args.north_star_aln), int(args.north_star_svs)
