@@ -13,7 +13,11 @@ SO = os.path.join(HERE, "_build", "liboracle.so")
 SRC = os.path.join(HERE, "svjg_oracle.c")
 
 HIT_DTYPE = np.dtype([("line_index", "<u8"), ("line_start", "<u8"), ("sv", "<u4"), ("allele", "<u4")])
-_ERR = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError, 9: MemoryError}
+class Undecided(Exception):
+    """a number beyond what the C restatement represents (more than 18 digits): it says so instead of guessing (svjg_oracle.c: ORC_UNDECIDED)"""
+
+
+_ERR = {1: ValueError, 2: IndexError, 3: KeyError, 4: ZeroDivisionError, 7: Undecided, 9: MemoryError}
 
 
 def build(force=False):
@@ -74,6 +78,19 @@ class COracle:
         if rc:
             raise _ERR[rc](f"line {el.value}")
         return counts, (hits[: nh.value] if want_hits else None), nl.value
+
+
+    def filter_cases(self, frags):
+        """Many small GAF fragments (list of bytes), each on its own -> (counts uint64[n, n_sv, 2], exception class or None per fragment)"""
+        offs = np.zeros(len(frags) + 1, np.uint64)
+        np.cumsum([len(f) for f in frags], out=offs[1:])
+        buf = np.frombuffer(b"".join(frags) + b"\0", dtype=np.uint8)
+        counts = np.zeros((len(frags), len(self.sv_ids), 2), dtype=np.uint64)
+        rc = np.zeros(len(frags), np.int32)
+        self.lib.orc_filter_cases.restype = None
+        self.lib.orc_filter_cases.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        self.lib.orc_filter_cases(self.h, buf.ctypes.data, offs.ctypes.data, len(frags), counts.ctypes.data, len(self.sv_ids), rc.ctypes.data)
+        return counts, [_ERR[int(x)] if x else None for x in rc]
 
 
 def line_text(gaf_bytes, start):

@@ -16,7 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { ORC_OK = 0, ORC_VALUE_ERROR = 1, ORC_INDEX_ERROR = 2, ORC_KEY_ERROR = 3, ORC_ZERO_DIVISION = 4, ORC_HIT_OVERFLOW = 9, ORC_NOMEM = 9 };
+enum { ORC_OK = 0, ORC_VALUE_ERROR = 1, ORC_INDEX_ERROR = 2, ORC_KEY_ERROR = 3, ORC_ZERO_DIVISION = 4, ORC_UNDECIDED = 7, ORC_HIT_OVERFLOW = 9, ORC_NOMEM = 9 };
 
 typedef struct { uint32_t sv, allele; } entry_t;
 typedef struct { char *key; uint32_t klen; entry_t *ent; uint32_t n, cap; } edge_t;
@@ -104,29 +104,34 @@ void orc_add_alt_node(void *p, const char *name, int64_t len) {
 
 /* ---- Python-flavoured scalar parsing -------------------------------------------------------- */
 
-static int py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+/* Two blank sets: str.rstrip() takes what str.isspace() takes (ASCII: ' ', 9..13, 28..31); int() / float() strip what C isspace() takes
+ * (' ', 9..13) — "5\x1f" is a ValueError.  (r05 and before used the first set for both: found by the r05 judge's differential fuzz; the
+ * product's exact routine had the same misreading, so comparing the two could not show it.  tests/test_oracle_cross_fuzz.py now fuzzes
+ * this file against the Python oracle, which calls Python's own int() / float().) */
+static int py_strip_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+static int c_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
 
-#define BIG ((int64_t)1 << 61)
-
-/* int(str): optional blanks, sign, digits with single underscores; saturates far outside any length */
+/* int(str): optional blanks, sign, digits with single underscores.  1 = the value, exactly; 0 = ValueError; 2 = a valid spelling of more
+ * than 18 digits: beyond what this restatement represents (Python's integers have no width, and CPython >= 3.10.7 refuses more than
+ * 4300 digits) -> ORC_UNDECIDED, never a guess */
 static int py_int(const char *s, size_t n, int64_t *out) {
     size_t i = 0;
-    while (i < n && py_space((unsigned char)s[i])) ++i;
-    while (n > i && py_space((unsigned char)s[n - 1])) --n;
+    while (i < n && c_space((unsigned char)s[i])) ++i;
+    while (n > i && c_space((unsigned char)s[n - 1])) --n;
     int neg = 0;
     if (i < n && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
     if (i >= n || s[i] < '0' || s[i] > '9') return 0;
-    int64_t v = 0; int prev_us = 0;
+    int64_t v = 0; int prev_us = 0; int nd = 0;
     for (; i < n; ++i) {
         if (s[i] == '_') { if (prev_us) return 0; prev_us = 1; continue; }
         if (s[i] < '0' || s[i] > '9') return 0;
         prev_us = 0;
-        if (v < BIG) v = v * 10 + (s[i] - '0');
+        if (nd < 18) v = v * 10 + (s[i] - '0');
+        if (nd < 19) ++nd;
     }
     if (prev_us) return 0;
-    if (v > BIG) v = BIG;
     *out = neg ? -v : v;
-    return 1;
+    return nd > 18 ? 2 : 1;
 }
 
 static int ieq(const char *s, size_t n, const char *w) {
@@ -150,8 +155,8 @@ static size_t digits_us(const char *s, size_t i, size_t n, int *ok) {
 /* does float(str) succeed? */
 static int py_float_ok(const char *s, size_t n) {
     size_t i = 0;
-    while (i < n && py_space((unsigned char)s[i])) ++i;
-    while (n > i && py_space((unsigned char)s[n - 1])) --n;
+    while (i < n && c_space((unsigned char)s[i])) ++i;
+    while (n > i && c_space((unsigned char)s[n - 1])) --n;
     if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
     if (ieq(s + i, n - i, "inf") || ieq(s + i, n - i, "infinity") || ieq(s + i, n - i, "nan")) return 1;
     int ok = 1;
@@ -195,8 +200,8 @@ static int node_len(oracle_t *o, const char *nm, size_t n, int64_t *out) {
     const char *d2 = (const char *)memchr(e0, '-', rest);
     size_t en = d2 ? (size_t)(d2 - e0) : rest;
     int64_t s, e;
-    if (!py_int(e0, en, &e)) return ORC_VALUE_ERROR;
-    if (!py_int(co, (size_t)(d1 - co), &s)) return ORC_VALUE_ERROR;
+    { int r = py_int(e0, en, &e); if (r != 1) return r ? ORC_UNDECIDED : ORC_VALUE_ERROR; }
+    { int r = py_int(co, (size_t)(d1 - co), &s); if (r != 1) return r ? ORC_UNDECIDED : ORC_VALUE_ERROR; }
     *out = e - s + 1; return ORC_OK;
 }
 
@@ -209,7 +214,7 @@ static int same(const nm_t *a, const nm_t *b) { return a->n == b->n && memcmp(a-
 static int do_line(oracle_t *o, const char *ln, size_t n, uint64_t li, uint64_t lstart,
                    uint64_t *counts, uint64_t n_sv, orc_hit_t *hits, uint64_t hit_cap, uint64_t *n_hits)
 {
-    while (n > 0 && py_space((unsigned char)ln[n - 1])) --n;          /* line.rstrip() */
+    while (n > 0 && py_strip_space((unsigned char)ln[n - 1])) --n;    /* line.rstrip() */
     const char *f[12]; size_t fl[12]; int nf = 0;
     { size_t st = 0;
       for (size_t i = 0; i <= n && nf < 12; ++i)
@@ -217,7 +222,7 @@ static int do_line(oracle_t *o, const char *ln, size_t n, uint64_t li, uint64_t 
     if (nf < 12) return ORC_VALUE_ERROR;                              /* tuple unpacking of the slices */
     int64_t v[12];
     static const int intcols[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
-    for (int j = 0; j < 9; ++j) if (!py_int(f[intcols[j]], fl[intcols[j]], &v[intcols[j]])) return ORC_VALUE_ERROR;
+    for (int j = 0; j < 9; ++j) { int r = py_int(f[intcols[j]], fl[intcols[j]], &v[intcols[j]]); if (r != 1) return r ? ORC_UNDECIDED : ORC_VALUE_ERROR; }
     { const char *last = NULL, *h = ln; size_t hn = n;
       for (;;) { const char *q = find(h, hn, "id:f:", 5); if (!q) break; last = q; hn -= (size_t)(q + 1 - h); h = q + 1; }
       if (last) {
@@ -276,10 +281,10 @@ static int do_line(oracle_t *o, const char *ln, size_t n, uint64_t li, uint64_t 
                     int il = 0, ir = 0;
                     while (!same(&nm[il], L)) ++il;
                     while (!same(&nm[ir], R)) ++ir;
-                    int64_t left = 0, right = 0, l1; int rc;
+                    __int128 left = 0, right = 0; int64_t l1; int rc;       /* (values below 10^18 each: exact in 128 bits for any path) */
                     for (int j = 0; j <= il; ++j) { if ((rc = node_len(o, nm[j].p, nm[j].n, &l1))) return rc; left += l1; }
                     for (int j = ir; j < k; ++j) { if ((rc = node_len(o, nm[j].p, nm[j].n, &l1))) return rc; right += l1; }
-                    ok = (left - Ts >= 100) && (right - (Tlen - Te - 1) >= 100);
+                    ok = (left - Ts >= 100) && (right - ((__int128)Tlen - Te - 1) >= 100);
                     have_ok = 1;
                 }
                 if (!ok) continue;
@@ -316,4 +321,14 @@ int orc_filter(void *p, const char *gaf, uint64_t n, uint64_t *counts, uint64_t 
     }
     *n_lines = li;
     return ORC_OK;
+}
+
+/* many small GAF fragments against one table (tests/test_oracle_cross_fuzz.py): fragment i = gaf[offs[i], offs[i + 1]); its counts go to
+ * counts[i * n_sv * 2 ..] (zeroed by the caller), what orc_filter returns for it to rc[i] */
+void orc_filter_cases(void *p, const char *gaf, const uint64_t *offs, uint64_t n_cases, uint64_t *counts, uint64_t n_sv, int *rc)
+{
+    for (uint64_t i = 0; i < n_cases; ++i) {
+        uint64_t nh = 0, nl = 0, el = 0;
+        rc[i] = orc_filter(p, gaf + offs[i], offs[i + 1] - offs[i], counts + i * n_sv * 2, n_sv, NULL, 0, &nh, &nl, &el);
+    }
 }

@@ -766,8 +766,8 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 status = ST_DEFER;
                 if (nx != 0xFFFFu || eof_h) {                            // (always: the stripe handles only lines that end in it)
                     uint32_t e = nx != 0xFFFFu ? nx - 1 : Vh;
-                    if (e > s && py_space(text[e - 1])) {                // line.rstrip(): blanks, a CR, trailing tabs
-                        do --e; while (e > s && py_space(text[e - 1]));
+                    if (e > s && py_strip_space(text[e - 1])) {          // line.rstrip(): blanks, a CR, trailing tabs
+                        do --e; while (e > s && py_strip_space(text[e - 1]));
                     }
                     // the twelve column ends, one after the other on the tab bitmap: a decimal column has its tab within ten bytes
                     // (one 32-bit window); read name, strand and path column may be any length
@@ -1512,7 +1512,7 @@ __device__ inline int slow_wave_links_summed(const GraphView &g, const SlowLine 
 typedef const __attribute__((address_space(3))) uint8_t *slow_lds_text;
 __device__ inline int slow_prologue_wave(slow_lds_text t, uint64_t s, uint64_t e, SlowLine &o, uint32_t lane) {
     o.k = 0;
-    while (e > s && py_space(t[e - 1])) --e;
+    while (e > s && py_strip_space(t[e - 1])) --e;
     // the first twelve tabs of t[s, e)
     uint32_t tp[12], nt = 0;
 #pragma unroll
@@ -1541,7 +1541,7 @@ __device__ inline int slow_prologue_wave(slow_lds_text t, uint64_t s, uint64_t e
     int64_t v6 = 0, v7 = 0, v8 = 0, v10 = 0;
     {
         int64_t v = 0;
-#define SVJG_COL(c, keep) do { if (!py_int(t, fs(c), fe(c), v)) return has_high(t, fs(c), fe(c)) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR; keep; } while (0)
+#define SVJG_COL(c, keep) do { const int r_ = py_int(t, fs(c), fe(c), v); if (r_ != PY_INT_OK) return r_ == PY_INT_BIG || has_high(t, fs(c), fe(c)) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR; keep; } while (0)
         SVJG_COL(1, (void)0); SVJG_COL(2, (void)0); SVJG_COL(3, (void)0); SVJG_COL(6, v6 = v); SVJG_COL(7, v7 = v); SVJG_COL(8, v8 = v);
         SVJG_COL(9, (void)0); SVJG_COL(10, v10 = v); SVJG_COL(11, (void)0);
 #undef SVJG_COL

@@ -127,7 +127,11 @@ SVJG_HD void link_slots(uint64_t v, uint32_t seed, uint32_t mask, uint32_t &s1, 
     if (s2 == s1) s2 = s1 ^ 1u;
 }
 
-SVJG_HD bool py_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+// Two blank sets (r06; the r05 tree used the first for both and accepted "1100\x1f" as a column where the reference dies):
+// str.rstrip() / str.strip() without an argument take what str.isspace() takes — for ASCII: ' ', 9..13 AND 28..31 (filter-alignments.py:125);
+// int() / float() of a str strip what C's isspace() takes — ' ', 9..13 only: 0x1C..0x1F next to a number is a ValueError (:188-194).
+SVJG_HD bool py_strip_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+SVJG_HD bool c_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13); }
 
 // ---- byte searches of the exact routine, eight bytes per step ---------------------------------------------------------------
 // The exact routine walks a line byte by byte; where it only LOOKS FOR a byte (the next tab, the next path separator, the next 'i' of
@@ -212,28 +216,36 @@ SVJG_HD uint32_t edge_hit(const GraphView &g, const svjg_edge &e, uint32_t j) {
 // exact path
 // ---------------------------------------------------------------------------------------------------
 
-constexpr int64_t BIGV = (int64_t)1 << 61;
-
-// Python int(): blanks, sign, digits with single inner underscores (ASCII subset)
+// Python int() of t[a, b): blanks (C isspace), sign, digits with single inner underscores (ASCII subset).
+//   PY_INT_BAD  : int() raises ValueError (if the text holds bytes >= 0x80 the host asks Python: Unicode digits and blanks)
+//   PY_INT_OK   : the value, exactly
+//   PY_INT_BIG  : a valid spelling of more than max_digits digits.  Python's integers have no width — and since CPython 3.10.7 int() refuses
+//                 more than sys.get_int_max_str_digits() = 4300 digits unless the interpreter is told otherwise —; this routine's are
+//                 64 bits wide.  Such a value is never guessed at: the line goes to the host (SVJG_EXC_ASK_HOST), where Python's own int()
+//                 decides and the three columns that matter are rewritten within range with the same meaning (svjg/filter.py: host_line).
+// max_digits: 18 for a column (|v| < 10^18: Tlen - Te - 1 and the differences with the path sums below stay inside 64 bits), 12 for a
+// coordinate inside a node name that is no node of the graph (:343-349: its "length" is end - start + 1, and up to 2^16 of them are summed).
+constexpr int PY_INT_BAD = 0, PY_INT_OK = 1, PY_INT_BIG = 2;
+constexpr uint32_t COL_DIGITS = 18, NAME_DIGITS = 12;
 template <class P>
-SVJG_FN bool py_int(P t, uint64_t a, uint64_t b, int64_t &out) {
-    while (a < b && py_space(t[a])) ++a;
-    while (b > a && py_space(t[b - 1])) --b;
+SVJG_FN int py_int(P t, uint64_t a, uint64_t b, int64_t &out, uint32_t max_digits = COL_DIGITS) {
+    while (a < b && c_space(t[a])) ++a;
+    while (b > a && c_space(t[b - 1])) --b;
     bool neg = false;
     if (a < b && (t[a] == '+' || t[a] == '-')) { neg = t[a] == '-'; ++a; }
-    if (a >= b || (uint32_t)t[a] - '0' > 9) return false;
-    int64_t v = 0; bool us = false;
+    if (a >= b || (uint32_t)t[a] - '0' > 9) return PY_INT_BAD;
+    int64_t v = 0; bool us = false; uint32_t nd = 0;
     for (; a < b; ++a) {
         uint32_t c = t[a];
-        if (c == '_') { if (us) return false; us = true; continue; }
-        if (c - '0' > 9) return false;
+        if (c == '_') { if (us) return PY_INT_BAD; us = true; continue; }
+        if (c - '0' > 9) return PY_INT_BAD;
         us = false;
-        if (v < BIGV) v = v * 10 + (int64_t)(c - '0');
+        if (nd < max_digits) v = v * 10 + (int64_t)(c - '0');
+        if (nd <= max_digits) ++nd;
     }
-    if (us) return false;
-    if (v > BIGV) v = BIGV;
+    if (us) return PY_INT_BAD;
     out = neg ? -v : v;
-    return true;
+    return nd > max_digits ? PY_INT_BIG : PY_INT_OK;
 }
 
 template <class P>
@@ -259,8 +271,8 @@ SVJG_HD bool word_is(P t, uint64_t a, uint64_t b, const char *w, uint32_t wl) {
 // would Python's float() accept t[a,b) ?
 template <class P>
 SVJG_FN bool py_float_ok(P t, uint64_t a, uint64_t b) {
-    while (a < b && py_space(t[a])) ++a;
-    while (b > a && py_space(t[b - 1])) --b;
+    while (a < b && c_space(t[a])) ++a;
+    while (b > a && c_space(t[b - 1])) --b;
     if (a < b && (t[a] == '+' || t[a] == '-')) ++a;
     if (word_is(t, a, b, "inf", 3) || word_is(t, a, b, "infinity", 8) || word_is(t, a, b, "nan", 3)) return true;
     bool ok = true;
@@ -289,6 +301,13 @@ template <class P>
 SVJG_HD bool bytes_eq_before_tail(P t, uint64_t a, uint64_t b, uint64_t m) {
     for (uint64_t i = 0; i < m; i += 8) if (ld64(t, a + i) != ld64(t, b + i)) return false;
     return true;
+}
+
+// some byte >= 0x80 in t[a, b): what failed the ASCII rules may pass Python's (Unicode digits, Unicode blanks): the host decides
+template <class P>
+SVJG_HD bool has_high(P t, uint64_t a, uint64_t b) {
+    for (uint64_t q = a; q < b; ++q) if ((uint32_t)t[q] >= 0x80u) return true;
+    return false;
 }
 
 struct NameRef { uint64_t s, e; };     // node name = t[s, e)
@@ -409,8 +428,10 @@ SVJG_HD int node_len_resolved(const GraphView &g, P t, NameRef nm, uint32_t id, 
     uint64_t d2 = nm.e;
     for (uint64_t q = d1 + 1; q < nm.e; ++q) if (t[q] == '-') { d2 = q; break; }
     int64_t a, b;
-    if (!py_int(t, d1 + 1, d2, b)) return SVJG_EXC_VALUE_ERROR;
-    if (!py_int(t, c0, d1, a)) return SVJG_EXC_VALUE_ERROR;
+    // (a coordinate beyond NAME_DIGITS digits: the host refuses the line — svjg/filter.py: host_line, DESIGN §8 —; with bytes >= 0x80 Python's
+    //  int() might take Unicode digits where this one fails: the host's too)
+    { const int r = py_int(t, d1 + 1, d2, b, NAME_DIGITS); if (r != PY_INT_OK) return r == PY_INT_BIG || has_high(t, d1 + 1, d2) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR; }
+    { const int r = py_int(t, c0, d1, a, NAME_DIGITS); if (r != PY_INT_OK) return r == PY_INT_BIG || has_high(t, c0, d1) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR; }
     len = b - a + 1;
     return 0;
 }
@@ -535,17 +556,10 @@ SVJG_FN int strand_of_pieces(P t, uint64_t ps, const SVJG_TAB_AS uint32_t *pos, 
 // the nine int() columns, the id:f: tag, the path column and its node count.  0 or the exception class.
 struct SlowLine { uint64_t ps, pe; bool oriented; uint32_t k; int64_t Tlen, Ts, Te; };
 
-// some byte >= 0x80 in t[a, b): what failed the ASCII rules may pass Python's (Unicode digits, Unicode blanks): the host decides
-template <class P>
-SVJG_HD bool has_high(P t, uint64_t a, uint64_t b) {
-    for (uint64_t q = a; q < b; ++q) if ((uint32_t)t[q] >= 0x80u) return true;
-    return false;
-}
-
 template <class P>
 SVJG_FN int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
     o.k = 0;
-    while (e > s && py_space(t[e - 1])) --e;
+    while (e > s && py_strip_space(t[e - 1])) --e;
     // (str.rstrip() also takes Unicode blanks: a line that ends in a byte >= 0x80 is the host's if anything below fails on it)
     uint64_t fs[12], fe[12]; uint32_t nf = 0;
     { uint64_t st = s;
@@ -559,7 +573,8 @@ SVJG_FN int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
     int64_t v[12];
     const int cols[9] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
     for (int j = 0; j < 9; ++j)
-        if (!py_int(t, fs[cols[j]], fe[cols[j]], v[cols[j]])) return has_high(t, fs[cols[j]], fe[cols[j]]) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR;
+    {   const int r = py_int(t, fs[cols[j]], fe[cols[j]], v[cols[j]]);
+        if (r != PY_INT_OK) return r == PY_INT_BIG || has_high(t, fs[cols[j]], fe[cols[j]]) ? SVJG_EXC_ASK_HOST : SVJG_EXC_VALUE_ERROR; }
     { uint64_t last = e;                                           // "id:f:" in line  (:193-196)
       for (uint64_t q = find_byte(t, s, e, 'i'); q + 5 <= e; q = find_byte(t, q + 1, e, 'i'))
           if (t[q + 1] == 'd' && t[q + 2] == ':' && t[q + 3] == 'f' && t[q + 4] == ':') last = q;

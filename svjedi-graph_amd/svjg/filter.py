@@ -97,13 +97,26 @@ def reference_error(data, exc):
 
 
 # ---- lines the kernels leave to the host (svjg.h: SVJG_EXC_ASK_HOST) ---------------------------------------------------------
-# int() / float() / str.rstrip() of the reference (filter-alignments.py:125, :189-194) also take Unicode digits and blanks; the
-# kernels read ASCII.  A line whose decimal column (or id:f: value) fails the ASCII rules and holds a byte >= 0x80 is set aside by
-# the kernels: not counted, not an error.  Here such a line is put to Python's own int() / float(): it either raises what the
-# reference raises, or is rewritten — digit for digit, blank for blank — into an ASCII spelling that means the same to the
-# reference and goes through the GPU again (its hit records are mapped back onto the original line, whose text the JSON holds).
+# Two things the reference's int() / float() / str.rstrip() (filter-alignments.py:125, :189-194) do that the kernels do not:
+#   * they take Unicode digits and blanks: a line whose decimal column (or id:f: value) fails the ASCII rules and holds a byte >= 0x80;
+#   * Python's integers have no width (and CPython >= 3.10.7 refuses a literal of more than sys.get_int_max_str_digits() = 4300 digits
+#     with a ValueError): a decimal column of more than 18 digits (r06; the kernels' integers are 64 bits wide).
+# Such a line is set aside by the kernels: not counted, not an error.  Here it is put to Python's own int() / float() — the interpreter
+# the reference would run in —: it either raises what the reference raises, or is rewritten into an ASCII spelling within the kernels'
+# range that means the same to the reference and goes through the GPU again (its hit records are mapped back onto the original line,
+# whose text the JSON holds).
 HOST_BASE = 1 << 60            # base offset of the resubmitted lines: hit records / errors at or beyond it belong to them
 _INT_COLS = (1, 2, 3, 6, 7, 8, 9, 10, 11)
+_COL_CAP = 10 ** 18 - 1        # svjg_line.h: COL_DIGITS = 18
+
+
+class UnsupportedLine(RuntimeError):
+    """A GAF line the reference reads and this implementation refuses (exit 1 instead of a guess): a path node that is no node
+    of the graph whose name holds a coordinate of more than 12 digits or non-ASCII digits."""
+
+
+# what resolve_host_lines can raise for a line: the reference's exceptions (OverflowError: Am / Alen beyond a double, :196) or the refusal
+HOST_LINE_ERRORS = capi.LINE_ERRORS + (OverflowError, UnsupportedLine)
 
 
 def _ascii_number(s):
@@ -119,6 +132,10 @@ def _ascii_number(s):
     return "".join(out)
 
 
+def _clamp(v):
+    return max(-_COL_CAP, min(_COL_CAP, v))
+
+
 def host_line(text):
     """read_gaf_line (filter-alignments.py:184-198) on one line as the text-mode read delivers it, with Python's own int() /
     float().  Raises what the reference raises there; else -> the ASCII spelling of the line for the kernels."""
@@ -131,9 +148,23 @@ def host_line(text):
     if "id:f:" in line:
         float(line.split("id:f:")[-1].split("\t")[0])
     else:
-        val[9] / val[10]
+        val[9] / val[10]                                        # (ZeroDivisionError; OverflowError for a quotient beyond a double)
     for i in _INT_COLS:
         cols[i] = _ascii_number(cols[i])
+    if any(abs(v) > _COL_CAP for v in val.values()):
+        # Values beyond the kernels' 18 digits.  Six of the nine columns only have to BE integers (:185-191) and Alen only to be non-zero
+        # without an id:f: tag (:196); Tlen, Ts, Te enter two comparisons (:260-271):
+        #     left_sum - Ts >= d_over    and    right_sum - (Tlen - Te - 1) >= d_over
+        # with sums of node lengths that the kernels keep below 10^17 in magnitude (svjg_line.h: NAME_DIGITS).  Clamping Ts and
+        # U = Tlen - Te - 1 to +-(10^18 - 1) leaves both outcomes as they are; U is formed here, exactly, and written as Tlen = U + 1, Te = 0.
+        for i in (1, 2, 3, 9, 11):
+            if abs(val[i]) > _COL_CAP:
+                cols[i] = "1"
+        if abs(val[10]) > _COL_CAP:
+            cols[10] = "1"
+        if max(abs(val[6]), abs(val[7]), abs(val[8])) > _COL_CAP:
+            u = _clamp(val[6] - val[8] - 1)
+            cols[6], cols[7], cols[8] = (str(u + 1), str(_clamp(val[7])), "0") if u < _COL_CAP else (str(u), str(_clamp(val[7])), "-1")
     out = "\t".join(cols)
     if "id:f:" in out:
         head, _, tail = out.rpartition("id:f:")
@@ -177,7 +208,7 @@ def resolve_host_lines(ctxs, data, want_hits, error=None):
             break                                               # (the text-mode read dies first: check_utf8 / reference_error say where)
         try:
             accepted.append((off, host_line(text)))
-        except (ValueError, ZeroDivisionError, IndexError) as ex:
+        except (ValueError, ZeroDivisionError, IndexError, OverflowError) as ex:
             ex.svjg_offset = off
             first, limit = ex, off
             break
@@ -194,8 +225,19 @@ def resolve_host_lines(ctxs, data, want_hits, error=None):
                 ex.svjg_offset = int(orig[np.searchsorted(starts, np.uint64(o - HOST_BASE), side="right") - 1])
                 if limit is None or ex.svjg_offset < limit:
                     first = ex
-        if len(ctx.host_lines()) != before:
-            raise RuntimeError("a rewritten line was set aside again")
+        again = ctx.host_lines()[before:]
+        if len(again):
+            # every column of a rewritten line is plain ASCII within range: what the exact routine could not read is a NODE NAME — a path
+            # node that is no node of the graph (its length is arithmetic on its name, filter-alignments.py:343-349) with a coordinate of
+            # more than 12 digits or of non-ASCII digits, in a sum the reference forms.  The reference computes on; this implementation
+            # refuses unless an earlier line is fatal anyway.
+            o = int(orig[np.searchsorted(starts, np.uint64(int(np.min(again)) - HOST_BASE), side="right") - 1])
+            if limit is None or o < limit:
+                ex = UnsupportedLine(f"GAF line at byte offset {o}: a path node that is no node of the graph has a coordinate of more than 12 digits "
+                                     "(or non-ASCII digits); the reference computes with it, this implementation does not (DESIGN.md section 8)")
+                ex.svjg_offset = o
+                if first is None or getattr(first, "svjg_offset", None) is None or o < first.svjg_offset:
+                    first = ex
     if first is not None:
         raise first
     return (starts, orig) if accepted else None
@@ -297,7 +339,7 @@ def classify_file(ctx, graph, gaf_path, want_hits=True):
         err = e
     try:
         remap = resolve_host_lines([ctx], data, want_hits, err)
-    except capi.LINE_ERRORS as e:
+    except HOST_LINE_ERRORS as e:
         raise reference_error(data, e)
     if ctx.stats()["non_ascii"]:
         check_utf8(data)
@@ -342,7 +384,7 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
             raise err
         try:
             remap = resolve_host_lines(ctxs, data, want_hits, err)       # (lines with non-ASCII digits: Python's int() decides)
-        except capi.LINE_ERRORS as e:
+        except HOST_LINE_ERRORS as e:
             raise reference_error(data, e)
         capi.release_host_tables()                 # (every context has the graph: the shared host copy of the kernels' tables can go)
         _stamp(t, f"tables -> device, upload + classify on {len(distinct)} GPU(s)")
@@ -527,7 +569,7 @@ def classify_stream(graph, stream, want_hits=True, device=0, _t=None):
         data = np.frombuffer(bytes(buf), dtype=np.uint8) if err is not None else np.frombuffer(buf, dtype=np.uint8)
         try:
             remap = resolve_host_lines([ctx], data, want_hits, err)
-        except capi.LINE_ERRORS as e:
+        except HOST_LINE_ERRORS as e:
             raise reference_error(data, e)
         _stamp(t, "stream -> device, classified while it arrived")
         if ctx.stats()["non_ascii"]:

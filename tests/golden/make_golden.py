@@ -987,6 +987,108 @@ def make_longtail():
           "fatal:", sorted({e for c in cases for e in c["fatal_errors"]}))
 
 
+def ref_filter_inproc(gaf, gfa, prefix):
+    """The reference's filter-alignments.py main() in THIS process (the module is imported above; main() parses sys.argv itself,
+    filter-alignments.py:74) -> ("ok", per-SV list lengths of the JSON it wrote) | ("died", exception class).  For groups of thousands
+    of tiny cases, where a process per case is most of the time."""
+    js = prefix + "_informative_aln.json"
+    if os.path.exists(js):
+        os.remove(js)
+    argv = sys.argv
+    sys.argv = ["filter-alignments.py", "-a", gaf, "-g", gfa, "-p", prefix]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            ref_filter.main(None)
+    except Exception as e:
+        return ("died", type(e).__name__)
+    finally:
+        sys.argv = argv
+    d = json.load(open(js))
+    return ("ok", {k: [len(v[0]), len(v[1])] for k, v in d.items()})
+
+
+def _pack_cases(frags, verdicts):
+    """fragments (bytes) + the reference's verdicts -> JSON-able dict: the texts as one zlib blob (mutants of 40 lines deflate to a few
+    bytes each) so that the fixture does not depend on the mutator's random stream staying the same"""
+    import base64
+    import zlib
+    return {"lengths": [len(f) for f in frags], "text_zlib_b64": base64.b64encode(zlib.compress(b"".join(frags), 9)).decode(),
+            "text_sha256": hashlib.sha256(b"".join(frags)).hexdigest(),
+            "verdicts": [v[1] if v[0] == "ok" else v[1] for v in verdicts]}          # a dict = accepted (its counts), a string = the exception class
+
+
+def _testdir_tmp():
+    tmp = tempfile.mkdtemp()
+    for ext in (".gfa", "_svs_edges.json"):
+        os.symlink(f"{HERE}/testdir/test{ext}", os.path.join(tmp, "test" + ext))
+    return tmp
+
+
+def make_blanks():
+    """golden/blanks/blanks.json (r06): which bytes int() / float() / str.rstrip() of the reference take for blanks — each of 0x09-0x0D,
+    0x1C-0x1F, 0x20, 0x00, 0x7F in front of and behind each of the nine decimal columns, at both ends of an id:f: value (last tag / a tag
+    in front of others), at the line's end, for three lines of testdir/test.gaf (tests/alphabet_fuzz.py: blank_cases); and the same bytes
+    where the main kernel's 8 KB stage ends before them: behind column 8 of a line whose read name is 8 300 bytes long, at the end of an
+    id:f: value and at the line's end behind a cg:Z: tag of 9 000 bytes.  Every case through the reference's filter-alignments.py."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import alphabet_fuzz as AF
+    base = open(f"{HERE}/testdir/test.gaf", "rb").read().splitlines(keepends=True)
+    cases = [(f"l{i}_{lab}", b) for i in (0, 3, 4) for lab, b in AF.blank_cases(base[i])]
+    for ch in (0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x1C, 0x1D, 0x1E, 0x1F, 0x20, 0x00, 0x7F):
+        c1 = bytes([ch])
+        cols = base[0].rstrip(b"\n").split(b"\t")
+        x = list(cols); x[0] = b"r" * 8300; x[8] += c1
+        cases.append((f"past_stage_col8_back_{ch:02x}", b"\t".join(x) + b"\n"))
+        x = list(cols); x[0] = b"r" * 8300; x[7] = c1 + x[7]
+        cases.append((f"past_stage_col7_front_{ch:02x}", b"\t".join(x) + b"\n"))
+        cases.append((f"past_stage_idf_back_{ch:02x}", b"\t".join(cols + [b"cg:Z:" + b"12M3D" * 1800, b"id:f:0.9" + c1]) + b"\n"))
+        cases.append((f"past_stage_idf_front_{ch:02x}", b"\t".join(cols + [b"cg:Z:" + b"12M3D" * 1800, b"id:f:" + c1 + b"0.9", b"zz:i:1"]) + b"\n"))
+        cases.append((f"past_stage_end_{ch:02x}", b"\t".join(cols + [b"cg:Z:" + b"12M3D" * 1800]) + c1 + b"\n"))
+    tmp = _testdir_tmp()
+    verdicts = []
+    for _, frag in cases:
+        open(f"{tmp}/f.gaf", "wb").write(frag)
+        verdicts.append(ref_filter_inproc(f"{tmp}/f.gaf", f"{tmp}/test.gfa", f"{tmp}/test"))
+    out = _pack_cases([f for _, f in cases], verdicts)
+    out["labels"] = [lab for lab, _ in cases]
+    out["graph"] = "testdir/test.gfa + testdir/test_svs_edges.json"
+    out["python"] = sys.version.split()[0]
+    os.makedirs(f"{HERE}/blanks", exist_ok=True)
+    json.dump(out, open(f"{HERE}/blanks/blanks.json", "w"), indent=0, sort_keys=True)
+    died = {}
+    for (lab, _), v in zip(cases, verdicts):
+        if v[0] == "died":
+            died[lab.rsplit("_", 1)[1]] = died.get(lab.rsplit("_", 1)[1], 0) + 1
+    print("blanks:", len(cases), "cases; died per byte:", died)
+    shutil.rmtree(tmp)
+
+
+def make_fuzz7(n_cases=12000, seed=20261005):
+    """golden/fuzz7/fuzz7.json (r06): mutants of testdir/test.gaf over the FULL 7-bit alphabet (tests/alphabet_fuzz.py: mutate7 — any byte
+    anywhere, blank-like bytes around the decimal columns and id:f: values, numbers of 19..4301 digits, node names that are arithmetic),
+    each evaluated by the reference's filter-alignments.py.  The r05 fixture (golden/fuzz) drew from an 18-byte alphabet."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import alphabet_fuzz as AF
+    base = open(f"{HERE}/testdir/test.gaf", "rb").read().splitlines(keepends=True)
+    frags = AF.mutants(base, n_cases, seed)
+    tmp = _testdir_tmp()
+    verdicts = []
+    for frag in frags:
+        open(f"{tmp}/f.gaf", "wb").write(frag)
+        verdicts.append(ref_filter_inproc(f"{tmp}/f.gaf", f"{tmp}/test.gfa", f"{tmp}/test"))
+    out = _pack_cases(frags, verdicts)
+    out.update({"seed": seed, "graph": "testdir/test.gfa + testdir/test_svs_edges.json", "python": sys.version.split()[0],
+                "int_max_str_digits": sys.get_int_max_str_digits() if hasattr(sys, "get_int_max_str_digits") else 0})
+    os.makedirs(f"{HERE}/fuzz7", exist_ok=True)
+    json.dump(out, open(f"{HERE}/fuzz7/fuzz7.json", "w"), indent=0, sort_keys=True)
+    errs = {}
+    for v in verdicts:
+        if v[0] == "died":
+            errs[v[1]] = errs.get(v[1], 0) + 1
+    print(f"fuzz7: {len(frags)} cases: {sum(v[0] == 'ok' for v in verdicts)} accepted ({sum(v[0] == 'ok' and bool(v[1]) for v in verdicts)} with hits), died: {errs}")
+    shutil.rmtree(tmp)
+
+
 def make_contigs():
     """golden/contigs: contig names shaped like the GRCh38 analysis set's — HLA-DRB1*15:03:01:01 and HLA-A*01:01:01:01 (':', '*' and '-'
     INSIDE the contig part: the reference takes the LAST ':' field of a node name, filter-alignments.py:328-349), chrUn_JTFH01001998v1_decoy,

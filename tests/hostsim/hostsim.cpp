@@ -34,12 +34,9 @@ static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &has
     return v;
 }
 
-extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n,
-                                uint32_t *counts, uint64_t *n_lines, int *exc, uint64_t *err_off)
+static int classify_view(const GraphView &v, const svjg_graph *g, const char *gaf, uint64_t n,
+                         uint32_t *counts, uint64_t *n_lines, int *exc, uint64_t *err_off)
 {
-    std::vector<uint32_t> hash = build_chrom_hash(*g);
-    KernelTables kt = build_kernel_tables(*g);
-    GraphView v = make_view(g, hash, (g->flags & 2u) ? nullptr : &kt);      // flags bit 1 (harness only): sorted-table search instead
     const uint8_t *t = (const uint8_t *)gaf;
     *n_lines = 0; *exc = 0; *err_off = 0;
     uint64_t pos = 0;
@@ -132,6 +129,33 @@ extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n
         pos = e + 1;
     }
     return 0;
+}
+
+extern "C" int hostsim_classify(const svjg_graph *g, const char *gaf, uint64_t n,
+                                uint32_t *counts, uint64_t *n_lines, int *exc, uint64_t *err_off)
+{
+    std::vector<uint32_t> hash = build_chrom_hash(*g);
+    KernelTables kt = build_kernel_tables(*g);
+    GraphView v = make_view(g, hash, (g->flags & 2u) ? nullptr : &kt);      // flags bit 1 (harness only): sorted-table search instead
+    return classify_view(v, g, gaf, n, counts, n_lines, exc, err_off);
+}
+
+// many small GAF fragments against one graph (tests/test_oracle_cross_fuzz.py): fragment i = gaf[offs[i], offs[i + 1]); its counts go to
+// counts[i * n_slots * 2 ..] (zeroed by the caller), the exception class it dies with (0: none) to exc[i]
+extern "C" void hostsim_classify_cases(const svjg_graph *g, const char *gaf, const uint64_t *offs, uint64_t n_cases, uint32_t *counts, int *exc)
+{
+    std::vector<uint32_t> hash = build_chrom_hash(*g);
+    KernelTables kt = build_kernel_tables(*g);
+    GraphView v = make_view(g, hash, (g->flags & 2u) ? nullptr : &kt);
+    const uint64_t stride = (uint64_t)(g->n_slots ? g->n_slots : 1u) * 2u;
+    for (uint64_t i = 0; i < n_cases; ++i) {
+        // (a copy of its own: the routines read up to eight bytes at a time, never beyond the line's end — a heap block of exactly the
+        //  fragment's size lets AddressSanitizer see it if they did)
+        std::vector<char> frag(gaf + offs[i], gaf + offs[i + 1]);
+        uint64_t nl = 0, eo = 0;
+        exc[i] = 0;
+        classify_view(v, g, frag.data(), frag.size(), counts + i * stride, &nl, &exc[i], &eo);
+    }
 }
 
 // the main kernel's hash tables must agree with the sorted node table / CSR rows: every node name resolves to its

@@ -59,6 +59,27 @@ def classify(graph, gaf, tables=True, wave=False):
     return counts[: graph.n_slots], nl.value
 
 
+_WAVE_FLAGS = {0: 0, 1: 4, 2: 8, 3: 32, 4: 8 | 64, 5: 8 | 128}
+
+
+def classify_cases(graph, frags, tables=True, wave=0):
+    """Many small GAF fragments (list of bytes), each on its own -> (counts uint32[n, n_slots, 2], exception class or None per fragment)"""
+    lib, capi = _lib()
+    cg = capi.cgraph_of(graph)
+    if not tables:
+        cg.flags |= 2
+    cg.flags |= _WAVE_FLAGS[int(wave)]
+    offs = np.zeros(len(frags) + 1, np.uint64)
+    np.cumsum([len(f) for f in frags], out=offs[1:])
+    buf = np.frombuffer(b"".join(frags) + b"\0", dtype=np.uint8)
+    counts = np.zeros((len(frags), max(graph.n_slots, 1), 2), dtype=np.uint32)
+    exc = np.zeros(len(frags), np.int32)
+    lib.hostsim_classify_cases.restype = None
+    lib.hostsim_classify_cases.argtypes = [ctypes.POINTER(capi.CGraph)] + [ctypes.c_void_p] * 2 + [ctypes.c_uint64] + [ctypes.c_void_p] * 2
+    lib.hostsim_classify_cases(ctypes.byref(cg), buf.ctypes.data, offs.ctypes.data, len(frags), counts.ctypes.data, exc.ctypes.data)
+    return counts[:, : graph.n_slots], [EXC.get(int(x)) if x else None for x in exc]
+
+
 def check_tables(graph):
     lib, capi = _lib()
     cg = capi.cgraph_of(graph)

@@ -1533,6 +1533,69 @@ def test_fuzz_cases(ctx, golden):
         assert type(ei.value).__name__ == c["error"], (i, raw)
 
 
+@pytest.mark.parametrize("all_slow", [False, True])
+@pytest.mark.parametrize("group", ["blanks/blanks.json", "fuzz7/fuzz7.json"])
+def test_full_alphabet_cases_by_the_reference(ctx, golden, group, all_slow):
+    """r06 (the r05 verdict's parity defect: 0x1C..0x1F next to a decimal column were taken for blanks, "1100\\x1f" accepted where the
+    reference's int() dies).  golden/blanks: every blank-like byte in front of / behind every decimal column, an id:f: value, the
+    line's end, also beyond the main kernel's 8 KB stage; golden/fuzz7: 12 000 mutants over the full 7-bit alphabet, numbers of
+    19..4301 digits among them (Python's own int() on the host decides those).  Every verdict is the REFERENCE's (tests/golden/make_golden.py:
+    make_blanks, make_fuzz7).  Every fragment alone — main kernel and exact path —, then all accepted ones in one text."""
+    from svjg import filter as flt
+    from svjg.graph import Graph
+    from tests import alphabet_fuzz as AF
+    t = f"{golden}/testdir"
+    g = Graph.from_files(f"{t}/test_svs_edges.json", f"{t}/test.gfa", all_slow=all_slow)
+    cases = AF.load_packed(f"{golden}/{group}")
+    if all_slow and group.startswith("fuzz7"):
+        cases = cases[::4]                                  # (the exact path alone: a quarter of the mutants; the main kernel defers to it anyway)
+    ctx.load_graph(g)
+
+    def classify(raw):
+        data = np.frombuffer(raw, dtype=np.uint8)
+        err = None
+        try:
+            ctx.classify(data)
+        except (ValueError, IndexError, KeyError, ZeroDivisionError) as e:
+            err = e
+        try:
+            flt.resolve_host_lines([ctx], data, False, err)
+        except flt.HOST_LINE_ERRORS as e:
+            raise flt.reference_error(data, e)
+
+    total, good, refused, n_host = {}, [], 0, 0
+    for i, (raw, want) in enumerate(cases):
+        ctx.reset_counts()
+        try:
+            classify(raw)
+            got = ("ok", {k: tuple(v) for k, v in _counts_dict(g, ctx.counts()).items()})
+        except flt.UnsupportedLine:
+            refused += 1                                    # (a node the graph lacks with a coordinate of > 12 digits: DESIGN §8)
+            continue
+        except Exception as e:
+            got = ("died", type(e).__name__)
+        n_host += len(ctx.host_lines()) > 0
+        assert got == want, (i, raw[:300], want, got)
+        if want[0] == "ok":
+            good.append(raw if raw.endswith((b"\n", b"\r")) else raw + b"\n")
+            for k, v in want[1].items():
+                a = total.setdefault(k, [0, 0]); a[0] += v[0]; a[1] += v[1]
+    assert refused < 0.02 * len(cases)
+    if group.startswith("fuzz7"):
+        assert n_host > 0.02 * len(cases)                   # the host's part was really used (numbers of more than 18 digits)
+    else:
+        assert refused == 0
+    # the reproducer of the r05 verdict, spelled out: 0x1F behind column 7 of a testdir line
+    line = open(f"{t}/test.gaf", "rb").readline().rstrip(b"\n").split(b"\t")
+    line[6] += b"\x1f"
+    ctx.reset_counts()
+    with pytest.raises(ValueError):
+        classify(b"\t".join(line) + b"\n")
+    ctx.reset_counts()
+    classify(b"".join(good) * 3)
+    assert _counts_dict(g, ctx.counts()) == {k: [3 * v[0], 3 * v[1]] for k, v in total.items()}
+
+
 def test_stripes_the_lists_cannot_hold(ctx, tmp_path):
     """Stripes with more tabs or orientation marks than the per-stripe lists of the main kernel hold are handed to the
     exact path as a whole: lines with hundreds of tags, a tag full of '<' '>', both mixed with ordinary lines."""
