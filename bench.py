@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the untimed end-to-end block (files -> JSON -> VCF through the drop-in scripts)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the untimed north_star block (BASELINE configs[3] split over the GPUs of the run)")
     ap.add_argument("--no-long-read", action="store_true", help="skip the untimed long_read block (long-read shaped lines: paths long-tailed to 200 nodes, cg:Z: strings)")
+    ap.add_argument("--no-hg002-shape", action="store_true", help="skip the untimed hg002_shape block (BASELINE configs[4]'s shape: whole-genome reads, most lines single-node)")
     ap.add_argument("--no-e2e-north-star", action="store_true", help="skip the untimed e2e_north_star block (configs[3] as files through the drop-in scripts; needs ~160 GB of /dev/shm)")
     ap.add_argument("--north-star-aln", type=int, default=NORTH_STAR["aln"], help="alignments of the north_star block (tests)")
     ap.add_argument("--north-star-svs", type=int, default=NORTH_STAR["svs"], help="SVs of the north_star block (tests)")
@@ -196,6 +197,13 @@ def main():
             lr_in = long_read_inputs(synth, tmp, check=not args.no_cpu_baseline)
         except Exception as e:                                   # noqa: BLE001
             lr_in = {"failed": f"{type(e).__name__}: {e}"[:300]}
+
+    hg_in = None
+    if not args.no_hg002_shape and n_total_ranks == 1 and not os.environ.get("SVJG_BENCH_CAPI"):
+        try:
+            hg_in = hg002_shape_inputs(synth, tmp, check=not args.no_cpu_baseline)
+        except Exception as e:                                   # noqa: BLE001
+            hg_in = {"failed": f"{type(e).__name__}: {e}"[:300]}
 
     ctxs = [capi.Context(local_rank + i) for i in range(n_local)]
     t_h2d = 0.0
@@ -298,6 +306,13 @@ def main():
         except Exception as e:                                   # noqa: BLE001
             lr = {"failed": f"{type(e).__name__}: {e}"[:300]}
         lr_in = None
+    hg = None
+    if hg_in is not None:
+        try:
+            hg = hg002_shape_block(Graph, ctx, hg_in) if "failed" not in hg_in else hg_in
+        except Exception as e:                                   # noqa: BLE001
+            hg = {"failed": f"{type(e).__name__}: {e}"[:300]}
+        hg_in = None
 
     if rank == 0:
         total_aln = n_aln * n_total_ranks
@@ -314,7 +329,8 @@ def main():
             "dtype": "u8/int64 (classify), f64 (likelihood)", "data": "synthetic",
             "config": {"workload": desc, "alignments_per_gpu": n_aln, "svs": n_sv, "gaf_bytes_per_gpu": gaf_bytes_0,
                        "bytes_per_alignment": round(gaf_bytes_0 / n_aln, 1), "count_slots": graph.n_slots,
-                       "graph_nodes": graph.n_nodes, "vcf_rows": int(len(rows.sv_type))},
+                       "graph_nodes": graph.n_nodes, "vcf_rows": int(len(rows.sv_type)),
+                       "untimed_settle_passes_before_warmup": n_settle},
             # (every rank genotypes ALL rows from the summed counts — 54 B a row, replicated rather than sharded: rows per second of ONE rank's kernel)
             "svs_genotyped_per_s": float(len(rows.sv_type) / (np.mean(geno_ms) * 1e-3)) if np.mean(geno_ms) > 0 else None,
             "genotyped_rows": int((done & 1).sum()),
@@ -341,6 +357,8 @@ def main():
             res["north_star"] = ns
         if lr is not None:
             res["long_read"] = lr
+        if hg is not None:
+            res["hg002_shape"] = hg
         if rccl:
             rccl["allreduce_stream"] = {"compute": {"ms_per_step": ms_per_step, "classify_main_ms": k_main}, "second": second,
                                         "value_is": "compute (the all-reduce between this pass's kernels and the next pass's)"}
@@ -436,24 +454,98 @@ def long_read_inputs(synth, tmp, check=True):
     pre = os.path.join(tmp, "long_read")
     inf = synth.generate(pre, 0, n_sv, 8, "mixed", seed, write_gaf=False, chrom_style="ucsc")
     gaf = synth.gaf_bytes(inf["tables"], seed, 0, n_lines, threads=min(16, os.cpu_count() or 8), shape="long")
-    out = {"pre": pre, "gaf": gaf, "n_lines": n_lines, "n_sv": n_sv, "oracle": None}
-    if check:
-        import multiprocessing as mp
-        from oracle import oracle_c, oracle_py
-        t = time.perf_counter()
-        orc = oracle_c.COracle(oracle_py.load_edges(pre + "_svs_edges.json"), oracle_py.load_alt_node_len(pre + ".gfa"))
-        cores = min(len(os.sched_getaffinity(0)), 16)
-        nl = np.flatnonzero(gaf == 10)
-        cuts = [0] + [int(nl[min(nl.size, (nl.size * (i + 1)) // (4 * cores)) - 1]) + 1 for i in range(4 * cores)]   # (shares of unequal cost: four a worker)
-        _FORK_STATE.update(orc=orc, gaf=gaf)
-        want, lines = np.zeros((len(orc.sv_ids), 2), dtype=np.uint64), 0
+    out = {"pre": pre, "gaf": gaf, "n_lines": n_lines, "n_sv": n_sv, "oracle": _oracle_counts_parallel(pre, gaf) if check else None}
+    return out
+
+
+def _oracle_counts_parallel(pre, gaf):
+    """The checker, not the thing measured: the C oracle's counts over ALL lines of `gaf` against the graph files at `pre`, one contiguous
+    share of lines per forked worker.  Forks: call before this process touches the GPU."""
+    import multiprocessing as mp
+    from oracle import oracle_c, oracle_py
+    t = time.perf_counter()
+    orc = oracle_c.COracle(oracle_py.load_edges(pre + "_svs_edges.json"), oracle_py.load_alt_node_len(pre + ".gfa"))
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    nl = np.flatnonzero(gaf == 10)
+    cuts = [0] + [int(nl[min(nl.size, (nl.size * (i + 1)) // (4 * cores)) - 1]) + 1 for i in range(4 * cores)]   # (shares of unequal cost: four a worker)
+    _FORK_STATE.update(orc=orc, gaf=gaf)
+    want, lines = np.zeros((len(orc.sv_ids), 2), dtype=np.uint64), 0
+    try:
         with mp.get_context("fork").Pool(cores) as pool:
             for c, n in pool.imap_unordered(_oracle_shard_counts, [(cuts[i], cuts[i + 1]) for i in range(4 * cores)], chunksize=1):
                 want += c
                 lines += n
+    finally:
         _FORK_STATE.clear()
-        out["oracle"] = {"counts": {sv: (int(want[i, 0]), int(want[i, 1])) for i, sv in enumerate(orc.sv_ids) if want[i].sum()}, "lines": lines,
-                         "seconds": round(time.perf_counter() - t, 1), "cores": cores}
+    return {"counts": {sv: (int(want[i, 0]), int(want[i, 1])) for i, sv in enumerate(orc.sv_ids) if want[i].sum()}, "lines": lines,
+            "seconds": round(time.perf_counter() - t, 1), "cores": cores}
+
+
+def hg002_shape_inputs(synth, tmp, check=True):
+    """The hg002_shape block's inputs (tools/synth.py: generate_hg002 — BASELINE configs[4]'s shape) and, `check`, the C oracle's counts over
+    all of its lines (forks: before the GPU is touched)."""
+    n_reads = int(os.environ.get("SVJG_HG002_READS", synth.HG002_READS))
+    pre = os.path.join(tmp, "hg002")
+    inf = synth.generate_hg002(pre, n_reads=n_reads, write_gaf=False, return_gaf=True, threads=min(16, os.cpu_count() or 8))
+    gaf = inf["gaf"]
+    return {"pre": pre, "gaf": gaf, "n_lines": n_reads, "n_sv": inf["n_sv"], "n_nodes": inf["n_nodes"],
+            "big_nodes": int((inf["tables"]["len"][: inf["tables"]["n_ref"]] >= (1 << 25)).sum()),
+            "oracle": _oracle_counts_parallel(pre, gaf) if check else None}
+
+
+def hg002_shape_block(Graph, ctx, hg):
+    """Untimed for `value`: BASELINE configs[4]'s SHAPE — HG002 GIAB v0.6 Tier1 (~12.8 k DEL / INS of 50 bp .. 10 kb) on the 24 GRCh37 contigs
+    at their real lengths, 30x of ~20 kb reads walked from genome positions: with ~240 kb between breakpoints nine GAF lines in ten are
+    SINGLE-node paths, which filter-alignments.py:133-134 skips — the regime a real whole-genome run is in and none of configs[1..3] is
+    (4-5 nodes a line).  minigraph and the data are absent here; the shape is reproduced: the graph is byte for byte the one the reference's
+    construct-graph.py builds from the same VCF (tests/golden/hg002shape: sha256 checked here), and the first 200 000 lines of this very
+    stream went through the reference's filter (same fixture: their counts are checked here).  Classification only, kernel time by HIP
+    events; `parity`: the counts of the WHOLE block against the C oracle's."""
+    import hashlib
+    pre, gaf, n_lines = hg["pre"], hg["gaf"], hg["n_lines"]
+    graph = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    ctx.load_graph(graph)
+    out = {}
+    try:                                                         # the sample the reference itself ran (tests/golden/make_golden.py: make_hg002shape)
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "hg002shape", "hg002shape.json")))
+        sha = lambda path: hashlib.sha256(open(path, "rb").read()).hexdigest()  # noqa: E731
+        graph_ok = sha(pre + "_svs_edges.json") == gold["edges_json_sha256"] and sha(pre + ".gfa") == gold["gfa_elided_sha256"]
+        nl = np.flatnonzero(gaf[: gold["gaf_bytes"] + 1] == 10)
+        sample = gaf[: gold["gaf_bytes"]]
+        sample_ok = n_lines >= gold["n_reads"] and hashlib.sha256(sample.tobytes()).hexdigest() == gold["gaf_sha256"] and nl.size >= gold["n_reads"]
+        if sample_ok:
+            ctx.reset_counts()
+            ctx.classify(sample)
+            g = ctx.counts()
+            got = {graph.sv_ids[i]: [int(g[i, 0]), int(g[i, 1])] for i in range(graph.n_slots) if g[i].sum()}
+            sample_ok = got == gold["counts"]
+        out["pinned_by_the_reference"] = {"graph_is_construct_graph_py_s": bool(graph_ok),
+                                          "first_lines_counts_equal_the_reference_s": bool(sample_ok), "lines": gold["n_reads"]}
+    except (OSError, ValueError, KeyError) as e:
+        out["pinned_by_the_reference"] = {"failed": f"{type(e).__name__}: {e}"[:200]}
+    ctx.upload(gaf)
+    ms = []
+    for i in range(9):
+        ctx.reset_counts()
+        ctx.classify_resident()
+        if i >= 2:
+            ms.append(ctx.kernel_ms()[:2])
+    main_ms, slow_ms = float(np.mean([m[0] for m in ms])), float(np.mean([m[1] for m in ms]))
+    st, cause = ctx.stats(), ctx.defer_causes()
+    marks = int(((gaf == ord("<")) | (gaf == ord(">"))).sum())
+    out.update({"workload": f"{n_lines} whole-genome long-read lines (30x of ~20 kb reads) x {hg['n_sv']} DEL / INS on the 24 GRCh37 contigs "
+                            f"({hg['n_nodes']} nodes, {hg['big_nodes']} of them >= 2^25 bp); classification only, untimed for `value`",
+                "lines": n_lines, "gaf_bytes": int(gaf.size), "bytes_per_line": round(gaf.size / n_lines, 1), "path_nodes_per_line": round(marks / n_lines, 3),
+                "kernel_ms": {"classify_main": main_ms, "classify_exact_path": slow_ms},
+                "lines_per_s": n_lines / ((main_ms + slow_ms) * 1e-3), "gb_per_s": gaf.size / ((main_ms + slow_ms) * 1e-3) / 1e9,
+                "roofline_frac": gaf.size / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "deferred_lines": int(st["n_deferred"]), "deferred_by_cause": {k: int(v) for k, v in cause.items() if v}})
+    if hg["oracle"] is not None:
+        g = ctx.counts()
+        got = {graph.sv_ids[i]: (int(g[i, 0]), int(g[i, 1])) for i in range(graph.n_slots) if g[i].sum()}
+        orc = hg["oracle"]
+        out["parity"] = "bit-exact" if (got == orc["counts"] and int(st["n_lines"]) == orc["lines"] == n_lines) else "MISMATCH"
+        out["parity_over"] = f"all {orc['lines']} lines, {sum(a + b for a, b in orc['counts'].values())} hits; oracle/svjg_oracle.c in {orc['cores']} forked workers, {orc['seconds']} s"
     return out
 
 
@@ -605,31 +697,47 @@ def end_to_end(workload, pre, gaf):
         env.setdefault("SVJG_DEVICES", os.environ.get("LOCAL_RANK", "0"))   # (one GPU — this rank's — unless the caller names devices: the scripts would pick for themselves)
         t0 = time.perf_counter()
         r1 = subprocess.run([sys.executable, os.path.join(amd, "filter-alignments.py"), "-a", p + ".gaf", "-g", p + ".gfa", "-p", p],
-                            capture_output=True, text=True, env=env)
+                            capture_output=True, text=True, env=env, timeout=E2E_TIMEOUT_S)
         t1 = time.perf_counter()
         r2 = subprocess.run([sys.executable, os.path.join(amd, "predict-genotype.py"), "-d", p + "_informative_aln.json", "-v", p + ".vcf",
-                             "--minsupport", "3", "-o", p + "_genotype.vcf"], capture_output=True, text=True, env=env)
+                             "--minsupport", "3", "-o", p + "_genotype.vcf"], capture_output=True, text=True, env=env, timeout=E2E_TIMEOUT_S)
         t2 = time.perf_counter()
         if r1.returncode or r2.returncode:
             return {"failed": (r1.stderr or r2.stderr)[-300:]}
+        # predict-genotype.py the way it is specified — on a JSON it knows nothing about (predict-genotype.py:67-68, :216-226): no counts
+        # hand-off, the native reader over the whole file
+        r3 = subprocess.run([sys.executable, os.path.join(amd, "predict-genotype.py"), "-d", p + "_informative_aln.json", "-v", p + ".vcf",
+                             "--minsupport", "3", "-o", p + "_genotype_from_json.vcf"], capture_output=True, text=True, env=dict(env, SVJG_NO_HANDOFF="1"), timeout=E2E_TIMEOUT_S)
+        t3 = time.perf_counter()
+        if r3.returncode:
+            return {"failed": "predict-genotype.py without the hand-off: " + r3.stderr[-300:]}
         ok_json = os.path.getsize(p + "_informative_aln.json") == want["json_bytes"] and sha(p + "_informative_aln.json") == want["sha256_json"]
         ok_vcf = sha(p + "_genotype.vcf") == want["sha256_vcf"] and r2.stdout == want["genotype_stdout"]
+        ok_vcf_json = sha(p + "_genotype_from_json.vcf") == want["sha256_vcf"] and r3.stdout == want["genotype_stdout"]
         return {"what": "GAF file -> filter-alignments.py -> predict-genotype.py (drop-in scripts, files on tmpfs; includes process start, "
                         "HIP initialisation, graph tables, upload, JSON and VCF writing)",
                 "filter_s": round(t1 - t0, 2), "genotype_s": round(t2 - t1, 2), "total_s": round(t2 - t0, 2),
+                "genotype_from_json_s": round(t3 - t2, 2), "sha_vcf_from_json_ok": bool(ok_vcf_json),
+                "genotype_from_json_is": "predict-genotype.py with SVJG_NO_HANDOFF=1: the counts come from the JSON file alone (native reader, chained threads)",
                 "gaf_bytes": int(gaf.size), "json_bytes": os.path.getsize(p + "_informative_aln.json"),
-                "sha_ok": bool(ok_json and ok_vcf), "sha_json_ok": bool(ok_json), "sha_vcf_ok": bool(ok_vcf),
+                "sha_ok": bool(ok_json and ok_vcf and ok_vcf_json), "sha_json_ok": bool(ok_json), "sha_vcf_ok": bool(ok_vcf),
                 "reference_s": {"filter": want.get("filter_s"), "genotype": want.get("genotype_s"), "where": want.get("host")}}
+    except subprocess.TimeoutExpired as e:
+        return {"failed": f"timeout after {E2E_TIMEOUT_S} s: {' '.join(map(str, e.cmd))[-200:]}"}
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
 
+E2E_TIMEOUT_S = 600                 # no script run of an end-to-end leg may hang the bench (their files sit in tmpfs, i.e. in memory)
 E2E_NS_BYTES = 160 << 30            # e2e_north_star: 21.6 GB of GAF + 117.3 GB of _informative_aln.json + the graph files, on tmpfs
 
 
 def e2e_scratch(need):
-    """-> (a fresh directory on /dev/shm with `need` bytes free, None) or (None, why not)"""
+    """-> (a fresh directory on /dev/shm with `need` bytes free, None) or (None, why not).  The directory is also removed when the process
+    ends, however it ends short of SIGKILL (up to 140 GB of tmpfs, i.e. of host memory, must not outlive the run)."""
+    import atexit
     import shutil
+    import signal
     base = "/dev/shm"
     try:
         if not os.path.isdir(base):
@@ -637,7 +745,12 @@ def e2e_scratch(need):
         free = shutil.disk_usage(base).free
         if free < need:
             return None, f"/dev/shm has {free >> 30} GB free, the files of configs[3] need {need >> 30} GB"
-        return tempfile.mkdtemp(prefix="svjg_e2e_ns_", dir=base), None
+        d = tempfile.mkdtemp(prefix="svjg_e2e_ns_", dir=base)
+        atexit.register(shutil.rmtree, d, True)
+        for sig in (signal.SIGTERM, signal.SIGHUP):              # (an outer `timeout`: ends the process through sys.exit, so that atexit runs)
+            if signal.getsignal(sig) is signal.SIG_DFL:
+                signal.signal(sig, lambda n, f: sys.exit(128 + n))
+        return d, None
     except OSError as e:
         return None, str(e)
 
@@ -660,25 +773,33 @@ def end_to_end_north_star(work, ns):
         env = dict(os.environ)
         env.setdefault("SVJG_DEVICES", os.environ.get("LOCAL_RANK", "0"))   # (one GPU unless SVJG_DEVICES names more: "all" cuts the file over every visible GPU)
         t0 = time.perf_counter()
-        r1 = subprocess.run([sys.executable, os.path.join(amd, "filter-alignments.py"), "-a", p + ".gaf", "-g", p + ".gfa", "-p", p], capture_output=True, text=True, env=env)
+        r1 = subprocess.run([sys.executable, os.path.join(amd, "filter-alignments.py"), "-a", p + ".gaf", "-g", p + ".gfa", "-p", p], capture_output=True, text=True, env=env, timeout=E2E_TIMEOUT_S)
         t1 = time.perf_counter()
         if r1.returncode:
             return {"failed": "filter-alignments.py: " + r1.stderr[-300:]}
         js = os.path.getsize(p + "_informative_aln.json")
         r2 = subprocess.run([sys.executable, os.path.join(amd, "predict-genotype.py"), "-d", p + "_informative_aln.json", "-v", p + ".vcf",
-                             "--minsupport", "3", "-o", p + "_genotype.vcf"], capture_output=True, text=True, env=env)
+                             "--minsupport", "3", "-o", p + "_genotype.vcf"], capture_output=True, text=True, env=env, timeout=E2E_TIMEOUT_S)
         t2 = time.perf_counter()
         if r2.returncode:
             return {"failed": "predict-genotype.py: " + r2.stderr[-300:]}
         h = hashlib.sha256(open(p + "_genotype.vcf", "rb").read()).hexdigest()
+        # the contract path of predict-genotype.py (predict-genotype.py:67-68): the 117 GB JSON read back, no counts hand-off
+        r3 = subprocess.run([sys.executable, os.path.join(amd, "predict-genotype.py"), "-d", p + "_informative_aln.json", "-v", p + ".vcf",
+                             "--minsupport", "3", "-o", p + "_genotype_from_json.vcf"], capture_output=True, text=True, env=dict(env, SVJG_NO_HANDOFF="1"), timeout=E2E_TIMEOUT_S)
+        t3 = time.perf_counter()
+        from_json = {"failed": r3.stderr[-300:]} if r3.returncode else {
+            "genotype_from_json_s": round(t3 - t2, 2), "json_gb_per_s": round(js / max(t3 - t2, 1e-9) / 1e9, 2),
+            "vcf_from_json_sha_equals_oracle": hashlib.sha256(open(p + "_genotype_from_json.vcf", "rb").read()).hexdigest() == gold["vcf_sha256"]}
         return {"what": "configs[3] as files on tmpfs: GAF -> filter-alignments.py -> _informative_aln.json -> predict-genotype.py -> _genotype.vcf "
                         "(drop-in scripts; includes process start, HIP initialisation, graph tables, upload, JSON and VCF writing)",
                 "devices": os.environ.get("SVJG_DEVICES", "") or "one GPU (SVJG_DEVICES unset)",
                 "filter_s": round(t1 - t0, 2), "genotype_s": round(t2 - t1, 2), "total_s": round(t2 - t0, 2), "under_60_s": (t2 - t0) < 60.0,
                 "gaf_bytes": os.path.getsize(p + ".gaf"), "json_bytes": js,
                 "vcf_sha_equals_oracle": h == gold["vcf_sha256"], "genotype_stdout": r2.stdout.strip()[-60:],
+                "without_the_counts_hand_off": from_json,
                 "json_check": "none at this size: the reference cannot produce it (pinned to the reference at configs[2], e2e.sha_json_ok)"}
-    except (OSError, ValueError, KeyError) as e:
+    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired) as e:
         return {"failed": f"{type(e).__name__}: {e}"[:300]}
     finally:
         shutil.rmtree(work, ignore_errors=True)

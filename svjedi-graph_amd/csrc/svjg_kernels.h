@@ -1006,7 +1006,23 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 // (all nodes of a line sit in this pass — or the line is a long one, none of whose links has been counted yet: what its
                 // earlier sub-passes found waits in the worker's log).  Ordinary text never gets here.
                 {
-                    const wmask bad = live_m & (m_eq(id, NONE32) | m_ge(lbp, 1u << 25));
+                    wmask bad = live_m & m_eq(id, NONE32);
+                    // r06: a node of 2^25 bp and more (GRCh37 has SV-free stretches of that order: a whole-genome graph's node Y:25 Mbp-59 Mbp,
+                    // every contig without an SV) no longer sends its line away.  The wave's prefix sum below wraps modulo 2^32 across
+                    // LINES, which the per-line differences undo; what must hold is that each line's OWN path stays below 2^32 bp.  When
+                    // some node of the pass is that long, the same prefix sum over the lengths >> 6 (at most 2^25 each: no wrap over 64
+                    // lanes) bounds every line's total from above: (sum of len >> 6) + nodes < 2^26  =>  path < 2^32.  A sub-pass of a
+                    // line of > 64 nodes keeps the old rule (its running total is checked for wrapping ONCE per sub-pass).
+                    const wmask big = live_m & m_ge(lbp, 1u << 25);
+                    if (RARELY(big)) {
+                        if (RARELY(lsub)) bad |= big;
+                        else {
+                            const uint32_t l6 = live ? (lbp >> 6) + 1u : 0u, s6 = wave_incl_scan(l6);
+                            const uint32_t first6 = (uint32_t)__shfl((int)(s6 - l6), (int)lnb);
+                            const uint32_t last6 = (uint32_t)__shfl((int)s6, (int)(lane + (lk ? lk - 1u - j : 0u)));
+                            bad |= live_m & m_ge(last6 - first6, 1u << 26);
+                        }
+                    }
                     if (RARELY(bad)) {
                         if (in_mask(bad)) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | ((ST_DEFER + DC_NAME) << 24);
                         wave_sync();
@@ -1017,7 +1033,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 if (!live) { j = 0; lk = 0; lnb = 0; id = NONE32; lbp = 0; }
                 tick(4);
                 // -- running path length of the line (inclusive) = wave prefix sum minus what precedes the line's first node --
-                const uint32_t gsum = wave_incl_scan(lbp);               // every lbp < 2^25: no overflow over 64 lanes
+                const uint32_t gsum = wave_incl_scan(lbp);               // (wraps modulo 2^32 across lines; every line's own total is below 2^32: above)
                 const uint32_t gfirst = (uint32_t)__shfl((int)(gsum - lbp), (int)lnb);
                 const uint32_t glast = (uint32_t)__shfl((int)gsum, (int)(lane + (lk ? lk - 1 - j : 0u)));
                 uint32_t pre = gsum - gfirst, tot = glast - gfirst;

@@ -1089,6 +1089,77 @@ def make_fuzz7(n_cases=12000, seed=20261005):
     shutil.rmtree(tmp)
 
 
+def make_hg002shape(n_reads=200_000):
+    """golden/hg002shape/hg002shape.json (r06): BASELINE configs[4]'s SHAPE without minigraph and without the data (tools/synth.py:
+    make_svs_hg002 — 12.8 k DEL / INS of 50 bp .. 10 kb on the 24 GRCh37 contigs at their real lengths, SV deserts, clusters — and
+    svjg_synth_gaf_reads — 30x of ~20 kb reads walked from genome positions, nine lines in ten single-node paths).
+      1. The GRAPH is built by the reference's construct-graph.py from the generated VCF and a FASTA stand-in of the contigs' lengths
+         (3.1 GB of 'N': the filter never reads reference sequences); its _svs_edges.json must equal tools/synth.py's byte for byte and
+         its GFA after eliding the reference sequences — the fixture holds the sha256 of both, so the GPU box can regenerate the graph
+         and know it is the one the reference built.
+      2. The first n_reads lines of the GAF through the reference's filter-alignments.py and predict-genotype.py: per-SV counts,
+         sha256 of the JSON and of the VCF, the reference's run times."""
+    import time
+    sys.path.insert(0, f"{ROOT}/tools")
+    import synth
+    out = f"{HERE}/hg002shape"
+    os.makedirs(out, exist_ok=True)
+    tmp = tempfile.mkdtemp(dir="/tmp")
+    pre = f"{tmp}/hg"
+    inf = synth.generate_hg002(pre, n_reads=n_reads)
+    t0 = time.time()
+    with open(f"{tmp}/ref.fa", "w") as fh:
+        for c, l in zip(inf["chroms"], inf["chrom_len"]):
+            fh.write(f">{c}\n")
+            fh.write("N" * l)
+            fh.write("\n")
+    os.makedirs(f"{tmp}/r")
+    t1 = time.time()
+    subprocess.run([sys.executable, f"{REF}/construct-graph.py", "-v", pre + ".vcf", "-r", f"{tmp}/ref.fa", "-o", f"{tmp}/r/hg.gfa"], check=True, capture_output=True)
+    t_construct = time.time() - t1
+    os.remove(f"{tmp}/ref.fa")
+    assert open(pre + "_svs_edges.json").read() == open(f"{tmp}/r/hg_svs_edges.json").read(), "edges JSON differs from construct-graph.py's"
+    h_ref, h_own = hashlib.sha256(), hashlib.sha256()
+    with open(f"{tmp}/r/hg.gfa") as fr, open(pre + ".gfa") as fo:
+        for lr in fr:
+            if lr.startswith("S"):
+                c = lr.rstrip("\n").split("\t", 2)
+                if "." not in c[1].split(":")[-1]:
+                    lr = f"S\t{c[1]}\t*\n"
+            lo = fo.readline()
+            assert lr == lo, (lr[:200], lo[:200])
+            h_ref.update(lr.encode()); h_own.update(lo.encode())
+        assert fo.readline() == ""
+    os.remove(f"{tmp}/r/hg.gfa")
+    # the filter and the genotyper of the reference on the sample (the graph files are now known to be the reference's own)
+    t1 = time.time()
+    rc, err = run_ref_filter(pre + ".gaf", pre + ".gfa", pre)
+    assert rc == 0, err
+    t_filter = time.time() - t1
+    js = open(pre + "_informative_aln.json").read()
+    d = json.loads(js)
+    t1 = time.time()
+    rc, so = run_ref_genotype(pre + "_informative_aln.json", pre + ".vcf", pre + "_genotype.vcf")
+    assert rc == 0
+    t_geno = time.time() - t1
+    vcf = open(pre + "_genotype.vcf", "rb").read()
+    gaf = open(pre + ".gaf", "rb").read()
+    lines = gaf.split(b"\n")[:-1]
+    k = [ln.split(b"\t")[5].count(b">") + ln.split(b"\t")[5].count(b"<") for ln in lines]
+    fix = {"seed": synth.HG002_SEED, "n_reads": n_reads, "n_sv": inf["n_sv"], "n_nodes": inf["n_nodes"], "n_edge_keys": inf["n_edge_keys"],
+           "edges_json_sha256": hashlib.sha256(open(pre + "_svs_edges.json", "rb").read()).hexdigest(),
+           "gfa_elided_sha256": h_own.hexdigest(), "vcf_in_sha256": hashlib.sha256(open(pre + ".vcf", "rb").read()).hexdigest(),
+           "gaf_sha256": hashlib.sha256(gaf).hexdigest(), "gaf_bytes": len(gaf), "single_node_lines": int(sum(x == 1 for x in k)),
+           "json_sha256": hashlib.sha256(js.encode()).hexdigest(), "json_bytes": len(js), "vcf_sha256": hashlib.sha256(vcf).hexdigest(),
+           "genotyped": so.strip(), "counts": {key: [len(v[0]), len(v[1])] for key, v in d.items()},
+           "reference_seconds": {"construct_graph": round(t_construct, 1), "filter": round(t_filter, 2), "genotype": round(t_geno, 2)},
+           "graph_built_by": "construct-graph.py of the reference, from the generated VCF + a FASTA of N at GRCh37 lengths"}
+    assert h_ref.hexdigest() == h_own.hexdigest()
+    json.dump(fix, open(f"{out}/hg002shape.json", "w"), indent=0, sort_keys=True)
+    print("hg002shape:", {k2: v for k2, v in fix.items() if k2 != "counts"}, len(fix["counts"]), "SVs with informative alignments")
+    shutil.rmtree(tmp)
+
+
 def make_contigs():
     """golden/contigs: contig names shaped like the GRCh38 analysis set's — HLA-DRB1*15:03:01:01 and HLA-A*01:01:01:01 (':', '*' and '-'
     INSIDE the contig part: the reference takes the LAST ':' field of a node name, filter-alignments.py:328-349), chrUn_JTFH01001998v1_decoy,

@@ -115,3 +115,55 @@ def test_count_reader_rejects(tmp_path, text):
     p.write_text(text)
     with pytest.raises(ValueError):
         capi.count_informative_json(str(p))
+
+
+def _canonical(n_keys, rng, escapes=False):
+    d = {}
+    for k in range(n_keys):
+        def text(i):
+            s = f"read{k}_{i}\t20015\t12\t+\t>chr1:1000-2000<chr2:1-9\t300\ttp:A:P\n"
+            return s + ('\n    "trap": [\\ "' if escapes and i % 7 == 3 else "")      # (escaped in the file: no raw newline inside a string)
+        d[f"chr{k % 5}:DEL-{k * 1000}-{k * 1000 + 300}"] = [[text(i) for i in range(int(rng.integers(0, 40)))], [text(i) for i in range(int(rng.integers(0, 9)))]]
+    return d
+
+
+@pytest.mark.parametrize("threads", [2, 3, 8, 32])
+def test_count_reader_in_parallel_equals_json_load(tmp_path, monkeypatch, threads):
+    """r06: files of 64 MB and more are parsed by several threads, chained (svjg_json.cpp: count_chained); here small files are sent the
+    same way.  json.dumps' own layout (the chain holds), and layouts whose guessed starts are wrong or absent (the chain fails, one thread
+    parses): always what json.load says."""
+    rng = np.random.default_rng(threads)
+    monkeypatch.setenv("SVJG_JSON_PARALLEL_FROM", "0")
+    monkeypatch.setenv("SVJG_JSON_THREADS", str(threads))
+    d = _canonical(400, rng, escapes=True)
+    layouts = {"indent4": json.dumps(d, sort_keys=True, indent=4), "indent2": json.dumps(d, indent=2), "compact": json.dumps(d, separators=(",", ":")),
+               "indent4_crlf": json.dumps(d, indent=4).replace("\n", "\r\n"), "one_key": json.dumps({"k": [["a"] * 500, []]}, indent=4),
+               "empty": "{}", "empty_lists": json.dumps({f"k{i}": [[], []] for i in range(300)}, indent=4)}
+    # elements at the indent json.dumps gives keys: every guessed start is inside a pair
+    layouts["elements_at_four"] = "{\n" + ",\n".join('"%s": [[\n    "x",\n    "y"\n],\n[\n    "z"\n]]' % k for k in list(d)[:200]) + "\n}"
+    # extra elements behind the two lists, nested values as elements
+    layouts["extras"] = json.dumps({k: [v[0], v[1], "more", {"x": [1, 2]}] for k, v in list(d.items())[:100]}, indent=4)
+    for name, text in layouts.items():
+        p = tmp_path / f"{name}.json"
+        p.write_text(text)
+        keys, cnt = capi.count_informative_json(str(p))
+        want = json.loads(text)
+        assert keys == list(want), name
+        assert cnt.tolist() == [[len(want[k][0]), len(want[k][1])] for k in keys], name
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("text", ['{"a": [["x\ny"], []]}', '{"a": [["x\\qy"], []]}', '{"a": [["\\u12G4"], []]}', '{"a\tb": [[], []]}', '{"a": [["x\x01"], []]}',
+                                  '{\n    "a": [[], []],\n    "b": [["x"], [] ],\n    "c": [[], []]\n    "d": [[], []]\n}',
+                                  '{\n    "a": [[], []],\n    "b": [["x"], []]\n}\n    "c": [[], []]\n}'])
+def test_count_reader_is_as_strict_as_json_load(tmp_path, monkeypatch, text, threads):
+    """what json.load refuses (predict-genotype.py:67-68 dies with JSONDecodeError, a ValueError): raw control characters inside a string,
+    escapes JSON does not have, a missing comma between pairs, text behind the object — by one thread and by the chained threads"""
+    monkeypatch.setenv("SVJG_JSON_PARALLEL_FROM", "0")
+    monkeypatch.setenv("SVJG_JSON_THREADS", str(threads))
+    with pytest.raises(ValueError):
+        json.loads(text)
+    p = tmp_path / "bad.json"
+    p.write_text(text)
+    with pytest.raises(ValueError):
+        capi.count_informative_json(str(p))

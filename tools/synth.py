@@ -38,11 +38,12 @@ def build_lib():
         os.makedirs(os.path.dirname(so), exist_ok=True)
         subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
     lib = ctypes.CDLL(so)
-    for fn in (lib.svjg_synth_gaf, lib.svjg_synth_gaf_long):
+    for fn in (lib.svjg_synth_gaf, lib.svjg_synth_gaf_long, lib.svjg_synth_gaf_reads):
         fn.restype = ctypes.c_long
         fn.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                        ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    lib.svjg_synth_gaf_reads.argtypes = lib.svjg_synth_gaf_reads.argtypes + [ctypes.c_void_p]
     _LIB = lib
     return lib
 
@@ -136,6 +137,85 @@ def make_svs(n_sv, n_chrom, mix, seed, chrom_style="plain"):
 
 def _ins_seq(n):
     return (_INS_UNIT * (n // len(_INS_UNIT) + 1))[:n]
+
+
+# ---- BASELINE configs[4]'s SHAPE (HG002 GIAB v0.6 Tier1 + 30x ONT): what can be reproduced without minigraph and without the data ----------
+# The 24 contigs of GRCh37 with their real lengths (names as in the GIAB v0.6 VCF: no "chr" prefix); ~12.8 k SVs — 5.5 k DEL, 7.3 k INS,
+# 50 bp .. 10 kb, small ones most frequent — placed uniformly outside a few SV deserts (centromeres / heterochromatin with their poorly
+# mapped flanks, the acrocentric short arms, the tail of Y: approximate hg19 coordinates; Tier1 has no calls there) with a quarter of them
+# in clusters of 2..4 within a few kb (tandem-repeat regions); 2 % of the INS share their position with another INS.  With ~240 kb
+# between breakpoints a 20 kb read crosses none nine times out of ten: most GAF lines are single-node paths.  The node Y:25 Mbp..59.37 Mbp
+# is longer than 2^25 bp.
+GRCH37 = [("1", 249250621), ("2", 243199373), ("3", 198022430), ("4", 191154276), ("5", 180915260), ("6", 171115067), ("7", 159138663),
+          ("8", 146364022), ("9", 141213431), ("10", 135534747), ("11", 135006516), ("12", 133851895), ("13", 115169878), ("14", 107349540),
+          ("15", 102531392), ("16", 90354753), ("17", 81195210), ("18", 78077248), ("19", 59128983), ("20", 63025520), ("21", 48129895),
+          ("22", 51304566), ("X", 155270560), ("Y", 59373566)]
+_DESERTS = {"1": [(121_000_000, 145_000_000)], "9": [(38_800_000, 71_000_000)], "13": [(0, 19_000_000)], "14": [(0, 19_000_000)],
+            "15": [(0, 20_000_000)], "16": [(35_000_000, 46_500_000)], "21": [(0, 14_300_000)], "22": [(0, 16_000_000)],
+            "X": [(58_000_000, 62_000_000)], "Y": [(25_000_000, 59_373_566)]}
+_WEIGHT = {"X": 0.5, "Y": 0.15}
+
+
+def make_svs_hg002(seed, n_sv=12_800):
+    """-> (SV dicts in VCF order, contig names, contig lengths) for build_graph() / vcf_text()"""
+    chroms = [c for c, _ in GRCH37]
+    chrom_len = [l for _, l in GRCH37]
+    allowed = []
+    for c, L in GRCH37:
+        iv, at = [], 10_000
+        for a, b in sorted(_DESERTS.get(c, [])):
+            if a > at:
+                iv.append((at, a))
+            at = max(at, b)
+        if at < L - 30_000:
+            iv.append((at, L - 30_000))
+        allowed.append(iv)
+    room = np.array([sum(b - a for a, b in iv) * _WEIGHT.get(c, 1.0) for (c, _), iv in zip(GRCH37, allowed)])
+    per = np.floor(room / room.sum() * n_sv).astype(int)
+    per[0] += n_sv - per.sum()
+    svs = []
+    for c, (iv, n_c) in enumerate(zip(allowed, per)):
+        u_pos = _draws(seed, int(n_c), 100 + c)
+        u_kind = _draws(seed, int(n_c), 200 + c)
+        u_size = _draws(seed, int(n_c), 300 + c)
+        u_near = _draws(seed, int(n_c), 400 + c)
+        tot = sum(b - a for a, b in iv)
+        raw = np.sort((u_pos % np.uint64(tot)).astype(np.int64))
+        pos_prev, end_prev, i = 0, 0, 0
+        while i < n_c:
+            off = int(raw[i])
+            for a, b in iv:                                   # offset within the allowed intervals -> coordinate
+                if off < b - a:
+                    pos = a + off
+                    break
+                off -= b - a
+            members = 1
+            if int(u_near[i] % np.uint64(100)) < 9:           # a cluster: this one and 1..3 followers a few hundred bp .. 3 kb apart
+                members = 2 + int((u_near[i] >> np.uint64(8)) % np.uint64(3))
+            for m in range(members):
+                if i >= n_c:
+                    break
+                if m:
+                    pos = max(end_prev, pos_prev) + 60 + int((u_near[i] >> np.uint64(16)) % np.uint64(2940))
+                pos = max(pos, pos_prev + 2)
+                kind = int(u_kind[i] % np.uint64(1280))
+                size = int(50 * 200.0 ** ((int(u_size[i] % np.uint64(1 << 20)) / float(1 << 20)) ** 2))
+                sv = {"chrom": c, "pos": pos, "idx": len(svs)}
+                if kind < 550:
+                    sv["type"] = "DEL"; sv["end"] = pos + size
+                    end_prev = sv["end"]
+                else:
+                    sv["type"] = "INS"; sv["alt_len"] = size
+                    end_prev = pos
+                svs.append(sv)
+                if sv["type"] == "INS" and kind >= 1255 and i + 1 < n_c:     # 2 % of the INS: a second INS at the same position
+                    i += 1
+                    size2 = int(50 * 200.0 ** ((int(u_size[i] % np.uint64(1 << 20)) / float(1 << 20)) ** 2))
+                    svs.append({"chrom": c, "pos": pos, "idx": len(svs), "type": "INS", "alt_len": size2})
+                pos_prev = pos
+                i += 1
+        assert max(sv.get("end", sv["pos"]) for sv in svs if sv["chrom"] == c) < chrom_len[c] - 2
+    return svs, chroms, chrom_len
 
 
 def vcf_text(svs, chroms, chrom_len):
@@ -314,7 +394,12 @@ def gaf_bytes(tab, seed, first, n, threads=8, shape="short"):
     """GAF text for lines [first, first+n) as one numpy uint8 array.  shape "long": long-read shaped lines (svjg_synth_gaf_long: read
     names of sequencers, paths long-tailed to 200 nodes, cg:Z: strings on a third of the lines)."""
     lib = build_lib()
-    fn = lib.svjg_synth_gaf_long if shape == "long" else lib.svjg_synth_gaf
+    fn = lib.svjg_synth_gaf_long if shape == "long" else lib.svjg_synth_gaf_reads if shape == "reads" else lib.svjg_synth_gaf
+    extra = ()
+    if shape == "reads":                                        # reads start at genome positions: running sum of the reference nodes' lengths
+        cum = np.zeros(tab["n_ref"] + 1, dtype=np.uint64)
+        np.cumsum(tab["len"][: tab["n_ref"]], out=cum[1:])
+        extra = (cum.ctypes.data,)
     threads = max(1, min(threads, (n + 9999) // 10000))
     step = (n + threads - 1) // threads
     # measurement only (SVJG_SYNTH_HOT=d): reads start in the first 1/d of the reference nodes, so that the records they touch fit the L2
@@ -323,11 +408,11 @@ def gaf_bytes(tab, seed, first, n, threads=8, shape="short"):
     def work(t):
         a = first + t * step
         cnt = max(0, min(step, first + n - a))
-        cap = cnt * (2600 if shape == "long" else 700) + 16384
+        cap = cnt * (2600 if shape == "long" else 700) + 32768
         buf = np.empty(cap, dtype=np.uint8)
         got = fn(tab["blob"], tab["off"].ctypes.data, tab["len"].ctypes.data, n_start,
                                  tab["ptr"].ctypes.data, tab["to"].ctypes.data, tab["sv"].ctypes.data,
-                                 tab["gt"].ctypes.data, seed, a, cnt, buf.ctypes.data, cap)
+                                 tab["gt"].ctypes.data, seed, a, cnt, buf.ctypes.data, cap, *extra)
         assert got >= 0
         return buf[:got]
 
@@ -351,6 +436,33 @@ def generate(prefix, n_aln, n_sv, n_chrom, mix, seed, write_gaf=True, threads=8,
             "chroms": chroms, "chrom_len": chrom_len, "svs": svs}
     if write_gaf or return_gaf:
         buf = gaf_bytes(tab, seed, 0, n_aln, threads, shape)
+        info["gaf_bytes"] = int(buf.size)
+        if write_gaf:
+            buf.tofile(prefix + ".gaf")
+        if return_gaf:
+            info["gaf"] = buf
+    return info
+
+
+HG002_SEED = 20260515 + 4
+HG002_READS = 4_650_000          # 30x of GRCh37's 3.1 Gbp in reads of ~20 kb
+
+
+def generate_hg002(prefix, n_reads=HG002_READS, seed=HG002_SEED, write_gaf=True, threads=8, return_gaf=False, first=0):
+    """BASELINE configs[4]'s shape: writes {prefix}.vcf, {prefix}.gfa, {prefix}_svs_edges.json (and {prefix}.gaf: reads [first, first + n_reads))."""
+    svs, chroms, chrom_len = make_svs_hg002(seed)
+    with open(prefix + ".vcf", "w") as fh:
+        fh.write(vcf_text(svs, chroms, chrom_len))
+    g = build_graph(svs, chroms, chrom_len)
+    with open(prefix + ".gfa", "w") as fh:
+        fh.write("".join(g["gfa"]))
+    with open(prefix + "_svs_edges.json", "w") as fh:
+        fh.write(json.dumps(g["edges"], sort_keys=True, indent=4))
+    tab = walk_tables(g, seed)
+    info = {"n_sv": len(svs), "n_nodes": len(g["node_names"]), "n_edge_keys": len(g["edges"]), "tables": tab,
+            "chroms": chroms, "chrom_len": chrom_len, "svs": svs}
+    if write_gaf or return_gaf:
+        buf = gaf_bytes(tab, seed, first, n_reads, threads, "reads")
         info["gaf_bytes"] = int(buf.size)
         if write_gaf:
             buf.tofile(prefix + ".gaf")
