@@ -86,7 +86,7 @@ struct svjg_ctx {
     // graph
     bool have_graph = false, have_counts = false;
     svjg_node *d_nodes = nullptr;  svjg_edge *d_edges = nullptr;  uint32_t *d_hits = nullptr;
-    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr, *d_names = nullptr, *d_links = nullptr, *d_nok = nullptr;  uint16_t *d_disp = nullptr;  uint32_t *d_ihits = nullptr;
+    uint8_t *d_cnames = nullptr;   uint32_t *d_coff = nullptr, *d_clo = nullptr, *d_chash = nullptr, *d_names = nullptr, *d_links = nullptr, *d_nok = nullptr;  uint16_t *d_disp = nullptr;  uint32_t *d_ihits = nullptr, *d_pfx = nullptr;
     GraphView gv{};
     uint32_t names_len = 0, gflags = 0, n_slots = 0;
     unsigned long long *d_counts = nullptr, *d_snap = nullptr;
@@ -184,8 +184,8 @@ extern "C" int svjg_init(int device, svjg_ctx **out) {
 
 static void free_graph(svjg_ctx *c) {
     hipFree(c->d_nodes); hipFree(c->d_edges); hipFree(c->d_hits); hipFree(c->d_cnames); hipFree(c->d_coff);
-    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap); hipFree(c->d_names); hipFree(c->d_links); hipFree(c->d_disp); hipFree(c->d_ihits); hipFree(c->d_nok);
-    c->d_nok = nullptr; c->d_names = nullptr; c->d_links = nullptr; c->d_disp = nullptr; c->d_ihits = nullptr;
+    hipFree(c->d_clo); hipFree(c->d_chash); hipFree(c->d_counts); hipFree(c->d_snap); hipFree(c->d_names); hipFree(c->d_links); hipFree(c->d_disp); hipFree(c->d_ihits); hipFree(c->d_nok); hipFree(c->d_pfx);
+    c->d_pfx = nullptr; c->d_nok = nullptr; c->d_names = nullptr; c->d_links = nullptr; c->d_disp = nullptr; c->d_ihits = nullptr;
     c->d_nodes = nullptr; c->d_edges = nullptr; c->d_hits = nullptr; c->d_cnames = nullptr; c->d_coff = nullptr;
     c->d_clo = nullptr; c->d_chash = nullptr; c->d_counts = nullptr; c->d_snap = nullptr;
     c->have_graph = false; c->have_counts = false;
@@ -271,11 +271,13 @@ extern "C" int svjg_load_graph(svjg_ctx *c, const svjg_graph *g) {
     if ((rc = upload(c, &c->d_disp, kt.disp.data(), kt.disp.size()))) return rc;
     if ((rc = upload(c, &c->d_ihits, kt.ihits.data(), kt.ihits.size()))) return rc;
     if ((rc = upload(c, &c->d_nok, kt.node_of_kid.data(), kt.node_of_kid.size()))) return rc;
+    if (!kt.name_pfx.empty() && (rc = upload(c, &c->d_pfx, kt.name_pfx.data(), kt.name_pfx.size()))) return rc;   // (names of 49..64 bytes: rare)
     HIPCHK(c, hipStreamSynchronize(c->stream));           // `hash` and `kt` are locals
     c->gv.nodes = c->d_nodes; c->gv.n_nodes = (uint32_t)g->n_nodes; c->gv.edges = c->d_edges; c->gv.hits = c->d_hits;
     c->gv.chrom_names = c->d_cnames; c->gv.chrom_off = c->d_coff; c->gv.chrom_lo = c->d_clo; c->gv.chrom_hash = c->d_chash;
     c->gv.n_chrom = g->n_chrom; c->gv.hash_mask = (uint32_t)hash.size() - 1; c->gv.d_over = g->d_over;
     c->gv.dover_list = (g->flags & SVJG_GRAPH_DOVER_LIST) ? 1u : 0u;
+    c->gv.name_pfx = c->d_pfx;
     c->gv.node_of_kid = c->d_nok; c->gv.name_tab = c->d_names; c->gv.name_ihits = c->d_ihits; c->gv.name_disp = c->d_disp; c->gv.name_slots = kt.name_slots; c->gv.name_buckets = kt.name_buckets;
     c->gv.name_complete = (kt.names_left_out == 0 && kt.names_skipped == 0) ? 1u : 0u;
     c->gv.link_tab = c->d_links; c->gv.link_mask = kt.link_mask; c->gv.link_seed = kt.link_seed;
@@ -536,8 +538,9 @@ static int classify_range(svjg_ctx *c, uint64_t begin, uint64_t end, uint64_t ba
         const uint64_t n_def = c->hs().n_deferred;
 #ifdef SVJG_TIMING
         if (a.diag & 16u) {
-            unsigned long long d[12];
+            unsigned long long d[16];
             HIPCHK(c, hipMemcpy(d, c->d_dbg, sizeof d, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[svjg diag] sub-passes of long lines: first sweep counting %llu, first sweep measuring only %llu, second sweep %llu; nodes in sub-passes %llu\n", d[12], d[13], d[14], d[15]);
             fprintf(stderr, "[svjg diag] wave time per phase (sum over waves, counter ticks)  A+B1 %llu  prefix %llu  B2 %llu  R1 %llu  NP: lists %llu  names+disp %llu  records %llu  scan+search %llu  links+atomics %llu  R6+end %llu;  passes %llu (sub-passes of long lines %llu), nodes in them %llu\n",
                     d[0], d[1], d[2], d[3], d[8], d[9], d[4], 0ull, d[6], d[7], d[10], d[11], d[5]);
         }

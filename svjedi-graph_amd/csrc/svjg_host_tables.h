@@ -86,6 +86,7 @@ struct KernelTables {
     std::vector<uint32_t> names; uint32_t name_slots = 0, name_buckets = 0;
     std::vector<uint16_t> disp;                               // displacement of every bucket of the name hash
     std::vector<uint32_t> ihits;                              // hit lists of inline links with more than one hit: count, hits...
+    std::vector<uint32_t> name_pfx;                           // names of 49..64 bytes: their first len - 48 bytes, 4 words per kernel id (empty: no such name)
     std::vector<uint32_t> links; uint32_t link_mask = 0, link_seed = 0;
     uint64_t names_left_out = 0, links_left_out = 0, links_unplaced = 0;   // links_unplaced: their left nodes are flagged for the exact path
     uint32_t names_skipped = 0;                               // node names the table cannot hold (> 32 bytes, id too large)
@@ -201,8 +202,16 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             uint32_t c = (uint32_t)(nd.key >> 48), pos = (uint32_t)(nd.key >> 16), kind = (uint32_t)(nd.key >> 15) & 1u, cnt = (uint32_t)nd.key & 0x7FFFu;
             std::string nm(g.chrom_names + g.chrom_off[c], g.chrom_off[c + 1] - g.chrom_off[c]);
             nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
-            if (nm.size() > 4 * NAME_WORDS || kid[i] > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path (the record holds the WALK-ORDER id in 24 bits)
+            if (nm.size() > NAME_MAX_BYTES || kid[i] > NAME_MAX_ID) { ++kt.names_skipped; continue; }    // such a name can only be handled by the exact path (the record holds the WALK-ORDER id in 24 bits)
             uint32_t d[NAME_WORDS];
+            uint64_t pfx_hash = 0;
+            if (nm.size() > 4 * NAME_WORDS) {                 // 49..64 bytes: windows of the last 48, the bytes in front of them in name_pfx
+                name_windows(nm.data() + (nm.size() - 4 * NAME_WORDS), 0, 4 * NAME_WORDS, d);
+                if (kt.name_pfx.empty()) kt.name_pfx.assign((size_t)g.n_nodes * NAME_PFX_WORDS, 0u);
+                uint32_t *pw = &kt.name_pfx[(size_t)kid[i] * NAME_PFX_WORDS];
+                name_prefix_words(nm.data(), 0, (uint32_t)nm.size(), pw);
+                pfx_hash = name_pfx_hash(pw);
+            } else
             name_windows(nm.data(), 0, (uint32_t)nm.size(), d);
             uint32_t flags = ((nd.row & 0x80000000u) ? 1u : 0u) | ((kind && nd.aux == SVJG_LEN_UNKNOWN) ? 2u : 0u);
             uint32_t len_bp = kind ? nd.aux : nd.aux - pos + 1;
@@ -210,7 +219,7 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             for (uint32_t w = 0; w < NAME_WORDS; ++w) ent.push_back(d[w]);
             ent.push_back((kid[i] << NAME_ID_SHIFT) | (flags << NAME_LEN_BITS) | ((uint32_t)nm.size() - 1u));
             ent.push_back(len_bp & ~REC_ROW_INLINE);
-            hs.push_back(name_prehash(d, (uint32_t)nm.size()));
+            hs.push_back(name_prehash(d, (uint32_t)nm.size()) + pfx_hash);
             key_node.push_back((uint32_t)i);
         }
         // two names with one 64-bit pre-hash cannot be told apart by any displacement: both stay out (exact path)

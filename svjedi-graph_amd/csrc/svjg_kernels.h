@@ -186,7 +186,7 @@ enum : uint32_t { ST_NONE = 0, ST_OK = 1, ST_NOHIT = 2, ST_DEFER = 3 };   // per
 enum : uint32_t { DC_COLUMNS = 0,      // the line's columns are not twelve plain ones (blanks, signs, too few, Alen = 0, marks outside the path column, ...)
                   DC_IDF = 1,          // a 64-byte span of the line holds the pair "d:" (an id:f: tag, or a false alarm)
                   DC_LONG_PATH = 2,    // more than KMAX path nodes
-                  DC_NAME = 3,         // a node name the name table does not hold (unknown, hazard-prone, longer than 48 bytes, alt length unknown)
+                  DC_NAME = 3,         // a node name the name table does not hold (unknown, hazard-prone, longer than 64 bytes, alt length unknown), a path of 2^32 bp
                   DC_STRIPE = 4,       // the whole stripe: denser than the lists hold, a line longer than the staged text, or the caller asked for the exact path
                   DC_N = 5 };
 
@@ -227,6 +227,16 @@ __device__ inline void name_words_far(const uint8_t *text, uint32_t a0, uint32_t
     const u32_any *w = (const u32_any *)(text + a0 + (L > 32u ? L - 24u : 0u));
 #pragma unroll
     for (uint32_t i = 0; i < 4; ++i) f[i] = L > 32u ? w[i] : 0u;
+}
+// the first L - 48 bytes of a name of 49..64 bytes as four words, zero behind them (svjg_line.h: name_prefix_words), from the staged text
+__device__ inline void name_prefix_lds(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t p[NAME_PFX_WORDS]) {
+    const u32_any *w = (const u32_any *)(text + a0);
+    const int32_t n = (int32_t)L - (int32_t)(4u * NAME_WORDS);
+#pragma unroll
+    for (int32_t i = 0; i < (int32_t)NAME_PFX_WORDS; ++i) {
+        const int32_t k = n - 4 * i;                                      // bytes of word i that belong to the prefix
+        p[i] = k >= 4 ? w[i] : k <= 0 ? 0u : (w[i] & ((1u << (8 * k)) - 1u));
+    }
 }
 __device__ inline uint64_t name_words_tail2(const uint8_t *text, uint32_t a0, uint32_t L) {
     uint32_t f[4];
@@ -477,11 +487,11 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     unsigned long long wave_lines = 0;
     // measurement only (build with -DSVJG_TIMING, run with SVJG_DIAG & 16): time this wave spends per phase
 #ifdef SVJG_TIMING
-    unsigned long long stamp = __builtin_readcyclecounter(), acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp = __builtin_readcyclecounter(), acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&](int ph) { const unsigned long long t = __builtin_readcyclecounter(); acc[ph] += t - stamp; stamp = t; };
     // (8 .. 10 split the node pass's load phase: these wait for the loads they stamp, which the shipped kernel does not do there)
 #define tick_mem(ph) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tick(ph); } while (0)
-#define tally(ph, n) do { acc[ph] += (n); } while (0)             // (5: nodes in passes, 10: passes, 11: sub-passes of long lines)
+#define tally(ph, n) do { acc[ph] += (n); } while (0)             // (5: nodes in passes, 10: passes, 11: sub-passes of long lines; of those 12: first sweep, counting, 13: first sweep, measuring only, 14: second sweep; 15: nodes in sub-passes)
 #elif defined(SVJG_MARK)
     // static census (tools/isa): the phase boundaries show up as comments in the -S output
 #define tick(ph) asm volatile("; MARK " #ph)
@@ -782,9 +792,9 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const bool kfit = k >= 1 && k <= KLONG;
                     const uint32_t m_first = OPL_POS(o0), m_last = OPL_POS(kfit ? o0 + k - 1 : o0);
                     uint32_t t5 = tab_near(tbm, m_last + 1);
-                    if (t5 == TEXT) {                                     // (a name of 32..48 bytes: the tab is at most 49 bytes behind the mark)
-                        const uint32_t far = tab_near(tbm, m_last + 33 < TEXT ? m_last + 33 : TEXT);
-                        t5 = far <= m_last + 49u ? far : TEXT;
+                    if (RARELY(t5 == TEXT)) {                             // (a name of 32..64 bytes: the tab is at most 65 bytes behind the mark)
+                        t5 = tab_near(tbm, m_last + 33 < TEXT ? m_last + 33 : TEXT);
+                        if (t5 == TEXT) { const uint32_t f2 = tab_near(tbm, m_last + 65 < TEXT ? m_last + 65 : TEXT); t5 = f2 == m_last + 65u ? f2 : TEXT; }
                     }
                     uint32_t wb = tab_window(tbm, t5 + 1);              // columns 7..9
                     const uint32_t t6 = take_tab(wb, t5 + 1), t7 = take_tab(wb, t5 + 1), t8 = take_tab(wb, t5 + 1);
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         id_end = e | (lend << 16);
                     }
                     if (!ok && status == ST_DEFER && kall > KLONG) status = ST_DEFER + DC_LONG_PATH;
-                    else if (!ok && status == ST_DEFER && t5 == TEXT && t4 < TEXT && kfit) status = ST_DEFER + DC_NAME;   // (no tab within 49 bytes of the last mark: a name beyond 48 bytes)
+                    else if (!ok && status == ST_DEFER && t5 == TEXT && t4 < TEXT && kfit) status = ST_DEFER + DC_NAME;   // (no tab within 65 bytes of the last mark: a name beyond 64 bytes)
                     if (ok_cols) {
                         if (ok) status = k >= 2 ? ST_OK : ST_NOHIT;
                         r_need_l = ts + g.d_over;
@@ -949,7 +959,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     okl = 1ull << i0;
                 }
                 __builtin_amdgcn_s_setprio(P_LOAD);
-                tally(10, 1); tally(5, n_pass); if (lsub) tally(11, 1);
+                tally(10, 1); tally(5, n_pass); if (lsub) { tally(11, 1); tally(15, n_pass); if (lsub & L_SWEEP1) tally(14, 1); }
                 // -- the node of this lane: line, index in the line, name.  Every lane runs the same straight code on indices that
                 //    are safe to read (a lane beyond the pass looks at the pass's first mark); `live` says whose results count --
                 const wmask act_m = low_bits64(n_pass);
@@ -971,15 +981,25 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t na0 = opv + 1u;
                 const uint32_t len = ((j + 1 < lk) ? (op2.y & 0xFFFFu) : rl.w) - na0;
                 const uint32_t oribit = text[opv] == '<' ? 1u : 0u;
-                const wmask probe_m = live_m & m_le(len - 1u, 4u * NAME_WORDS - 1u);   // names of 1..48 bytes; longer ones: exact path
+                const wmask probe_m = live_m & m_le(len - 1u, NAME_MAX_BYTES - 1u);   // names of 1..64 bytes; longer ones: exact path
                 const bool probe = in_mask(probe_m);
+                // r06: a name of 49..64 bytes is looked up by the windows of its LAST 48 bytes (na1, len1); its first len - 48 bytes enter the
+                // hash here and are held against the table's (g.name_pfx) once the record has named a node (svjg_line.h: name_prefix_words)
+                uint32_t na1 = na0, len1 = len;
+                const wmask vlong_m = probe_m & m_gt(len, 4u * NAME_WORDS);                  // (wave-uniform: some name of the pass has 49..64 bytes)
+                if (RARELY(vlong_m)) { if (in_mask(vlong_m)) { na1 = na0 + len - 4u * NAME_WORDS; len1 = 4u * NAME_WORDS; } }
                 uint32_t d[8];
                 tick_mem(8);                                             // (list and per-line record read)
-                const uint32_t plen = probe ? len : 8u;                  // (keeps the longer names' window addresses inside the staged text)
-                uint64_t h = name_words_head(text, na0, len, (probe_m & m_lt(len, 8u)) != 0, d);   // the first three windows of the name
-                if (RARELY(probe_m & m_gt(len, 24u))) h += name_words_tail(text, na0, plen, d);      // (wave-uniform: node names of the usual length fit three windows)
-                const bool long_names = (probe_m & m_gt(len, 32u)) != 0;                     // (wave-uniform: some name of the pass has 33..48 bytes)
-                if (RARELY(long_names)) h += name_words_tail2(text, na0, plen);
+                const uint32_t plen = probe ? len1 : 8u;                 // (keeps the longer names' window addresses inside the staged text)
+                uint64_t h = name_words_head(text, na1, len1, (probe_m & m_lt(len, 8u)) != 0, d);   // the first three windows of the name
+                if (RARELY(probe_m & m_gt(len, 24u))) h += name_words_tail(text, na1, plen, d);      // (wave-uniform: node names of the usual length fit three windows)
+                const bool long_names = (probe_m & m_gt(len, 32u)) != 0;                     // (wave-uniform: some name of the pass has 33..64 bytes)
+                if (RARELY(long_names)) h += name_words_tail2(text, na1, plen);
+                if (RARELY(vlong_m)) {
+                    uint32_t pw[NAME_PFX_WORDS];
+                    name_prefix_lds(text, na0, in_mask(vlong_m) ? len : 4u * NAME_WORDS + 1u, pw);
+                    if (in_mask(vlong_m)) h += name_pfx_hash(pw) + (uint64_t)(len - len1) * 0x7FEB352Du;   // (the hash's length term is the whole name's)
+                }
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
@@ -999,7 +1019,15 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 uint32_t row_inline = 0;
                 // id << 8 | flags << 6 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
                 bool same = probe && name_match(r0, r1, r2, d, len);
-                if (RARELY(long_names)) { uint32_t f[4]; name_words_far(text, na0, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
+                if (RARELY(long_names)) { uint32_t f[4]; name_words_far(text, na1, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
+                if (RARELY(vlong_m)) {                                   // the bytes in front of the last 48 against those of the node the record names
+                    if (in_mask(vlong_m) && same && r1.z != 0xFFFFFFFFu) {
+                        uint32_t pw[NAME_PFX_WORDS];
+                        name_prefix_lds(text, na0, len, pw);
+                        const uint4 q = *(const uint4 *)(g.name_pfx + (size_t)(r1.z >> NAME_ID_SHIFT) * NAME_PFX_WORDS);
+                        same = ((q.x ^ pw[0]) | (q.y ^ pw[1]) | (q.z ^ pw[2]) | (q.w ^ pw[3])) == 0u;
+                    }
+                }
                 if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = r1.w >> 31; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
                 // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
@@ -1067,7 +1095,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                             IDS[t63 + lane] = id | (oribit << 31);
                             __hip_atomic_store(a.long_pre + (size_t)blockIdx.x * LONG_WORDS + t63 + lane, pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        if (lD0 == 3u) {
+                        if (lD0 == 3u && !DIAG(64u)) {                    // (DIAG 64, measurement only: no search for names that come twice — wrong counts where one does)
                             wave_sync();
                             wmask d = 0;
                             for (uint32_t m = 0; m < t63; ++m) d |= m_eq(id, IDS[m] & 0x00FFFFFFu);
@@ -1078,7 +1106,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 {
                     const uint32_t dprev = lane_below(dir);
                     const wmask oddm = step_m & (m_eq(dir, 0u) | (m_ge(j, 1u) & m_ne(dir, dprev)));
-                    if (RARELY(oddm)) {
+                    if (RARELY(oddm) && !DIAG(64u)) {
                         // the lanes of the lines that have such a step (a sub-pass of a long line: every lane is that line's)
                         const wmask search_m = live_m & (RARELY(lsub) ? ~0ull : ballot64(((low_bits64(lk) << lnb) & oddm) != 0ull));
                         const bool search = in_mask(search_m);
@@ -1110,10 +1138,12 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     }
                     if (revisits || l_dup) SET_D0(4u);
                     if (!(lsub & L_MEASURE) && lD0 < 4u) {          // (3: the ids turn, but every node so far has been held against all nodes before it)
+                        tally(12, 1);
                         lsub |= L_ONE;
                         tot = lS + rdlane(gsum, n_pass - 1u);
                     } else {
                         if (!(lsub & L_MEASURE)) { lsub |= L_MEASURE; SET_R(lP); }
+                        tally(13, 1);
                         if (lsub & L_FINAL) { lTOT = lS + rdlane(gsum, n_pass - 1u); lS = 0; lsub = (lsub & 0xFF0070u) | 1u | L_SWEEP1; }   // (the second sweep begins at the line's first node; lR and lD0 stay; what the first sweep has found — links [0, lR) — waits in the log until the second is through)
                         else { lS += rdlane(gsum, n_pass - 2u); SET_P(lP + n_pass - 1u); }
                         continue;
@@ -1325,7 +1355,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
     if (lane == 0 && wave_lines) atomicAdd(&a.st->n_lines, wave_lines);
 #ifdef SVJG_TIMING
     if ((a.diag & 16u) && lane == 0)
-        for (int i = 0; i < 12; ++i) atomicAdd(&a.dbg[i], acc[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&a.dbg[i], acc[i]);
 #endif
 }
 

@@ -59,6 +59,7 @@ struct GraphView {
     const uint32_t *node_of_kid; // the records hold the main kernel's node ids (walk order, svjg_host_tables.h): id -> index into nodes[] (exact path)
     uint32_t name_slots, name_buckets;
     uint32_t name_complete;      // every node name is in name_tab: a miss there means "no such node" (else: search the sorted table)
+    const uint32_t *name_pfx;    // main kernel: the first len - 48 bytes of a name of 49..64 bytes, 4 words per node id (kernel's ids); nullptr: the graph has no such name
     const uint32_t *link_tab;    // main kernel: (left, strand, right, strand) -> hits, 4 words per entry
     uint32_t link_mask, link_seed;
 };
@@ -93,6 +94,23 @@ SVJG_HD void name_windows(P t, uint64_t s, uint32_t len, uint32_t d[NAME_WORDS])
     d[0] = word(0); d[1] = word(4); d[2] = word(o1); d[3] = word(o1 + 4); d[4] = word(o2); d[5] = word(o2 + 4);
     d[6] = len > 24u ? word(len - 8u) : 0u; d[7] = len > 24u ? word(len - 4u) : 0u;
     for (uint32_t i = 0; i < 4; ++i) d[8 + i] = len > 32u ? word(len - 24u + 4u * i) : 0u;
+}
+// r06 — names of 49..64 bytes (contigs named like assemblies name their scaffolds): the twelve window words are those of the name's LAST 48
+// bytes, and its first len - 48 bytes (at most 16: four words, zero behind them) wait in a table of their own, four words per node id
+// (GraphView::name_pfx; present only if the graph has such a name).  They enter the pre-hash too, so that contigs which differ only at their
+// very beginning do not land in one slot.  (windows of the last 48 bytes, the first len - 48 bytes, len) determine the name.
+constexpr uint32_t NAME_MAX_BYTES = 64, NAME_PFX_WORDS = 4;
+template <class P>
+SVJG_HD void name_prefix_words(P t, uint64_t s, uint32_t len, uint32_t p[NAME_PFX_WORDS]) {      // 48 < len <= 64 bytes at t[s ..]
+    const uint32_t n = len - 4u * NAME_WORDS;
+    for (uint32_t w = 0; w < NAME_PFX_WORDS; ++w) {
+        uint32_t v = 0;
+        for (uint32_t b = 0; b < 4; ++b) if (4u * w + b < n) v |= (uint32_t)(uint8_t)t[s + 4u * w + b] << (8 * b);
+        p[w] = v;
+    }
+}
+SVJG_HD uint64_t name_pfx_hash(const uint32_t p[NAME_PFX_WORDS]) {
+    return (uint64_t)p[0] * 0xA24BAED5u + (uint64_t)p[1] * 0x9FB21C65u + (uint64_t)p[2] * 0xE7037ED1u + (uint64_t)p[3] * 0x8EBC6AF1u;
 }
 SVJG_HD uint64_t name_prehash(const uint32_t d[NAME_WORDS], uint32_t len) {
     const uint32_t C[NAME_WORDS] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u,

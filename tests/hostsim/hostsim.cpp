@@ -26,7 +26,7 @@ static GraphView make_view(const svjg_graph *g, const std::vector<uint32_t> &has
     v.chrom_names = (const uint8_t *)g->chrom_names; v.chrom_off = g->chrom_off; v.chrom_lo = g->chrom_node_lo;
     v.chrom_hash = hash.data(); v.n_chrom = g->n_chrom; v.hash_mask = (uint32_t)hash.size() - 1; v.d_over = g->d_over;
     v.dover_list = (g->flags & SVJG_GRAPH_DOVER_LIST) ? 1u : 0u;
-    v.node_of_kid = nullptr; v.name_tab = nullptr; v.name_ihits = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
+    v.node_of_kid = nullptr; v.name_tab = nullptr; v.name_pfx = nullptr; v.name_ihits = nullptr; v.name_disp = nullptr; v.name_slots = 0; v.name_buckets = 0; v.name_complete = 0; v.link_tab = nullptr; v.link_mask = 0; v.link_seed = 0;
     if (kt) {                                                             // the exact path resolves names through the node-name table
         v.node_of_kid = kt->node_of_kid.data(); v.name_tab = kt->names.data(); v.name_ihits = kt->ihits.data(); v.name_disp = kt->disp.data(); v.name_slots = kt->name_slots; v.name_buckets = kt->name_buckets;
         v.name_complete = (kt->names_left_out == 0 && kt->names_skipped == 0) ? 1u : 0u;
@@ -169,7 +169,11 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
         ++found;
         uint32_t d[NAME_WORDS];
         name_ent_words(e, d);
-        const uint64_t h = name_prehash(d, name_ent_len(e));
+        uint64_t h = name_prehash(d, name_ent_len(e));
+        if (name_ent_len(e) > 4 * NAME_WORDS) {                 // 49..64 bytes: the bytes in front of the last 48 are part of the hash (and wait in name_pfx)
+            if (kt.name_pfx.empty()) { ++bad; continue; }
+            h += name_pfx_hash(&kt.name_pfx[(size_t)name_ent_id(e) * NAME_PFX_WORDS]);
+        }
         if (j != name_slot(h, kt.disp[name_bucket(h, kt.name_buckets)], kt.name_slots)) ++bad;   // the kernel's one probe lands here
         const uint32_t id = kt.node_of_kid[name_ent_id(e)];    // (the record holds the kernel's id: walk order)
         if (!kt.node_has[id] || kt.node_slot[id] != j || kt.node_pre[id] != h) ++bad;
@@ -181,6 +185,12 @@ extern "C" uint64_t hostsim_check_tables(const svjg_graph *g) {
             std::string nm(g->chrom_names + g->chrom_off[c], g->chrom_off[c + 1] - g->chrom_off[c]);
             nm += ":" + std::to_string(pos) + (kind ? "." + std::to_string(cnt) : "-" + std::to_string(nd.aux));
             uint32_t w[NAME_WORDS];
+            if (nm.size() > 4 * NAME_WORDS) {
+                name_windows(nm.data() + (nm.size() - 4 * NAME_WORDS), 0, 4 * NAME_WORDS, w);
+                uint32_t pw[NAME_PFX_WORDS];
+                name_prefix_words(nm.data(), 0, (uint32_t)nm.size(), pw);
+                if (memcmp(pw, &kt.name_pfx[(size_t)name_ent_id(e) * NAME_PFX_WORDS], sizeof pw) != 0) ++bad;
+            } else
             name_windows(nm.data(), 0, (uint32_t)nm.size(), w);
             if (nm.size() != name_ent_len(e) || memcmp(w, d, sizeof w) != 0) ++bad;
         }

@@ -171,3 +171,33 @@ def test_long_path_fuzz(seed):
         for wave in (0, 2, 5):
             with pytest.raises(KeyError):
                 sim.classify(g, bad.encode(), True, wave)
+
+
+def test_tables_with_node_names_of_49_to_64_bytes(tmp_path):
+    """r06: names of 49..64 bytes are in the main kernel's table (windows of the last 48 bytes + the first bytes in name_pfx, both hashed);
+    beyond 64 bytes they stay out.  The table check finds every such node under its hash with its prefix words; the exact routine agrees
+    with the C oracle on a graph whose contigs differ only in their first bytes."""
+    import synth
+    pre = str(tmp_path / "n")
+    synth.generate(pre, 3000, 600, 7, "mixed", 57)
+    a = "scaffold_of_an_assembly_that_names_them_at_length"
+    ren = {"chr2": "chromosome_2", "chr3": "chr1_KI270706v1_random", "chr4": "a_contig_name_of_thirty_six_bytes_xx", "chr5": "A_" + a[:42], "chr6": "B_" + a[:42],
+           "chr7": "a_contig_name_that_is_really_fifty_five_bytes_long_abcde"}
+    for ext in (".gfa", "_svs_edges.json", ".gaf"):
+        t = open(pre + ext).read()
+        for old, new in ren.items():
+            t = t.replace(old + ":", new + ":").replace(old + "\t", new + "\t")
+        open(pre + ext, "w").write(t)
+    g = Graph.from_files(pre + "_svs_edges.json", pre + ".gfa")
+    lens = np.array([len(n) for n in g.node_names])
+    assert ((lens > 48) & (lens <= 64)).sum() > 100 and (lens > 64).sum() > 50
+    assert sim.check_tables(g) == 0
+    stats = sim.table_stats(g)
+    assert stats[0] == 0 and stats[1] == int((lens > 64).sum())               # left out: none; skipped: exactly the names beyond 64 bytes
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    gaf = np.fromfile(pre + ".gaf", dtype=np.uint8)
+    want, _, _ = orc.filter(gaf, want_hits=False)
+    order = [orc.sv_ids.index(x) for x in g.sv_ids]
+    for wave in (0, 2, 5):
+        c, _ = sim.classify(g, gaf, True, wave)
+        assert (c.astype(np.uint64) == want[order]).all()
