@@ -981,25 +981,15 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t na0 = opv + 1u;
                 const uint32_t len = ((j + 1 < lk) ? (op2.y & 0xFFFFu) : rl.w) - na0;
                 const uint32_t oribit = text[opv] == '<' ? 1u : 0u;
-                const wmask probe_m = live_m & m_le(len - 1u, NAME_MAX_BYTES - 1u);   // names of 1..64 bytes; longer ones: exact path
+                const wmask probe_m = live_m & m_le(len - 1u, 4u * NAME_WORDS - 1u);   // names of 1..48 bytes (49..64: the cold block below; longer ones: exact path)
                 const bool probe = in_mask(probe_m);
-                // r06: a name of 49..64 bytes is looked up by the windows of its LAST 48 bytes (na1, len1); its first len - 48 bytes enter the
-                // hash here and are held against the table's (g.name_pfx) once the record has named a node (svjg_line.h: name_prefix_words)
-                uint32_t na1 = na0, len1 = len;
-                const wmask vlong_m = probe_m & m_gt(len, 4u * NAME_WORDS);                  // (wave-uniform: some name of the pass has 49..64 bytes)
-                if (RARELY(vlong_m)) { if (in_mask(vlong_m)) { na1 = na0 + len - 4u * NAME_WORDS; len1 = 4u * NAME_WORDS; } }
                 uint32_t d[8];
                 tick_mem(8);                                             // (list and per-line record read)
-                const uint32_t plen = probe ? len1 : 8u;                 // (keeps the longer names' window addresses inside the staged text)
-                uint64_t h = name_words_head(text, na1, len1, (probe_m & m_lt(len, 8u)) != 0, d);   // the first three windows of the name
-                if (RARELY(probe_m & m_gt(len, 24u))) h += name_words_tail(text, na1, plen, d);      // (wave-uniform: node names of the usual length fit three windows)
-                const bool long_names = (probe_m & m_gt(len, 32u)) != 0;                     // (wave-uniform: some name of the pass has 33..64 bytes)
-                if (RARELY(long_names)) h += name_words_tail2(text, na1, plen);
-                if (RARELY(vlong_m)) {
-                    uint32_t pw[NAME_PFX_WORDS];
-                    name_prefix_lds(text, na0, in_mask(vlong_m) ? len : 4u * NAME_WORDS + 1u, pw);
-                    if (in_mask(vlong_m)) h += name_pfx_hash(pw) + (uint64_t)(len - len1) * 0x7FEB352Du;   // (the hash's length term is the whole name's)
-                }
+                const uint32_t plen = probe ? len : 8u;                  // (keeps the longer names' window addresses inside the staged text)
+                uint64_t h = name_words_head(text, na0, len, (probe_m & m_lt(len, 8u)) != 0, d);   // the first three windows of the name
+                if (RARELY(probe_m & m_gt(len, 24u))) h += name_words_tail(text, na0, plen, d);      // (wave-uniform: node names of the usual length fit three windows)
+                const bool long_names = (probe_m & m_gt(len, 32u)) != 0;                     // (wave-uniform: some name of the pass has 33..48 bytes)
+                if (RARELY(long_names)) h += name_words_tail2(text, na0, plen);
                 // -- perfect hash of the names: the bucket's displacement (a small, cache-resident array), then the ONE record
                 //    the name can be in: 64 bytes with the spelling, id, length and the node's commonest links --
                 uint32_t dsp = 0;
@@ -1019,43 +1009,89 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 uint32_t row_inline = 0;
                 // id << 8 | flags << 6 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
                 bool same = probe && name_match(r0, r1, r2, d, len);
-                if (RARELY(long_names)) { uint32_t f[4]; name_words_far(text, na1, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
-                if (RARELY(vlong_m)) {                                   // the bytes in front of the last 48 against those of the node the record names
-                    if (in_mask(vlong_m) && same && r1.z != 0xFFFFFFFFu) {
-                        uint32_t pw[NAME_PFX_WORDS];
-                        name_prefix_lds(text, na0, len, pw);
-                        const uint4 q = *(const uint4 *)(g.name_pfx + (size_t)(r1.z >> NAME_ID_SHIFT) * NAME_PFX_WORDS);
-                        same = ((q.x ^ pw[0]) | (q.y ^ pw[1]) | (q.z ^ pw[2]) | (q.w ^ pw[3])) == 0u;
-                    }
-                }
+                if (RARELY(long_names)) { uint32_t f[4]; name_words_far(text, na0, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
                 if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = r1.w >> 31; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
                 // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
                 // (all nodes of a line sit in this pass — or the line is a long one, none of whose links has been counted yet: what its
                 // earlier sub-passes found waits in the worker's log).  Ordinary text never gets here.
                 {
+                    // One test on the path of ordinary text — is any node of the pass unknown, or 2^25 bp long and more — in front of three
+                    // things ordinary text never needs (in this order):
+                    //  * r06 — names of 49..64 bytes (contigs named like assemblies name their scaffolds) are looked up HERE by the windows of their
+                    //    LAST 48 bytes; their first len - 48 bytes enter the hash and are held against a table of their own (g.name_pfx, four
+                    //    words per node id; svjg_line.h: name_prefix_words).  A second, dependent trip to the tables for such a pass, nothing
+                    //    for every other (woven into the lookup above it cost the headline 0.9 %: profiles/r06/experiments/names_49_to_64_bytes.txt).
+                    //  * r06 — a node of 2^25 bp and more (GRCh37 has SV-free stretches of that order: a whole-genome graph's node Y:25 Mbp-59 Mbp,
+                    //    every contig without an SV) no longer sends its line away.  The wave's prefix sum below wraps modulo 2^32 across
+                    //    LINES, which the per-line differences undo; what must hold is that each line's OWN path stays below 2^32 bp.  The
+                    //    same prefix sum over the lengths >> 6 (at most 2^25 each: no wrap over 64 lanes) bounds every line's total from
+                    //    above: (sum of len >> 6) + nodes < 2^26  =>  path < 2^32.  A sub-pass of a line of > 64 nodes keeps the old rule
+                    //    (its running total is checked for wrapping ONCE per sub-pass).
+                    //  * an unknown node, or a path that long: the line takes the exact path.  The lanes that see it say so in the line's
+                    //    record, and every lane of the pass reads its line's record again (all nodes of a line sit in this pass — or the
+                    //    line is a long one, none of whose links has been counted yet: what its earlier sub-passes found waits in the
+                    //    worker's log).
                     wmask bad = live_m & m_eq(id, NONE32);
-                    // r06: a node of 2^25 bp and more (GRCh37 has SV-free stretches of that order: a whole-genome graph's node Y:25 Mbp-59 Mbp,
-                    // every contig without an SV) no longer sends its line away.  The wave's prefix sum below wraps modulo 2^32 across
-                    // LINES, which the per-line differences undo; what must hold is that each line's OWN path stays below 2^32 bp.  When
-                    // some node of the pass is that long, the same prefix sum over the lengths >> 6 (at most 2^25 each: no wrap over 64
-                    // lanes) bounds every line's total from above: (sum of len >> 6) + nodes < 2^26  =>  path < 2^32.  A sub-pass of a
-                    // line of > 64 nodes keeps the old rule (its running total is checked for wrapping ONCE per sub-pass).
-                    const wmask big = live_m & m_ge(lbp, 1u << 25);
-                    if (RARELY(big)) {
-                        if (RARELY(lsub)) bad |= big;
-                        else {
-                            const uint32_t l6 = live ? (lbp >> 6) + 1u : 0u, s6 = wave_incl_scan(l6);
-                            const uint32_t first6 = (uint32_t)__shfl((int)(s6 - l6), (int)lnb);
-                            const uint32_t last6 = (uint32_t)__shfl((int)s6, (int)(lane + (lk ? lk - 1u - j : 0u)));
-                            bad |= live_m & m_ge(last6 - first6, 1u << 26);
+                    wmask big = live_m & m_ge(lbp, 1u << 25);
+                    if (RARELY(bad | big)) {
+#ifndef SVJG_NO_VLONG
+                        {
+                            const wmask vl_m = bad & m_le(len - (4u * NAME_WORDS + 1u), NAME_MAX_BYTES - 4u * NAME_WORDS - 1u);
+                            if (vl_m != 0ull && g.name_pfx != nullptr) {
+                                const bool vl = in_mask(vl_m);
+                                const uint32_t a1 = vl ? na0 + len - 4u * NAME_WORDS : na0;     // (the others: an address inside the staged text)
+                                // The twelve window words of the last 48 bytes are those bytes' words in the order 0..5, 10, 11, 6..9 (svjg_line.h:
+                                // name_windows with len = 48), so hash and compare walk the staged text word by word — one temporary each, the
+                                // record goes into the pass's own r0..r3 (a lane without a record holds nothing there): no scratch memory.
+                                const u32_any *sw = (const u32_any *)(text + a1);
+                                const u32_any *pwd = (const u32_any *)(text + na0);
+                                const int32_t npre = vl ? (int32_t)(len - 4u * NAME_WORDS) : 1;       // bytes in front of the last 48
+                                auto pword = [&](int32_t i) -> uint32_t { const int32_t k = npre - 4 * i; return k >= 4 ? pwd[i] : k <= 0 ? 0u : (pwd[i] & ((1u << (8 * k)) - 1u)); };
+                                uint64_t hh = (uint64_t)len * 0x7FEB352Du;
+                                hh += (uint64_t)sw[0] * 0x9E3779B1u; hh += (uint64_t)sw[1] * 0x85EBCA77u; hh += (uint64_t)sw[2] * 0xC2B2AE3Du; hh += (uint64_t)sw[3] * 0x27D4EB2Fu;
+                                hh += (uint64_t)sw[4] * 0x165667B1u; hh += (uint64_t)sw[5] * 0xD3A2646Du; hh += (uint64_t)sw[10] * 0xFD7046C5u; hh += (uint64_t)sw[11] * 0xB55A4F09u;
+                                hh += (uint64_t)sw[6] * 0x94D049BBu; hh += (uint64_t)sw[7] * 0xBF58476Du; hh += (uint64_t)sw[8] * 0x2545F491u; hh += (uint64_t)sw[9] * 0x9FB21C65u;
+                                hh += (uint64_t)pword(0) * 0xA24BAED5u; hh += (uint64_t)pword(1) * 0x9FB21C65u; hh += (uint64_t)pword(2) * 0xE7037ED1u; hh += (uint64_t)pword(3) * 0x8EBC6AF1u;
+                                if (vl) {
+                                    const uint4 *e = (const uint4 *)(g.name_tab + (size_t)name_slot(hh, g.name_disp[name_bucket(hh, g.name_buckets)], g.name_slots) * 16);
+                                    r0 = e[0]; r1 = e[1]; r2 = e[2]; r3 = e[3];
+                                }
+                                uint32_t diff = vl ? ((r1.z & NAME_LEN_MASK) ^ (len - 1u)) : 1u;
+                                diff |= (r0.x ^ sw[0]) | (r0.y ^ sw[1]) | (r0.z ^ sw[2]) | (r0.w ^ sw[3]) | (r1.x ^ sw[4]) | (r1.y ^ sw[5]);
+                                diff |= (r2.x ^ sw[10]) | (r2.y ^ sw[11]) | (r2.z ^ sw[6]) | (r2.w ^ sw[7]) | (r3.x ^ sw[8]) | (r3.y ^ sw[9]);
+                                if (diff == 0u && r1.z != 0xFFFFFFFFu) {
+                                    const uint4 pq = *(const uint4 *)(g.name_pfx + (size_t)(r1.z >> NAME_ID_SHIFT) * NAME_PFX_WORDS);
+                                    diff = (pq.x ^ pword(0)) | (pq.y ^ pword(1)) | (pq.z ^ pword(2)) | (pq.w ^ pword(3));
+                                    if (diff == 0u && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) {
+                                        id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = r1.w >> 31;
+                                        h = hh;                              // (the hash the link table is asked with; r3.zw is the name's one inline link)
+                                    }
+                                }
+                                bad = live_m & m_eq(id, NONE32);
+                                big = live_m & m_ge(lbp, 1u << 25);
+                            }
                         }
-                    }
-                    if (RARELY(bad)) {
-                        if (in_mask(bad)) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | ((ST_DEFER + DC_NAME) << 24);
-                        wave_sync();
-                        live_m &= m_eq(((const uint32_t *)&RL[ln])[2] >> 24, ST_OK);
-                        live = in_mask(live_m);
+#endif
+#ifdef SVJG_NO_BIG                                                         /* measurement variant: the r05 rule */
+                        bad |= big;
+#else
+                        if (big) {
+                            if (RARELY(lsub)) bad |= big;
+                            else {
+                                const uint32_t l6 = live ? (lbp >> 6) + 1u : 0u, s6 = wave_incl_scan(l6);
+                                const uint32_t first6 = (uint32_t)__shfl((int)(s6 - l6), (int)lnb);
+                                const uint32_t last6 = (uint32_t)__shfl((int)s6, (int)(lane + (lk ? lk - 1u - j : 0u)));
+                                bad |= live_m & m_ge(last6 - first6, 1u << 26);
+                            }
+                        }
+#endif
+                        if (bad) {
+                            if (in_mask(bad)) ((uint32_t *)&RL[ln])[2] = (meta & 0x00FFFFFFu) | ((ST_DEFER + DC_NAME) << 24);
+                            wave_sync();
+                            live_m &= m_eq(((const uint32_t *)&RL[ln])[2] >> 24, ST_OK);
+                            live = in_mask(live_m);
+                        }
                     }
                 }
                 if (!live) { j = 0; lk = 0; lnb = 0; id = NONE32; lbp = 0; }

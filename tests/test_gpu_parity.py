@@ -711,7 +711,7 @@ def test_node_names_of_25_to_64_bytes(ctx, tmp_path):
     lines = open(pre + ".gaf", "rb").read().split(b"\n")[:-1]
     extra = []
     for l in lines:
-        if b">A_scaffold" in l or b"<A_scaffold" in l:
+        if (b">A_scaffold" in l or b"<A_scaffold" in l) and b"." not in l.split(b"\t")[5]:       # (no insertion node: renamed, the reference would miss it in the GFA and die)
             extra.append(l.replace(b"A_scaffold", b"C_scaffold", 1))
             extra.append(l.replace(b"an_assembly", b"an_assembIy", 1))
         if len(extra) > 4000:
