@@ -189,6 +189,9 @@ int svjg_allreduce_counts(svjg_ctx *ctx);
  * communicators from ncclCommInitAll, the same all-reduce issued for every context; n == 1 is allowed (no collective).
  * Both all-reduce forms fail with SVJG_E_OVERFLOW when a per-SV count cannot be represented (>= 2^32). */
 int svjg_comm_init_all(svjg_ctx *const *ctxs, int n);
+/* What went wrong in the last failed svjg_comm_init_all (NUL terminated, at most cap bytes).  That call may run in a thread of its own beside
+ * other calls on the same contexts, so it never writes a context's svjg_last_error. */
+int svjg_comm_error(char *out, uint64_t cap);
 /* Where the fused pass (svjg_run_begin) enqueues its all-reduce: 0 (default) on the compute stream, between this pass's kernels and
  * the next pass's; 1 on the second stream, in front of the pass's genotype kernel (bench.py measures both on a multi-GPU box). */
 int svjg_comm_set_stream(svjg_ctx *ctx, int second_stream);

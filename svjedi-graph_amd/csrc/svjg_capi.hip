@@ -117,7 +117,7 @@ struct svjg_ctx {
         void *d = nullptr;  uint64_t d_cap = 0;  void *h = nullptr;  uint64_t h_cap = 0;  void *h_dev = nullptr;   // h_dev: the pinned block as the device sees it
         unsigned long long *counts = nullptr;  uint64_t counts_cap = 0;   // the pass's own count vector (+ guard words): the next pass may zero its own while this one is genotyped
         hipEvent_t ev[6] = {};  hipEvent_t computed = nullptr, copied = nullptr;
-        uint64_t base_offset = 0;  uint32_t min_support = 0;  double err = 0;  bool had_text = false;
+        uint64_t base_offset = 0;  uint32_t min_support = 0;  double err = 0;  bool had_text = false, slow_end_own = false;
     } run[2];
     int run_head = 0, run_tail = 0, run_inflight = 0;
     int counts_in_slot = -1;                             // >= 0: the newest counts live in that slot's vector, not yet in d_counts (fetch_slot_counts)
@@ -836,6 +836,19 @@ extern "C" int svjg_allreduce_counts(svjg_ctx *c) {
 
 // One process, several GPUs (the drop-in filter-alignments.py): one communicator per context from ncclCommInitAll, then the same
 // all-reduce issued for every context between ncclGroupStart / ncclGroupEnd.  n == 1: only the overflow guard runs.
+// svjg_comm_init_all may run in a thread of its own beside calls on the same contexts (svjg/filter.py: _CommInit), so what goes wrong in it
+// is NOT written into a context's error string (another thread may be writing that): it has a message buffer of its own.
+static std::mutex g_comm_err_mu;
+static std::string g_comm_err;
+static void comm_err_set(const std::string &m) { std::lock_guard<std::mutex> lk(g_comm_err_mu); g_comm_err = m; }
+extern "C" int svjg_comm_error(char *out, uint64_t cap) {
+    if (!out || !cap) return SVJG_E_ARG;
+    std::lock_guard<std::mutex> lk(g_comm_err_mu);
+    const size_t n = g_comm_err.size() < cap - 1 ? g_comm_err.size() : (size_t)cap - 1;
+    memcpy(out, g_comm_err.data(), n); out[n] = 0;
+    return 0;
+}
+
 extern "C" int svjg_comm_init_all(svjg_ctx *const *ctxs, int n) {
     if (!ctxs || n < 1 || n > 64) return SVJG_E_ARG;
     for (int i = 0; i < n; ++i) if (!ctxs[i]) return SVJG_E_ARG;
@@ -844,10 +857,10 @@ extern "C" int svjg_comm_init_all(svjg_ctx *const *ctxs, int n) {
     ncclComm_t comms[64];
     for (int i = 0; i < n; ++i) {
         devs[i] = ctxs[i]->device;
-        for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) { ctxs[0]->err = "svjg_comm_init_all: one context per device"; return SVJG_E_ARG; }
+        for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) { comm_err_set("svjg_comm_init_all: one context per device"); return SVJG_E_ARG; }
     }
     ncclResult_t r = ncclCommInitAll(comms, n, devs);
-    if (r != ncclSuccess) { ctxs[0]->err = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return SVJG_E_RCCL; }
+    if (r != ncclSuccess) { comm_err_set(std::string("ncclCommInitAll: ") + ncclGetErrorString(r)); return SVJG_E_RCCL; }
     for (int i = 0; i < n; ++i) {
         if (ctxs[i]->comm) ncclCommDestroy(ctxs[i]->comm);
         ctxs[i]->comm = comms[i];
@@ -1122,7 +1135,13 @@ extern "C" int svjg_run_begin(svjg_ctx *c, uint64_t base_offset, uint32_t min_su
         HIPCHK(c, hipMemcpyAsync(base + L.guard, r.counts + c->n_slots, GUARD_WORDS * 8, hipMemcpyDeviceToDevice, st));
         return 0;
     };
-    if (c->comm && !allreduce_second && (rc = reduce_on(c->stream))) return rc;
+    r.slow_end_own = false;
+    if (c->comm && !allreduce_second) {
+        // (the exact-path kernels' interval must not hold the collective: under a communicator it gets an end event of its own — 6 us of a
+        //  multi-GPU pass, none of a one-GPU pass, whose interval `computed` ends)
+        if (r.had_text) { HIPCHK(c, hipEventRecord(r.ev[2], c->stream)); r.slow_end_own = true; }
+        if ((rc = reduce_on(c->stream))) return rc;
+    }
     HIPCHK(c, hipEventRecord(r.computed, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, r.computed, 0));
     if (c->comm && allreduce_second && (rc = reduce_on(c->copy_stream))) return rc;
@@ -1165,7 +1184,7 @@ extern "C" int svjg_run_end(svjg_ctx *c, const uint8_t **gt, const int32_t **pl,
     c->ms_slow = 0;
     if (r.had_text) {
         HIPCHK(c, hipEventElapsedTime(&c->ms_main, r.ev[0], r.ev[1]));
-        if (c->hs().n_deferred) HIPCHK(c, hipEventElapsedTime(&c->ms_slow, r.ev[1], r.computed));   // (under a communicator with the all-reduce on the compute stream: the guard kernel and the all-reduce are in it)
+        if (c->hs().n_deferred) HIPCHK(c, hipEventElapsedTime(&c->ms_slow, r.ev[1], r.slow_end_own ? r.ev[2] : r.computed));   // (the exact-path kernels alone: never the all-reduce)
     }
     if (n_rows) HIPCHK(c, hipEventElapsedTime(&c->ms_geno, r.ev[4], r.ev[5]));
     bool again = false;

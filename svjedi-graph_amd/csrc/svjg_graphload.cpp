@@ -22,6 +22,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -398,6 +399,14 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
             // meets one of Y's colons — Cx is a suffix of what stands in front of that colon, Tx a prefix of what follows it.  For every Y
             // and every colon of Y: the contigs that end there x the prefixes behind it that spell a tail (digits, '-' or '.', digits).
             std::string cand;
+            // (r06: the contigs that END at a colon are looked up by their distinct lengths in a set — thousands of contigs x every colon of
+            //  every node name was seconds here and minutes in the Python loader for an analysis set)
+            std::unordered_set<std::string> cset;
+            std::vector<uint32_t> clens;
+            for (auto &c : chroms) { cset.emplace((const char *)c.p, c.n); clens.push_back(c.n); }
+            std::sort(clens.begin(), clens.end());
+            clens.erase(std::unique(clens.begin(), clens.end()), clens.end());
+            std::string probe;
             for (uint32_t y = 0; y < n_nodes; ++y) {
                 const Str Y = info[y].name;
                 for (uint32_t c = 0; c < Y.n; ++c) {
@@ -406,8 +415,11 @@ extern "C" int svjg_graph_load(const char *edges_json, const char *gfa_path, svj
                     uint32_t i = 0;
                     while (i < rn && rest[i] >= '0' && rest[i] <= '9') ++i;
                     if (i == 0 || i >= rn || (rest[i] != '-' && rest[i] != '.')) continue;
-                    for (auto &cx : chroms) {
-                        if (cx.n > c || memcmp(Y.p + c - cx.n, cx.p, cx.n)) continue;
+                    for (const uint32_t cn : clens) {
+                        if (cn > c) break;
+                        probe.assign((const char *)Y.p + c - cn, cn);
+                        if (!cset.count(probe)) continue;
+                        const Str cx{Y.p + c - cn, cn};
                         for (uint32_t j = i + 1; j < rn && rest[j] >= '0' && rest[j] <= '9'; ++j) {
                             cand.assign((const char *)cx.p, cx.n); cand.push_back(':'); cand.append((const char *)rest, j + 1);
                             const Str X{(const uint8_t *)cand.data(), (uint32_t)cand.size()};

@@ -76,6 +76,7 @@ _SIGS = {
     "svjg_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "svjg_allreduce_counts": (ctypes.c_int, [ctypes.c_void_p]),
     "svjg_comm_init_all": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    "svjg_comm_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64]),
     "svjg_allreduce_counts_all": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "svjg_genotype": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
                                      ctypes.c_uint32, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -537,7 +538,11 @@ def _handles(ctxs):
 
 def comm_init_all(ctxs):
     """One process, one Context per GPU: RCCL communicators for all of them (ncclCommInitAll inside the library)."""
-    ctxs[0]._chk(ctxs[0].lib.svjg_comm_init_all(_handles(ctxs), len(ctxs)))
+    rc = ctxs[0].lib.svjg_comm_init_all(_handles(ctxs), len(ctxs))
+    if rc:                                                       # (its own message buffer: the call may run beside others on these contexts)
+        buf = ctypes.create_string_buffer(512)
+        ctxs[0].lib.svjg_comm_error(buf, 512)
+        raise SvjgError(f"libsvjg_hip error {rc}: {buf.value.decode(errors='replace')}")
 
 
 def allreduce_counts_all(ctxs):

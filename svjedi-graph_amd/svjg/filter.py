@@ -31,11 +31,49 @@ def output_names(prefix, output_dir=None):
 
 
 CHUNK_BYTES = 1 << 30          # GAF bytes uploaded and classified per call (bounds device memory for the text)
-# A further GPU must save more than its communicator costs: ncclCommInitRank / ncclCommInitAll takes ~5.6 s (measured for one rank on the
-# one-GPU box, tools/rccl_probe.py; it runs beside upload + classify, which hides only as much of it as they last), and one GPU takes a file
-# in at ~8 GB/s (21.6 GB in 2.7 s, profiles/r05/experiments/ingest_record_buffer.txt): below ~32 GB of text per GPU a second GPU makes the run
-# LONGER.  (r04: 64 MB — on an eight-GPU node the 2.1 GB of configs[2] would have been cut eight ways.)  SVJG_DEVICES=all | 0,1,... overrides.
-MIN_BYTES_PER_DEVICE = 32 << 30
+# A further GPU must save more than its communicators cost.  One GPU takes a file in at ~5.7 GB/s end to end (upload + classify beside the
+# parts that do not shard), and creating the communicators (ncclCommInitAll) takes seconds — 5.6 s measured for ONE rank on the one-GPU box
+# (tools/rccl_probe.py; profiles/r06/rccl_probe.txt); nobody has measured eight.  So the threshold is not a constant but
+#     min_bytes_per_device() = rccl_init_s() x INGEST_BYTES_PER_S
+# with rccl_init_s() = SVJG_RCCL_INIT_S if set, else what the first multi-GPU run of this user measured and left in
+# ~/.cache/svjg/rccl_init_s (classify_sharded writes it), else 5.6: 32 GB per GPU.  BASELINE configs[3] (21.6 GB) therefore takes ONE GPU of
+# an eight-GPU node by default — measured sensible on one GPU (the JSON writer bounds that run at 20 of 28 s), unknown on eight.
+# SVJG_DEVICES=all | 0,1,... overrides.  (r04: 64 MB — on an eight-GPU node the 2.1 GB of configs[2] would have been cut eight ways.)
+INGEST_BYTES_PER_S = 5.7e9
+RCCL_INIT_S_DEFAULT = 5.6
+
+
+def _rccl_init_file():
+    return os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "svjg", "rccl_init_s")
+
+
+def rccl_init_s():
+    """seconds ncclCommInitAll takes on this machine: the environment's word, else the last measurement, else the one-rank figure"""
+    for src in (lambda: os.environ["SVJG_RCCL_INIT_S"], lambda: open(_rccl_init_file()).read()):
+        try:
+            v = float(src().split()[0])
+            if 0.0 <= v < 3600.0:
+                return v
+        except (KeyError, OSError, ValueError, IndexError):
+            pass
+    return RCCL_INIT_S_DEFAULT
+
+
+def note_rccl_init_s(seconds, n_ranks):
+    """what a multi-GPU run measured (best effort: a read-only home changes nothing)"""
+    try:
+        os.makedirs(os.path.dirname(_rccl_init_file()), exist_ok=True)
+        with open(_rccl_init_file(), "w") as fh:
+            fh.write(f"{seconds:.3f} {n_ranks} ranks, ncclCommInitAll\n")
+    except OSError:
+        pass
+
+
+def min_bytes_per_device():
+    return max(64 << 20, int(rccl_init_s() * INGEST_BYTES_PER_S))
+
+
+MIN_BYTES_PER_DEVICE = int(RCCL_INIT_S_DEFAULT * INGEST_BYTES_PER_S)          # (the default's value, 32 GB: documentation and tests)
 
 
 def read_gaf(path):
@@ -267,8 +305,8 @@ def _stamp(t, what):
 
 def pick_devices(n_bytes, device=None):
     """GPUs the alignments are sharded over.  SVJG_DEVICES = "all" | comma-separated indices (an index may repeat: two
-    shards on one GPU, used by the tests); unset: as many of the visible GPUs as get at least MIN_BYTES_PER_DEVICE of text each (one GPU
-    for anything below 64 GB: see there)."""
+    shards on one GPU, used by the tests); unset: as many of the visible GPUs as get at least min_bytes_per_device() of text each (with
+    the default communicator time: one GPU for anything below 64 GB — see there)."""
     if device is not None:
         return [device]
     spec = os.environ.get("SVJG_DEVICES", "").strip()
@@ -277,7 +315,7 @@ def pick_devices(n_bytes, device=None):
         return [int(x) for x in spec.split(",") if x.strip() != ""]
     if spec == "all":
         return list(range(n_vis))
-    return list(range(max(1, min(n_vis, n_bytes // MIN_BYTES_PER_DEVICE))))
+    return list(range(max(1, min(n_vis, n_bytes // min_bytes_per_device()))))
 
 
 def _classify_on_device(ctx, graph, data, ranges, want_hits, out, r, path=None):
@@ -317,8 +355,9 @@ class _CommInit(threading.Thread):
             self.error = e
         self.seconds = time.perf_counter() - t
 
-    def join_or_raise(self):
-        self.join()
+    def join_or_raise(self, started=True):
+        if started:
+            self.join()
         if self.error is not None:
             raise self.error
         return self.seconds
@@ -360,13 +399,25 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
     distinct = list(dict.fromkeys(devs))
     ranges = {d: [(cuts[r], cuts[r + 1]) for r, x in enumerate(devs) if x == d] for d in distinct}
     ctxs = []
+    comm = None
     try:
         for d in distinct:
             ctxs.append(capi.Context(d))
-        comm = None
-        if len(ctxs) > 1:                          # the communicators come to be beside upload + classify, not behind them
+        if len(ctxs) > 1:
+            # The communicators: by default created HERE, before any context uploads or classifies (seconds on the critical path of a
+            # multi-GPU run, which pick_devices only chooses for >= 32 GB a GPU).  SVJG_COMM_OVERLAP=1 creates them in a thread of its own
+            # beside upload + classify instead — measured with stand-in contexts only (tests/test_comm_overlap.py): ncclCommInitAll beside
+            # hipMalloc / hipFree / kernel launches on the same devices has never run on hardware, so it stays opt-in until it has.
             comm = _CommInit(ctxs)
-            comm.start()
+            if os.environ.get("SVJG_COMM_OVERLAP"):
+                comm.start()
+            else:
+                comm.run()
+                t_init = comm.join_or_raise(started=False)
+                note_rccl_init_s(t_init, len(ctxs))
+                if os.environ.get("SVJG_VERBOSE"):
+                    sys.stderr.write(f"[svjg] RCCL communicators for {len(ctxs)} GPUs (ncclCommInitAll): {t_init:.2f} s, in front of upload + classify\n")
+                comm = None
         errs = [None] * len(distinct)
         if len(distinct) == 1:
             _classify_on_device(ctxs[0], graph, data, ranges[distinct[0]], want_hits, errs, 0, gaf_path)
@@ -393,6 +444,7 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
         if comm is not None:
             t_wait = time.perf_counter()
             t_init = comm.join_or_raise()
+            note_rccl_init_s(t_init, len(ctxs))
             if os.environ.get("SVJG_VERBOSE"):
                 sys.stderr.write(f"[svjg] RCCL communicators for {len(ctxs)} GPUs (ncclCommInitAll): {t_init:.2f} s beside upload + classify, "
                                  f"{time.perf_counter() - t_wait:.2f} s of it waited for here\n")
@@ -405,7 +457,7 @@ def classify_sharded(graph, gaf_path, want_hits=True, devices=None, _t=None):
         _stamp(t, "count all-reduce, counts + hit records -> host")
         return total, recs, data
     finally:
-        if comm is not None:                       # (an error on the way: the communicator call must have returned before its contexts go)
+        if comm is not None and comm.is_alive():   # (an error on the way: the communicator call must have returned before its contexts go)
             comm.join()
         for c in ctxs:
             c.close()

@@ -217,7 +217,9 @@ class Graph:
         meets one of Y's colons: Cx is a suffix of what stands in front of that colon and Tx a prefix of what follows it.  For every
         Y and every colon of Y: the contigs that end there x the prefixes behind it that spell a tail (digits, '-' or '.', digits)."""
         out = set()
-        for y in info:
+        cset = set(chroms)
+        clens = sorted({len(cx) for cx in chroms})          # (r06: the contigs that END at a colon are looked up by their distinct lengths —
+        for y in info:                                       #  thousands of contigs x every colon of every node name was minutes for an analysis set)
             for c in (i for i, ch in enumerate(y) if ch == ":"):
                 head, rest = y[:c], y[c + 1:]
                 i = 0
@@ -230,8 +232,11 @@ class Graph:
                 while j < len(rest) and rest[j].isdigit() and rest[j].isascii():
                     j += 1
                     ends.append(j)
-                for cx in chroms:
-                    if head.endswith(cx):
+                for n in clens:
+                    if n > len(head):
+                        break
+                    cx = head[len(head) - n:]
+                    if cx in cset:
                         for e in ends:
                             x = cx + ":" + rest[:e]
                             if x != y and x in info:

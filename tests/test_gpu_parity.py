@@ -246,7 +246,6 @@ def test_unicode_digit_lines_sharded_and_streamed(golden, tmp_path, monkeypatch)
             continue
         for k, v in json.load(open(f"{u}/{n}.ref.json")).items():
             a = want.setdefault(k, [0, 0]); a[0] += 50 * len(v[0]); a[1] += 50 * len(v[1])
-    monkeypatch.setattr(flt, "MIN_BYTES_PER_DEVICE", 1)
     c1, r1, d1 = flt.classify_sharded(g, str(path), devices=[0, 0, 0])
     assert _counts_dict(g, c1) == want
     c2, r2, d2 = flt.classify_stream(g, io.BytesIO(raw))

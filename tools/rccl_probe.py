@@ -32,6 +32,19 @@ if n > 1:
 else:
     shard.RcclGroup(ctxs[0], 1, 0, lambda uid: uid)
 print(f"init_s: {time.perf_counter() - t_init:.3f} (communicator of {n} rank(s): {'ncclCommInitAll' if n > 1 else 'ncclCommInitRank'})")
+# r06: the call the drop-in filter-alignments.py makes (svjg_comm_init_all = ncclCommInitAll over the process's devices), straight on librccl for
+# the devices of this box — on a one-GPU box a communicator of one rank, which the library itself never creates (n == 1: no collective)
+import ctypes         # noqa: E402
+rccl = ctypes.CDLL("/opt/rocm/lib/librccl.so")
+comms = (ctypes.c_void_p * n)()
+devs = (ctypes.c_int * n)(*range(n))
+rccl.ncclCommInitAll.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+for rep in range(2):
+    t_all = time.perf_counter()
+    rc = rccl.ncclCommInitAll(comms, n, devs)
+    print(f"ncclCommInitAll({n} device(s)) call {rep + 1}: rc {rc}, {time.perf_counter() - t_all:.3f} s")
+    for cm in comms:
+        rccl.ncclCommDestroy(ctypes.c_void_p(cm))
 dt, ms, out = bench.timed_steps(ctxs, 3, 1)
 print("passes ok:", dt, [m[-1] for m in ms])
 import glob, re
