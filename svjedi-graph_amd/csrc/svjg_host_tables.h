@@ -53,8 +53,8 @@ namespace svjg {
 //     bit 1 length unknown; all ones = empty slot)   [7] node length in bp | REC_ROW_INLINE if the node has no other links
 //     than the inline ones
 //     names of up to 24 bytes: [8..15] = four inline links;  25..32 bytes: [8..9] = window words 6, 7, [10..15] = three
-//     inline links;  33..48 bytes (contig names like chr1_KI270706v1_random): [8..13] = window words 6..11, [14..15] = one
-//     inline link.  An inline link = two words: key = right id << 2 | left strand | right strand << 1 (all ones = none),
+//     inline links;  33..40 bytes (contig names like chr1_KI270706v1_random): [8..11] = window words 6..9, [12..15] = two inline links
+//     (r06: one before);  41..64 bytes: [8..13] = window words 6..11, [14..15] = one inline link.  An inline link = two words: key = right id << 2 | left strand | right strand << 1 (all ones = none),
 //     value = the hit (slot << 1 | allele) of a one-hit link, or REC_MANY | index into the inline hit list
 //     (ihits[index] = number of hits, then the hits).  Reference-allele links come first.  Nearly every path step is
 //     answered from the record that the node lookup fetched anyway and never touches the link table.
@@ -77,9 +77,9 @@ inline void name_ent_words(const uint32_t *e, uint32_t d[NAME_WORDS]) {
     for (int w = 0; w < 6; ++w) d[w] = e[w];
     const uint32_t n = name_ent_len(e);
     d[6] = n > 24u ? e[8] : 0u; d[7] = n > 24u ? e[9] : 0u;
-    for (int w = 0; w < 4; ++w) d[8 + w] = n > 32u ? e[10 + w] : 0u;
+    d[8] = n > 32u ? e[10] : 0u; d[9] = n > 32u ? e[11] : 0u; d[10] = n > 40u ? e[12] : 0u; d[11] = n > 40u ? e[13] : 0u;
 }
-inline uint32_t nm_first_link(uint32_t meta) { const uint32_t n = (meta & NAME_LEN_MASK) + 1u; return n > 32u ? 14u : n > 24u ? 10u : 8u; }   // word of the first inline link
+inline uint32_t nm_first_link(uint32_t meta) { const uint32_t n = (meta & NAME_LEN_MASK) + 1u; return n > 40u ? 14u : n > 32u ? 12u : n > 24u ? 10u : 8u; }   // word of the first inline link
 inline uint32_t rec_first_link(const uint32_t *e) { return nm_first_link(e[6]); }
 
 struct KernelTables {
@@ -266,7 +266,8 @@ inline KernelTables build_kernel_tables(const svjg_graph &g) {
             e[6] = src[NAME_WORDS]; e[7] = src[NAME_WORDS + 1];
             const uint32_t w0 = nm_first_link(src[NAME_WORDS]);
             if (w0 >= 10u) { e[8] = src[6]; e[9] = src[7]; }
-            if (w0 >= 14u) { e[10] = src[8]; e[11] = src[9]; e[12] = src[10]; e[13] = src[11]; }
+            if (w0 >= 12u) { e[10] = src[8]; e[11] = src[9]; }
+            if (w0 >= 14u) { e[12] = src[10]; e[13] = src[11]; }
             const uint32_t node = key_node[k];
             node_pre[node] = hs[k]; node_has[node] = 1; node_slot[node] = slot_of[k];
             // inline links: up to two rows of the node, those whose hits are all reference-allele first

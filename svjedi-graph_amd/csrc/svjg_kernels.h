@@ -223,10 +223,10 @@ __device__ inline uint64_t name_words_tail(const uint8_t *text, uint32_t a0, uin
 }
 // words 8..11 (names of 33..48 bytes) are not kept in registers while the record travels: they are read from the staged text twice,
 // for the hash and — in the branch only a pass with such a name takes — for the compare
+// (r06: a name of 33..40 bytes has two of them — its bytes [L - 16, L - 8) —, words 10 and 11 are zero: svjg_line.h: name_windows)
 __device__ inline void name_words_far(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t f[4]) {
-    const u32_any *w = (const u32_any *)(text + a0 + (L > 32u ? L - 24u : 0u));
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) f[i] = L > 32u ? w[i] : 0u;
+    const u32_any *w = (const u32_any *)(text + a0 + (L > 40u ? L - 24u : L > 32u ? L - 16u : 0u));
+    f[0] = L > 32u ? w[0] : 0u; f[1] = L > 32u ? w[1] : 0u; f[2] = L > 40u ? w[2] : 0u; f[3] = L > 40u ? w[3] : 0u;
 }
 // the first L - 48 bytes of a name of 49..64 bytes as four words, zero behind them (svjg_line.h: name_prefix_words), from the staged text
 __device__ inline void name_prefix_lds(const uint8_t *text, uint32_t a0, uint32_t L, uint32_t p[NAME_PFX_WORDS]) {
@@ -453,6 +453,38 @@ constexpr int P_B2 = SVJG_P_B2, P_R1 = SVJG_P_R1, P_LOAD = SVJG_P_LOAD, P_REST =
 #endif
 __device__ inline unsigned long long low_bits64(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
 __device__ inline uint32_t clamp64(uint32_t hi, uint32_t lo) { return hi > lo ? (hi - lo < 64u ? hi - lo : 64u) : 0u; }   // min(max(hi - lo, 0), 64)
+
+// r06 — may a node come twice in a line of K > 64 nodes (K <= KLONG)?  ids[0, K) = the line's node ids (low 24 bits) in path order, in the
+// words of LDS where the tab bitmap was; the words behind them, up to word 256, are free: a bitmap of B = 32 * nb bits there (nb = 128 / 64 / 32
+// words for K <= 128 / 192 / 216), bit (id mod M) per node, set with an LDS atomic OR that returns what was there.  No bit met twice => no id
+// twice (exact).  A bit met twice => maybe: two ids a multiple of M apart look alike.  The ids follow the genome, so the nodes of one stretch of
+// a path fall on neighbouring bits (an inversion walks its stretch backwards: still distinct bits), and only stretches on different contigs —
+// a line that follows a breakend — can fall on each other, which with a few such stretches happens for about a third of those lines.  So the
+// question is asked again with another modulus (B, then 15/16, 14/16 ... 9/16 of it: the stretches then lie differently) — a line that really
+// comes back to a node is caught by every one of them, a line that does not is let go by the first that tells its stretches apart — and only
+// what all eight flag takes the caller's full search, which is exact.  One call per long line, ~30 instructions a try, two tries on average.
+__device__ inline bool long_line_may_repeat(uint32_t *ids, uint32_t K, uint32_t lane) {
+    const uint32_t nb = K <= 128u ? 128u : K <= 192u ? 64u : 32u, B = nb * 32u;
+    uint32_t *bm = ids + 256u - nb;
+    for (uint32_t t = 0; t < 8u; ++t) {
+        const uint32_t M = B - t * (B >> 4) - (t ? 2u * t + 1u : 0u);        // 2048, 1917, 1787, 1657, 1527, 1397, 1267, 1137 (B = 2048)
+        const uint32_t inv = 0xFFFFFFFFu / M;
+        bm[lane & (nb - 1u)] = 0u;
+        if (nb > 64u) bm[64u + lane] = 0u;
+        wave_sync();
+        uint32_t twice = 0u;
+        for (uint32_t m = lane; m < K; m += WG) {
+            const uint32_t x = ids[m] & 0x00FFFFFFu;
+            uint32_t r = x - __umulhi(x, inv) * M;                            // x mod M (the quotient is at most one short)
+            if (r >= M) r -= M;
+            const uint32_t was = __hip_atomic_fetch_or(&bm[r >> 5], 1u << (r & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            twice |= (was >> (r & 31u)) & 1u;
+        }
+        if (ballot64(twice != 0u) == 0ull) return false;
+        wave_sync();
+    }
+    return true;
+}
 
 __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1009,7 +1041,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 uint32_t row_inline = 0;
                 // id << 8 | flags << 6 | byte length - 1, length in bp; hazard-prone name / unknown alt length: exact path
                 bool same = probe && name_match(r0, r1, r2, d, len);
-                if (RARELY(long_names)) { uint32_t f[4]; name_words_far(text, na0, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (r3.x ^ f[2]) | (r3.y ^ f[3])) == 0u); }
+                if (RARELY(long_names)) { uint32_t f[4]; name_words_far(text, na0, plen, f); same = same && (len <= 32u || ((r2.z ^ f[0]) | (r2.w ^ f[1]) | (len > 40u ? (r3.x ^ f[2]) | (r3.y ^ f[3]) : 0u)) == 0u); }
                 if (same && r1.z != 0xFFFFFFFFu && !(r1.z & (NAME_FLAG_HAZARD | NAME_FLAG_NOLEN))) { id = r1.z >> NAME_ID_SHIFT; lbp = r1.w & 0x7FFFFFFFu; row_inline = r1.w >> 31; }
                 // an unknown node, or one so long that 64 of them could overflow the 32-bit path sums: the line takes the exact
                 // path.  The lanes that see it say so in the line's record, and every lane of the pass reads its line's record again
@@ -1111,40 +1143,27 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                 const uint32_t idl = id, idr = nxv >> 1;
                 uint32_t f = lane;
                 const uint32_t dir = idr > id ? 1u : idr < id ? 2u : 0u;
-                bool l_dup = false, l_fail = false;
+                bool l_fail = false;
                 if (RARELY(lsub)) {
                     // -- a sub-pass of a long line: the path's length in front of it comes from the sub-passes before; the first sweep counts
-                    //    as it goes while no name has come twice (below), else it only measures (total length, is every name known) and a
-                    //    second sweep counts --
+                    //    as it goes (its hits wait in the log), and asks ONCE, at the line's last node, whether a name has come twice (below) --
                     pre = gsum + lS; tot = lTOT;
                     l_fail = lS + rdlane(gsum, n_pass - 1u) < lS;        // (a path of 4 Gbp and more: the sums here are 32 bits wide)
                     if (!(lsub & L_SWEEP1)) {
-                        // Does a name come twice?  While the ids rise (or fall) all the way, no.  Once they turn, every node is held against
-                        // the nodes of the sub-passes before it (their ids wait where the tab bitmap was: the line phase is over) and, further
-                        // down, against those of its own sub-pass (the search every pass has for lines whose ids turn).  lD0: 1 / 2 the ids
-                        // rise / fall, 3 they turn, 4 a name comes twice (sweep 1 then looks every first occurrence up).
-                        const uint32_t t63 = lP;
-                        uint32_t *IDS = tbm;
-                        if (t63 == 0u) SET_D0(rdlane(dir, 0));
-                        if (lD0 < 3u && (step_m & (m_ne(dir, lD0) | m_eq(dir, 0u))) != 0ull) SET_D0(3u);
+                        // every node's id and orientation (where the tab bitmap was: the line phase is over) and the path length behind it (the
+                        // worker's words of global memory): what the question at the line's end, and a second sweep, look at
                         if (live) {
-                            IDS[t63 + lane] = id | (oribit << 31);
-                            __hip_atomic_store(a.long_pre + (size_t)blockIdx.x * LONG_WORDS + t63 + lane, pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        if (lD0 == 3u && !DIAG(64u)) {                    // (DIAG 64, measurement only: no search for names that come twice — wrong counts where one does)
-                            wave_sync();
-                            wmask d = 0;
-                            for (uint32_t m = 0; m < t63; ++m) d |= m_eq(id, IDS[m] & 0x00FFFFFFu);
-                            l_dup = (d & live_m) != 0ull;
+                            tbm[lP + lane] = id | (oribit << 31);
+                            __hip_atomic_store(a.long_pre + (size_t)blockIdx.x * LONG_WORDS + lP + lane, pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 }
                 {
                     const uint32_t dprev = lane_below(dir);
                     const wmask oddm = step_m & (m_eq(dir, 0u) | (m_ge(j, 1u) & m_ne(dir, dprev)));
-                    if (RARELY(oddm) && !DIAG(64u)) {
-                        // the lanes of the lines that have such a step (a sub-pass of a long line: every lane is that line's)
-                        const wmask search_m = live_m & (RARELY(lsub) ? ~0ull : ballot64(((low_bits64(lk) << lnb) & oddm) != 0ull));
+                    if (RARELY(oddm) && !RARELY(lsub) && !DIAG(256u)) {      // (a long line: r06, see long_line_may_repeat; DIAG 256, measurement only: no search at all)
+                        // the lanes of the lines that have such a step
+                        const wmask search_m = live_m & ballot64(((low_bits64(lk) << lnb) & oddm) != 0ull);
                         const bool search = in_mask(search_m);
                         const uint32_t key = search ? (id | (ln << 26)) : NONE32;
                         const uint32_t jl = j < lane ? j : lane;             // nodes of the line below this lane, in this pass
@@ -1172,13 +1191,20 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                         ++i0; lsub = 0;
                         continue;
                     }
-                    if (revisits || l_dup) SET_D0(4u);
-                    if (!(lsub & L_MEASURE) && lD0 < 4u) {          // (3: the ids turn, but every node so far has been held against all nodes before it)
+                    // r06 — does a name come twice?  Asked ONCE, when the line's last node is known, of a bitmap of the ids (long_line_may_repeat)
+                    // instead of every node of every sub-pass searching all nodes in front of it (0.32 of the long-read block's 1.89 ms:
+                    // profiles/r06/experiments/long_read_block.txt).  Until then the sweep takes every name for a first occurrence; its hits
+                    // wait in the log anyway.  If one may come twice, nothing of that stays (lR = 0) and the second sweep counts every link with
+                    // every first occurrence looked up (lD0 = 4).
+                    if (lsub & L_FINAL) {
+                        wave_sync();                                     // (the ids of this sub-pass are in LDS)
+                        if (long_line_may_repeat(tbm, rdlane(kall, i0), lane)) { SET_D0(4u); lsub |= L_MEASURE; SET_R(0u); }
+                    }
+                    if (!(lsub & L_MEASURE)) {
                         tally(12, 1);
                         lsub |= L_ONE;
                         tot = lS + rdlane(gsum, n_pass - 1u);
                     } else {
-                        if (!(lsub & L_MEASURE)) { lsub |= L_MEASURE; SET_R(lP); }
                         tally(13, 1);
                         if (lsub & L_FINAL) { lTOT = lS + rdlane(gsum, n_pass - 1u); lS = 0; lsub = (lsub & 0xFF0070u) | 1u | L_SWEEP1; }   // (the second sweep begins at the line's first node; lR and lD0 stay; what the first sweep has found — links [0, lR) — waits in the log until the second is through)
                         else { lS += rdlane(gsum, n_pass - 2u); SET_P(lP + n_pass - 1u); }
@@ -1238,8 +1264,8 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     if (!(lsub & L_FINAL)) { lS += rdlane(gsum, adv - 1u); SET_P(lP + adv); }   // (nothing below looks at lS or lP again)
                 }
                 const uint32_t want = (idr << 2) | orl | (orr << 1);
-                const wmask le24 = m_le(len, 24u), le32 = m_le(len, 32u);   // (a longer name's bytes sit where the first links would)
-                const wmask m0 = le24 & m_eq(r2.x, want), m1 = le32 & m_eq(r2.z, want), m2 = le32 & m_eq(r3.x, want), m3 = m_eq(r3.z, want);
+                const wmask le24 = m_le(len, 24u), le32 = m_le(len, 32u), le40 = m_le(len, 40u);   // (a longer name's bytes sit where the first links would)
+                const wmask m0 = le24 & m_eq(r2.x, want), m1 = le32 & m_eq(r2.z, want), m2 = le40 & m_eq(r3.x, want), m3 = m_eq(r3.z, want);
                 const wmask inl = m0 | m1 | m2 | m3;
                 const uint32_t v = in_mask(m0) ? r2.y : in_mask(m1) ? r2.w : in_mask(m2) ? r3.y : r3.w;
                 const wmask found_m = go_m & ~moved_m & inl;
@@ -1252,7 +1278,7 @@ __global__ __launch_bounds__(WG, SVJG_MINW) void k_classify_main(ClassifyArgs a)
                     const wmask many = found_m & m_ge(v, 0x80000000u);   // (wave-uniform: a link with several hits)
                     if (RARELY(many)) { if (in_mask(many)) { hp = g.name_ihits + (v & 0x7FFFFFFFu) + 1; nh = hp[-1] | 0x80000000u; } }
                 }
-                if (RARELY(ask_m)) {
+                if (RARELY(ask_m) && !DIAG(512u)) {                       // (DIAG 512, measurement only: the link table is never asked)
                     const uint64_t hl = h;                               // (the first occurrence spells the same name)
                     const uint64_t hr = ((uint64_t)lane_above((uint32_t)(h >> 32)) << 32) | lane_above((uint32_t)h);
                     if (ask) {

@@ -75,7 +75,9 @@ struct GraphView {
 // pass's instructions.  For a name of len bytes, o2 = min(max(len - 8, 0), 16) and o1 = o2 / 2:
 //     d[0..1] = bytes [0, 8)      d[2..3] = bytes [o1, o1 + 8)      d[4..5] = bytes [o2, o2 + 8)          (they cover a name of 8..24 bytes)
 //     d[6..7] = bytes [len - 8, len) if len > 24, else 0                                        (.. of 25..32 bytes)
-//     d[8..11] = bytes [len - 24, len - 8) if len > 32, else 0                                  (.. of 33..48 bytes)
+//     d[8..11] = bytes [len - 24, len - 8) if len > 40                                          (.. of 41..48 bytes)
+//     d[8..9]  = bytes [len - 16, len - 8), d[10..11] = 0 if 32 < len <= 40                     (.. of 33..40 bytes: r06 — two words fewer in the
+//                record, i.e. room for a second inline link: GRCh38's chr1_KI270706v1_random:1234567-1234999 has 38 bytes)
 // Only a name shorter than 8 bytes has bytes behind its end in a window (all three are [0, 8) then): those read as zero.
 // (windows, len) determine the name, so comparing them is comparing the spelling.
 SVJG_HD uint32_t fmix32(uint32_t z) { z ^= z >> 16; z *= 0x7FEB352Du; z ^= z >> 15; z *= 0x846CA68Bu; z ^= z >> 16; return z; }
@@ -93,7 +95,8 @@ SVJG_HD void name_windows(P t, uint64_t s, uint32_t len, uint32_t d[NAME_WORDS])
     };
     d[0] = word(0); d[1] = word(4); d[2] = word(o1); d[3] = word(o1 + 4); d[4] = word(o2); d[5] = word(o2 + 4);
     d[6] = len > 24u ? word(len - 8u) : 0u; d[7] = len > 24u ? word(len - 4u) : 0u;
-    for (uint32_t i = 0; i < 4; ++i) d[8 + i] = len > 32u ? word(len - 24u + 4u * i) : 0u;
+    if (len > 40u) for (uint32_t i = 0; i < 4; ++i) d[8 + i] = word(len - 24u + 4u * i);
+    else { d[8] = len > 32u ? word(len - 16u) : 0u; d[9] = len > 32u ? word(len - 12u) : 0u; d[10] = 0u; d[11] = 0u; }
 }
 // r06 — names of 49..64 bytes (contigs named like assemblies name their scaffolds): the twelve window words are those of the name's LAST 48
 // bytes, and its first len - 48 bytes (at most 16: four words, zero behind them) wait in a table of their own, four words per node id
@@ -357,7 +360,7 @@ SVJG_HD void name_windows_inline(P t, uint64_t s, uint32_t len, uint32_t d[NAME_
     d[0] = (uint32_t)w0; d[1] = (uint32_t)(w0 >> 32); d[2] = (uint32_t)w1; d[3] = (uint32_t)(w1 >> 32); d[4] = (uint32_t)w2; d[5] = (uint32_t)(w2 >> 32);
     const uint64_t w3 = len > 24u ? ld64(t, s + len - 8u) : 0ull;
     d[6] = (uint32_t)w3; d[7] = (uint32_t)(w3 >> 32);
-    const uint64_t w4 = len > 32u ? ld64(t, s + len - 24u) : 0ull, w5 = len > 32u ? ld64(t, s + len - 16u) : 0ull;
+    const uint64_t w4 = len > 40u ? ld64(t, s + len - 24u) : len > 32u ? ld64(t, s + len - 16u) : 0ull, w5 = len > 40u ? ld64(t, s + len - 16u) : 0ull;
     d[8] = (uint32_t)w4; d[9] = (uint32_t)(w4 >> 32); d[10] = (uint32_t)w5; d[11] = (uint32_t)(w5 >> 32);
 }
 
@@ -381,8 +384,8 @@ SVJG_HD uint32_t name_tab_find(const GraphView &g, P t, NameRef nm, int64_t *len
         const w4 c = e[2];
         if (c[0] != d[6] || c[1] != d[7]) return NONE32;
         if (len > 32u) {
-            const w4 f = e[3];
-            if (c[2] != d[8] || c[3] != d[9] || f[0] != d[10] || f[1] != d[11]) return NONE32;
+            if (c[2] != d[8] || c[3] != d[9]) return NONE32;
+            if (len > 40u) { const w4 f = e[3]; if (f[0] != d[10] || f[1] != d[11]) return NONE32; }   // (33..40 bytes: those two words hold a link)
         }
     }
     if (len_bp) *len_bp = (meta & NAME_FLAG_NOLEN) ? -1 : (int64_t)(b[3] & 0x7FFFFFFFu);      // (record word 7: length in bp | "no other links" << 31)
