@@ -42,6 +42,21 @@ WORKLOADS = {
 }
 
 
+def _git_head():
+    """the commit this tree was taken from: .git here, or — on a GPU box, which gets no .git — what the caller left in tools/_build/git_head"""
+    try:
+        import subprocess
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        return open(os.path.join(ROOT, "tools", "_build", "git_head")).read().strip()[:12]
+    except OSError:
+        return None
+
+
 def _passes(c, n, min_support, err, ms):
     """n passes on one context, two in flight: pass k + 1 is enqueued before the results of pass k are waited for, so they cross
     PCIe while the next pass computes (svjg_run_begin / svjg_run_end).  -> the last pass's results"""
@@ -330,7 +345,7 @@ def main():
             "config": {"workload": desc, "alignments_per_gpu": n_aln, "svs": n_sv, "gaf_bytes_per_gpu": gaf_bytes_0,
                        "bytes_per_alignment": round(gaf_bytes_0 / n_aln, 1), "count_slots": graph.n_slots,
                        "graph_nodes": graph.n_nodes, "vcf_rows": int(len(rows.sv_type)),
-                       "untimed_settle_passes_before_warmup": n_settle},
+                       "untimed_settle_passes_before_warmup": n_settle, "git": _git_head()},
             # (every rank genotypes ALL rows from the summed counts — 54 B a row, replicated rather than sharded: rows per second of ONE rank's kernel)
             "svs_genotyped_per_s": float(len(rows.sv_type) / (np.mean(geno_ms) * 1e-3)) if np.mean(geno_ms) > 0 else None,
             "genotyped_rows": int((done & 1).sum()),
