@@ -13,6 +13,6 @@ g++ $SAN -pthread -o svjedi-graph_amd/csrc/libsvjg_host.so svjedi-graph_amd/csrc
 g++ $SAN -o tests/hostsim/_hostsim.so tests/hostsim/hostsim.cpp
 touch tests/hostsim/_hostsim.so
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$ASAN python -m pytest -q -p no:cacheprovider \
-    tests/test_json_writer.py tests/test_vcf_native.py tests/test_graph_native.py tests/test_handoff.py tests/test_fuzz_golden.py tests/test_hostsim_parity.py 2>&1 | tee /tmp/svjg_asan.log | tail -3
+    tests/test_json_writer.py tests/test_vcf_native.py tests/test_graph_native.py tests/test_handoff.py tests/test_fuzz_golden.py tests/test_hostsim_parity.py tests/test_oracle_cross_fuzz.py tests/test_hg002_shape.py 2>&1 | tee /tmp/svjg_asan.log | tail -3
 if grep -q "ERROR: AddressSanitizer\|runtime error" /tmp/svjg_asan.log; then echo "sanitizer findings: see /tmp/svjg_asan.log"; exit 1; fi
 echo "sanitizers: clean"
