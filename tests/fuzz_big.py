@@ -45,6 +45,8 @@ for _ in range(n_mut):
     try:
         orc.filter(m, want_hits=False)
         good.append(m if m.endswith((b"\n", b"\r")) else m + b"\n")
+    except OC.Undecided:
+        continue                                   # (a number beyond what the C restatement holds: the Python oracle's business, tests/test_oracle_cross_fuzz.py)
     except Exception as e:
         bad.append((m, type(e).__name__))
 mixed = []

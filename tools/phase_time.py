@@ -9,7 +9,10 @@ import synth
 from svjg import capi
 from svjg.graph import Graph
 tmp = tempfile.mkdtemp(); pre = os.path.join(tmp, "w")
-if len(sys.argv) > 1 and sys.argv[1] == "long":                  # bench.py's long_read block
+if len(sys.argv) > 1 and sys.argv[1] == "hg002":                 # bench.py's hg002_shape block
+    inf = synth.generate_hg002(pre, n_reads=synth.HG002_READS, write_gaf=False, return_gaf=True, threads=16)
+    gaf = inf["gaf"]
+elif len(sys.argv) > 1 and sys.argv[1] == "long":                # bench.py's long_read block
     seed = 20260515 + 9
     inf = synth.generate(pre, 0, 20_000, 8, "mixed", seed, write_gaf=False, chrom_style="ucsc")
     gaf = synth.gaf_bytes(inf["tables"], seed, 0, 3_000_000, threads=16, shape="long")
