@@ -241,8 +241,9 @@ def main():
     elif n_local > 1:
         capi.comm_init_all(ctxs)
         rccl = {"ranks": n_local, "init": "ncclCommInitAll, one process, one thread per GPU", "init_s": round(time.perf_counter() - t_comm, 3)}
-    # (init_s: what creating the communicators cost this rank, unique id's trip included; the drop-in filter-alignments.py makes
-    #  them in a thread of its own beside upload + classify — svjg/filter.py: _CommInit — so that this time is not on its critical path)
+    # (init_s: what creating the communicators cost this rank, unique id's trip included — the first RCCL call of a process pays ~6 s of
+    #  one-time start on the one-GPU box, profiles/r06/rccl_probe.txt; the drop-in filter-alignments.py makes them in front of its first upload,
+    #  or with SVJG_COMM_OVERLAP=1 in a thread of its own beside upload + classify: svjg/filter.py: _CommInit)
 
     outer = dist.barrier if dist is not None else None
 

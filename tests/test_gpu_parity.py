@@ -858,7 +858,9 @@ def test_every_line_with_an_identity_tag(ctx, tmp_path):
 def test_deferral_is_per_line_and_by_cause(ctx, tmp_path):
     """What sends a line to the exact path is that line's business (r03): an id:f: tag defers the lines whose 64-byte spans hold the
     pair "d:", not the stripe; a path of more than 64 nodes only that line; columns with blanks only theirs.  The causes are counted
-    (svjg_get_defer_causes) and add up to n_deferred; counts are the oracle's."""
+    (svjg_get_defer_causes) and add up to n_deferred; counts are the oracle's.  (r06: what no longer defers a line — a node of 2^25 bp and
+    more, a node name of 49..64 bytes — and what still does under `node_name` — a path of 2^32 bp, a name beyond 64 bytes, a name of no node — are
+    test_nodes_of_32_mbp_and_more_stay_in_the_main_kernel and test_node_names_of_25_to_64_bytes.)"""
     pre, gaf, g, orc = _synth_case(tmp_path, 20000, 600, 2, "mixed", 91)
     lines = bytes(gaf).split(b"\n")[:-1]
     rng = np.random.default_rng(5)
