@@ -42,18 +42,43 @@ WORKLOADS = {
 }
 
 
+def _source_digest():
+    """sha256 over the sources a measurement depends on (kernels, C ABI, host libraries, this script)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "svjedi-graph_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "svjedi-graph_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "svjedi-graph_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "include", "svjg.h"), os.path.abspath(__file__)])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def write_git_head():
+    """Where .git is (the build container): tools/_build/git_head = "<commit> <digest of the sources>", for the boxes that get the tree without .git.
+    The commit is only ever reported together with a matching digest, so a stale file cannot name a commit the sources are not."""
+    import subprocess
+    r = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=5)
+    if r.returncode == 0 and r.stdout.strip():
+        dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "svjedi-graph_amd/csrc", "include", "bench.py"], capture_output=True, text=True, timeout=10).stdout.strip()
+        os.makedirs(os.path.join(ROOT, "tools", "_build"), exist_ok=True)
+        with open(os.path.join(ROOT, "tools", "_build", "git_head"), "w") as fh:
+            fh.write(f"{r.stdout.strip()}{'+changes' if dirty else ''} {_source_digest()}\n")
+
+
 def _git_head():
-    """the commit this tree was taken from: .git here, or — on a GPU box, which gets no .git — what the caller left in tools/_build/git_head"""
+    """the commit this tree was taken from: .git here, or — on a GPU box, which gets no .git — what write_git_head() left, if the sources still match it"""
+    import subprocess
     try:
-        import subprocess
-        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5)
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5)
         if r.returncode == 0 and r.stdout.strip():
             return r.stdout.strip()
     except (OSError, subprocess.SubprocessError):
         pass
     try:
-        return open(os.path.join(ROOT, "tools", "_build", "git_head")).read().strip()[:12]
-    except OSError:
+        commit, digest = open(os.path.join(ROOT, "tools", "_build", "git_head")).read().split()[:2]
+        return commit[:12] + commit[40:] if digest == _source_digest() else f"unknown (the sources are not those of {commit[:12]})"
+    except (OSError, ValueError):
         return None
 
 

@@ -2,7 +2,7 @@
 # measurement only: everything profiles/<round>/ holds, in one call on the GPU box, PER WORKLOAD (default: c3 and c4shard = the
 # north_star shard): the bench line, rocprofv3 kernel trace + stats of the same command, FETCH_SIZE / WRITE_SIZE, three SQ counter
 # groups, TCC and GRBM in separate --pmc passes, and traffic.json (one entry per workload) from them.
-#   git rev-parse HEAD > tools/_build/git_head   (the GPU box has no .git: this file names the commit in every output)
+#   python -c "import bench; bench.write_git_head()"   (the GPU box has no .git: tools/_build/git_head names the commit — with a digest of the sources — in every output)
 #   gpurun -- bash tools/profile_round.sh r04 [workloads...] ; then copy the summaries from gpurun_out/r04/ into profiles/r04/
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${1:-profile}; mkdir -p $O
@@ -40,6 +40,6 @@ for W in $WL; do
   rm -rf $P
 done
 bash tools/resource_usage.sh > $O/resource_usage.txt 2>&1 || true
-echo "commit $(cat tools/_build/git_head 2>/dev/null || echo unknown), $(date -u +%FT%TZ): every file of this directory was taken with the library built from it (tools/profile_round.sh $*)" > $O/COMMIT.txt
+echo "commit $(cut -d" " -f1 tools/_build/git_head 2>/dev/null || echo unknown), $(date -u +%FT%TZ): every file of this directory was taken with the library built from it (tools/profile_round.sh $*)" > $O/COMMIT.txt
 python3 tools/mk_traffic.py $O $WL
 ls -la $O
