@@ -1155,8 +1155,32 @@ def make_hg002shape(n_reads=200_000):
            "reference_seconds": {"construct_graph": round(t_construct, 1), "filter": round(t_filter, 2), "genotype": round(t_geno, 2)},
            "graph_built_by": "construct-graph.py of the reference, from the generated VCF + a FASTA of N at GRCh37 lengths"}
     assert h_ref.hexdigest() == h_own.hexdigest()
+    # ... and the WHOLE block of bench.py (30x: synth.HG002_READS lines, 750 MB) through the reference's filter and genotyper: the reference can run
+    # this shape at full size (nine lines in ten are skipped at filter-alignments.py:133-134; ~620 k informative alignments)
+    full_n = synth.HG002_READS
+    gaf_full = synth.gaf_bytes(inf["tables"], synth.HG002_SEED, 0, full_n, threads=8, shape="reads")
+    assert hashlib.sha256(gaf_full[: len(gaf)].tobytes()).hexdigest() == fix["gaf_sha256"]          # (the sample is the stream's head)
+    gaf_full.tofile(pre + ".gaf")
+    t1 = time.time()
+    rc, err = run_ref_filter(pre + ".gaf", pre + ".gfa", pre)
+    assert rc == 0, err
+    t_filter_full = time.time() - t1
+    js = open(pre + "_informative_aln.json").read()
+    d = json.loads(js)
+    t1 = time.time()
+    rc, so = run_ref_genotype(pre + "_informative_aln.json", pre + ".vcf", pre + "_genotype.vcf")
+    assert rc == 0
+    t_geno_full = time.time() - t1
+    fix["full"] = {"n_reads": full_n, "gaf_bytes": int(gaf_full.size), "gaf_sha256": hashlib.sha256(gaf_full.tobytes()).hexdigest(),
+                   "json_sha256": hashlib.sha256(js.encode()).hexdigest(), "json_bytes": len(js),
+                   "vcf_sha256": hashlib.sha256(open(pre + "_genotype.vcf", "rb").read()).hexdigest(), "genotyped": so.strip(),
+                   "counts": {key: [len(v[0]), len(v[1])] for key, v in d.items()},
+                   "reference_seconds": {"filter": round(t_filter_full, 1), "genotype": round(t_geno_full, 1),
+                                         "where": "build container, 1 core of an Intel Xeon @ 2.1 GHz, Python " + sys.version.split()[0]}}
+    del d, js, gaf_full
     json.dump(fix, open(f"{out}/hg002shape.json", "w"), indent=0, sort_keys=True)
-    print("hg002shape:", {k2: v for k2, v in fix.items() if k2 != "counts"}, len(fix["counts"]), "SVs with informative alignments")
+    print("hg002shape:", {k2: v for k2, v in fix.items() if k2 not in ("counts", "full")}, len(fix["counts"]), "SVs with informative alignments")
+    print("hg002shape, whole block:", {k2: v for k2, v in fix["full"].items() if k2 != "counts"}, len(fix["full"]["counts"]), "SVs with informative alignments")
     shutil.rmtree(tmp)
 
 

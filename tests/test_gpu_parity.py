@@ -1781,6 +1781,16 @@ def test_hg002_shape(tmp_path, monkeypatch):
         assert st["n_lines"] == want["n_reads"] and st["n_deferred"] == 0, cause
     finally:
         c.close()
+    # the WHOLE block of bench.py (30x, 750 MB): the reference ran that too — both files through the drop-in scripts have its sha256, the genotyper
+    # reading the JSON alone
+    full = want["full"]
+    gaf = synth.gaf_bytes(inf["tables"], want["seed"], 0, full["n_reads"], threads=16, shape="reads")
+    assert hashlib.sha256(gaf.tobytes()).hexdigest() == full["gaf_sha256"]
+    gaf.tofile(pre + ".gaf")
+    flt.run(pre + ".gaf", pre + ".gfa", pre)
+    assert os.path.getsize(pre + "_informative_aln.json") == full["json_bytes"] and sha(pre + "_informative_aln.json") == full["json_sha256"]
+    n3 = genotype.run(pre + "_informative_aln.json", pre + ".vcf", pre + "_genotype_full.vcf")          # (SVJG_NO_HANDOFF is still set)
+    assert f"Genotyped svs: {n3}" == full["genotyped"] and sha(pre + "_genotype_full.vcf") == full["vcf_sha256"]
 
 
 def test_c4_graph_two_million_alignments(tmp_path):

@@ -37,3 +37,20 @@ def test_generator_and_oracles_reproduce_the_reference(tmp_path, golden):
     assert hashlib.sha256(js.encode()).hexdigest() == want["json_sha256"]
     text, n = O.genotype_vcf(open(pre + ".vcf").readlines(), D)
     assert f"Genotyped svs: {n}" == want["genotyped"] and hashlib.sha256(text.encode()).hexdigest() == want["vcf_sha256"]
+
+
+def test_the_whole_block_against_the_reference(tmp_path, golden):
+    """the bench block itself — all 4.65 M lines (30x) — went through the reference's filter and genotyper (fixture: `full`): the regenerated text
+    has its sha256 and the C oracle counts what the reference counted, for every SV"""
+    import synth
+    want = json.load(open(f"{golden}/hg002shape/hg002shape.json"))
+    full = want["full"]
+    pre = str(tmp_path / "hg")
+    inf = synth.generate_hg002(pre, n_reads=full["n_reads"], seed=want["seed"], write_gaf=False, return_gaf=True)
+    gaf = inf["gaf"]
+    assert int(gaf.size) == full["gaf_bytes"] and hashlib.sha256(gaf.tobytes()).hexdigest() == full["gaf_sha256"]
+    orc = OC.COracle(O.load_edges(pre + "_svs_edges.json"), O.load_alt_node_len(pre + ".gfa"))
+    cnt, _, n_lines = orc.filter(gaf, want_hits=False)
+    assert n_lines == full["n_reads"]
+    assert {sv: [int(cnt[i, 0]), int(cnt[i, 1])] for i, sv in enumerate(orc.sv_ids) if cnt[i].sum()} == full["counts"]
+    assert len(full["counts"]) > 12000 and full["genotyped"].startswith("Genotyped svs: ")
