@@ -599,6 +599,11 @@ def hg002_shape_block(Graph, ctx, hg):
         orc = hg["oracle"]
         out["parity"] = "bit-exact" if (got == orc["counts"] and int(st["n_lines"]) == orc["lines"] == n_lines) else "MISMATCH"
         out["parity_over"] = f"all {orc['lines']} lines, {sum(a + b for a, b in orc['counts'].values())} hits; oracle/svjg_oracle.c in {orc['cores']} forked workers, {orc['seconds']} s"
+    ref_counts = out.get("pinned_by_the_reference", {}).pop("_full_counts", None)
+    if ref_counts is not None:                                   # every line of the block, against what the REFERENCE's filter-alignments.py counted
+        g = ctx.counts()
+        got = {graph.sv_ids[i]: [int(g[i, 0]), int(g[i, 1])] for i in range(graph.n_slots) if g[i].sum()}
+        out["pinned_by_the_reference"]["all_lines_counts_equal_the_reference_s"] = bool(got == ref_counts and int(st["n_lines"]) == n_lines)
     return out
 
 
@@ -632,11 +637,6 @@ def long_read_block(Graph, ctx, lr_in):
         orc = lr_in["oracle"]
         out["parity"] = "bit-exact" if (got == orc["counts"] and int(st["n_lines"]) == orc["lines"] == n_lines) else "MISMATCH"
         out["parity_over"] = f"all {orc['lines']} lines, {sum(a + b for a, b in orc['counts'].values())} hits; oracle/svjg_oracle.c in {orc['cores']} forked workers, {orc['seconds']} s"
-    ref_counts = out.get("pinned_by_the_reference", {}).pop("_full_counts", None)
-    if ref_counts is not None:                                   # every line of the block, against what the REFERENCE's filter-alignments.py counted
-        g = ctx.counts()
-        got = {graph.sv_ids[i]: [int(g[i, 0]), int(g[i, 1])] for i in range(graph.n_slots) if g[i].sum()}
-        out["pinned_by_the_reference"]["all_lines_counts_equal_the_reference_s"] = bool(got == ref_counts and int(st["n_lines"]) == n_lines)
     return out
 
 
