@@ -300,16 +300,34 @@ struct Scan {
         }
         return true;
     }
-    // the next byte of a string body that is not plain text: '"', '\\' or a control character (< 0x20); eight bytes per step
+    // the next byte of a string body that is not plain ASCII text: '"', '\\', a control character (< 0x20) or a byte >= 0x80; eight bytes per step
     void plain_run() {
         while (p + 8 <= e) {
             uint64_t w; memcpy(&w, p, 8);
             const uint64_t q = w ^ 0x2222222222222222ull, b = w ^ 0x5C5C5C5C5C5C5C5Cull, c = w & 0xE0E0E0E0E0E0E0E0ull;
-            const uint64_t m = (((q - 0x0101010101010101ull) & ~q) | ((b - 0x0101010101010101ull) & ~b) | ((c - 0x0101010101010101ull) & ~c)) & 0x8080808080808080ull;
-            if (m) { p += __builtin_ctzll(m) >> 3; return; }     // (the LOWEST flag of each of the three tests is exact, so the lowest of all is)
+            const uint64_t m = ((((q - 0x0101010101010101ull) & ~q) | ((b - 0x0101010101010101ull) & ~b) | ((c - 0x0101010101010101ull) & ~c)) | w) & 0x8080808080808080ull;
+            if (m) { p += __builtin_ctzll(m) >> 3; return; }     // (the LOWEST flag of each of the three tests is exact — below the first byte >= 0x80 no borrow reaches them —, so the lowest of all is)
             p += 8;
         }
-        while (p < e && *p != '"' && *p != '\\' && *p >= 0x20) ++p;
+        while (p < e && *p != '"' && *p != '\\' && *p >= 0x20 && *p < 0x80) ++p;
+    }
+    // one UTF-8 sequence at p (its first byte is >= 0x80), as Python's decoder takes it — the reference reads the file in text mode and dies with
+    // UnicodeDecodeError on anything else: no overlong forms, no surrogates, nothing beyond U+10FFFF
+    bool utf8_seq() {
+        const uint8_t c = *p;
+        const size_t left = (size_t)(e - p);
+        if (c >= 0xC2 && c <= 0xDF) { if (left < 2 || (p[1] & 0xC0) != 0x80) return false; p += 2; return true; }
+        if ((c & 0xF0) == 0xE0) {
+            if (left < 3 || (p[1] & 0xC0) != 0x80 || (p[2] & 0xC0) != 0x80) return false;
+            if ((c == 0xE0 && p[1] < 0xA0) || (c == 0xED && p[1] >= 0xA0)) return false;
+            p += 3; return true;
+        }
+        if (c >= 0xF0 && c <= 0xF4) {
+            if (left < 4 || (p[1] & 0xC0) != 0x80 || (p[2] & 0xC0) != 0x80 || (p[3] & 0xC0) != 0x80) return false;
+            if ((c == 0xF0 && p[1] < 0x90) || (c == 0xF4 && p[1] >= 0x90)) return false;
+            p += 4; return true;
+        }
+        return false;
     }
     // string body -> out (unescaped UTF-8) or skipped when out == nullptr
     bool str(std::string *out) {
@@ -322,6 +340,7 @@ struct Scan {
             if (out && p > q) out->append((const char *)q, (size_t)(p - q));
             if (p >= e) return false;
             if (*p == '"') { ++p; return true; }
+            if (*p >= 0x80) { const uint8_t *u = p; if (!utf8_seq()) return false; if (out) out->append((const char *)u, (size_t)(p - u)); continue; }
             if (*p != '\\') return false;                        // a raw control character (json.load: "Invalid control character")
             if (p + 1 >= e) return false;
             const uint8_t c = p[1];
@@ -349,15 +368,33 @@ struct Scan {
             }
         }
     }
-    bool skip() {                                               // any JSON value
+    // a value that is neither string nor container, as json.load takes it: true / false / null, the three names Python's json adds (NaN, Infinity,
+    // -Infinity), or a number -?(0|[1-9][0-9]*)(\.[0-9]+)?([eE][-+]?[0-9]+)? — anything else is the JSONDecodeError the reference dies with
+    bool literal() {
+        auto word = [&](const char *w) { const size_t n = strlen(w); if ((size_t)(e - p) >= n && !memcmp(p, w, n)) { p += n; return true; } return false; };
+        if (word("true") || word("false") || word("null") || word("NaN") || word("Infinity") || word("-Infinity")) return true;
+        if (p < e && *p == '-') ++p;
+        if (p >= e || *p < '0' || *p > '9') return false;
+        if (*p == '0') ++p; else while (p < e && *p >= '0' && *p <= '9') ++p;
+        if (p < e && *p == '.') { const uint8_t *q = ++p; while (p < e && *p >= '0' && *p <= '9') ++p; if (p == q) return false; }
+        if (p < e && (*p == 'e' || *p == 'E')) {
+            const uint8_t *save = p;
+            ++p;
+            if (p < e && (*p == '+' || *p == '-')) ++p;
+            const uint8_t *q = p;
+            while (p < e && *p >= '0' && *p <= '9') ++p;
+            if (p == q) p = save;                               // ("1e" / "1e+": the number ends in front of the 'e', what follows is the caller's error)
+        }
+        return true;
+    }
+    bool skip(int depth = 0) {                                  // any JSON value
         ws();
-        if (p >= e) return false;
+        if (p >= e || depth > 900) return false;                // (nesting that deep: Python's scanner dies with RecursionError)
         if (*p == '"') return str(nullptr);
-        if (*p == '[') { ++p; if (eat(']')) return true; do { if (!skip()) return false; } while (eat(',')); return eat(']'); }
-        if (*p == '{') { ++p; if (eat('}')) return true; do { if (!str(nullptr) || !eat(':') || !skip()) return false; } while (eat(',')); return eat('}'); }
-        const uint8_t *q = p;
-        while (p < e && *p != ',' && *p != ']' && *p != '}' && *p != ' ' && *p != '\n' && *p != '\r' && *p != '\t') ++p;
-        return p > q;
+        if (*p == '[') { ++p; if (eat(']')) return true; do { if (!skip(depth + 1)) return false; } while (eat(',')); return eat(']'); }
+        if (*p == '{') { ++p; if (eat('}')) return true; do { if (!str(nullptr) || !eat(':') || !skip(depth + 1)) return false; } while (eat(',')); return eat('}'); }
+        if (!literal()) return false;
+        return p >= e || *p == ',' || *p == ']' || *p == '}' || *p == ' ' || *p == '\n' || *p == '\r' || *p == '\t';
     }
     bool count_list(uint64_t &n) {                              // '[' values ']' -> number of values
         n = 0;

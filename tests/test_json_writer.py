@@ -167,3 +167,46 @@ def test_count_reader_is_as_strict_as_json_load(tmp_path, monkeypatch, text, thr
     p.write_text(text)
     with pytest.raises(ValueError):
         capi.count_informative_json(str(p))
+
+
+def test_count_reader_takes_and_refuses_the_values_json_load_does(tmp_path):
+    """r06: list elements and extras that are neither strings nor containers are read with json.load's own grammar (true / false / null, NaN / Infinity /
+    -Infinity, numbers); what it refuses is refused (the reference dies with JSONDecodeError there, predict-genotype.py:67-68)"""
+    good = ['{"a": [[1, -0, 2.5e-3, 1E5, true, false, null], [NaN, Infinity, -Infinity]], "b": [[], [0.5]]}',
+            '{"a": [[{"k": [1, {"z": null}]}, [[[]]]], [], 7, "x"]}', ' {\n"a"\t:\r[ [ ] , [ ] ] }\n ']
+    bad = ['{"a": [[01], []]}', '{"a": [[1.], []]}', '{"a": [[.5], []]}', '{"a": [[+1], []]}', '{"a": [[1e], []]}', '{"a": [[tru], []]}', '{"a": [[True], []]}',
+           '{"a": [[nan], []]}', '{"a": [[1 2], []]}', '{"a": [[abc], []]}', '{"a": [[1,], []]}', '{"a": [[,1], []]}', '{"a": [[--1], []]}', '{"a": [[0x10], []]}',
+           '{"a": [[1e5x], []]}', '{"a": [[' + "[" * 2000 + "]" * 2000 + '], []]}', "\ufeff" + '{"a": [[], []]}', '{"a": [[], []],}', "{'a': [[], []]}"]
+    for i, text in enumerate(good):
+        d = json.loads(text)
+        p = tmp_path / f"g{i}.json"
+        p.write_text(text)
+        keys, cnt = capi.count_informative_json(str(p))
+        assert keys == list(d) and cnt.tolist() == [[len(d[k][0]), len(d[k][1])] for k in keys], text
+    for i, text in enumerate(bad):
+        with pytest.raises((ValueError, RecursionError)):
+            json.loads(text)
+        p = tmp_path / f"b{i}.json"
+        p.write_text(text, encoding="utf-8")
+        with pytest.raises(ValueError):
+            capi.count_informative_json(str(p))
+
+
+def test_count_reader_validates_utf8_inside_strings(tmp_path):
+    """the reference reads the JSON in text mode: a byte sequence that is not UTF-8 — anywhere, also inside a string it would only count — is a
+    UnicodeDecodeError (a ValueError) before json.load sees it; well-formed UTF-8 is text like any other"""
+    ok = '{"kéy\U0001F600": [["æøå ü 漢字 \U0001F9EC", "plain"], ["xé"]], "b": [[], []]}'.encode("utf-8")
+    p = tmp_path / "ok.json"
+    p.write_bytes(ok)
+    keys, cnt = capi.count_informative_json(str(p))
+    d = json.loads(ok.decode("utf-8"))
+    assert keys == list(d) and cnt.tolist() == [[len(d[k][0]), len(d[k][1])] for k in keys]
+    for i, badseq in enumerate((b"\xff", b"\xc0\xaf", b"\xe0\x80\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xc3", b"\xe2\x82", b"\x80", b"\xf8\x88\x80\x80\x80")):
+        for where in (b'{"a": [["x%sy"], []]}', b'{"a%s": [["x"], []]}', b'{"a": [["x"], []]}%s'):
+            raw = where % badseq
+            with pytest.raises(ValueError):
+                json.loads(raw.decode("utf-8"))
+            q = tmp_path / f"bad{i}.json"
+            q.write_bytes(raw)
+            with pytest.raises(ValueError):
+                capi.count_informative_json(str(q))
