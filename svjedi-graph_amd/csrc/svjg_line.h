@@ -247,7 +247,7 @@ SVJG_HD uint32_t edge_hit(const GraphView &g, const svjg_edge &e, uint32_t j) {
 // max_digits: 18 for a column (|v| < 10^18: Tlen - Te - 1 and the differences with the path sums below stay inside 64 bits), 12 for a
 // coordinate inside a node name that is no node of the graph (:343-349: its "length" is end - start + 1, and up to 2^16 of them are summed).
 constexpr int PY_INT_BAD = 0, PY_INT_OK = 1, PY_INT_BIG = 2;
-constexpr uint32_t COL_DIGITS = 18, NAME_DIGITS = 12;
+constexpr uint32_t COL_DIGITS = 18, NAME_DIGITS = 12, MAX_PATH_NODES = 65536;
 template <class P>
 SVJG_FN int py_int(P t, uint64_t a, uint64_t b, int64_t &out, uint32_t max_digits = COL_DIGITS) {
     while (a < b && c_space(t[a])) ++a;
@@ -608,6 +608,7 @@ SVJG_FN int slow_prologue(P t, uint64_t s, uint64_t e, SlowLine &o) {
     if (o.pe == o.ps) return SVJG_EXC_INDEX_ERROR;                 // p[0]
     o.oriented = t[o.ps] == '<' || t[o.ps] == '>';
     { NameRef nm{0, 0}; uint64_t pos = o.ps; while (next_node(t, o.pe, o.oriented, pos, nm)) ++o.k; }
+    if (o.k > MAX_PATH_NODES) return SVJG_EXC_ASK_HOST;            // (the 64-bit path sums are exact for up to 2^16 nodes of 12-digit coordinates; the host refuses such a line: DESIGN §8)
     o.Tlen = v[6]; o.Ts = v[7]; o.Te = v[8];
     return 0;
 }

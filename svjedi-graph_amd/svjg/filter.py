@@ -150,7 +150,7 @@ _COL_CAP = 10 ** 18 - 1        # svjg_line.h: COL_DIGITS = 18
 
 class UnsupportedLine(RuntimeError):
     """A GAF line the reference reads and this implementation refuses (exit 1 instead of a guess): a path node that is no node
-    of the graph whose name holds a coordinate of more than 12 digits or non-ASCII digits."""
+    of the graph whose name holds a coordinate of more than 12 digits or non-ASCII digits, or a path of more than 65 536 nodes."""
 
 
 # what resolve_host_lines can raise for a line: the reference's exceptions (OverflowError: Am / Alen beyond a double, :196) or the refusal
@@ -189,6 +189,8 @@ def host_line(text):
         val[9] / val[10]                                        # (ZeroDivisionError; OverflowError for a quotient beyond a double)
     for i in _INT_COLS:
         cols[i] = _ascii_number(cols[i])
+        if sum(ch.isdigit() for ch in cols[i]) > 18 and abs(val[i]) <= _COL_CAP:
+            cols[i] = str(val[i])                               # (more than 18 digits for a value that needs fewer: "0000000000000000000005", "1_0_0_...")
     if any(abs(v) > _COL_CAP for v in val.values()):
         # Values beyond the kernels' 18 digits.  Six of the nine columns only have to BE integers (:185-191) and Alen only to be non-zero
         # without an id:f: tag (:196); Tlen, Ts, Te enter two comparisons (:260-271):
@@ -272,7 +274,8 @@ def resolve_host_lines(ctxs, data, want_hits, error=None):
             o = int(orig[np.searchsorted(starts, np.uint64(int(np.min(again)) - HOST_BASE), side="right") - 1])
             if limit is None or o < limit:
                 ex = UnsupportedLine(f"GAF line at byte offset {o}: a path node that is no node of the graph has a coordinate of more than 12 digits "
-                                     "(or non-ASCII digits); the reference computes with it, this implementation does not (DESIGN.md section 8)")
+                                     "(or non-ASCII digits), or the path has more than 65 536 nodes; the reference computes with it, this implementation "
+                                     "does not (DESIGN.md section 8)")
                 ex.svjg_offset = o
                 if first is None or getattr(first, "svjg_offset", None) is None or o < first.svjg_offset:
                     first = ex

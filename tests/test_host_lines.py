@@ -51,6 +51,8 @@ def test_the_other_columns_and_what_python_refuses():
     assert flt.host_line(_line(c10=10 ** 40)).decode().split("\t")[10] == "1"             # Alen: only "zero or not" matters (:196)
     with pytest.raises(ZeroDivisionError):
         flt.host_line(_line(c10="0" * 30))
+    out = flt.host_line(_line(c6="0" * 30 + "900", c7="0_0_0_0_0_0_0_0_0_0_0_0_0_0_0_0_0_0_0_5", c1="+" + "0" * 40)).decode().split("\t")
+    assert out[6] == "900" and out[7] == "5" and out[1] == "0"                             # more digits than the value needs: written as the value
     with pytest.raises(OverflowError):                                                     # Am / Alen beyond a double (:196)
         flt.host_line(_line(c9=10 ** 400))
     assert flt.host_line(_line(c9=10 ** 400).rstrip("\n") + "\tid:f:0.9\n")                # with the tag the quotient is never formed

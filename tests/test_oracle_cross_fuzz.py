@@ -14,6 +14,7 @@ of the host's part is a difference like any other; both are counted and must sta
 """
 import io
 import os
+import re
 
 import numpy as np
 import pytest
@@ -78,6 +79,9 @@ def with_the_host(frags, g, tables, wave):
                 c2, e2 = sim.classify_cases(g, [again], tables, wave)
                 c, e = c2[0], e2[0]
                 if e is sim.HostLine:
+                    # the one refusal there is: a path node with a coordinate of more than 12 digits — anything else set aside twice is a bug
+                    path = again.split(b"\t")[5]
+                    assert any(len(run) > 12 for nm in re.split(rb"[<>,]", path) for run in re.findall(rb"[0-9_]+", nm.rsplit(b":", 1)[-1])), (ln, again)
                     verdict = ("died", "refused")
                     break
             if e is not None:
