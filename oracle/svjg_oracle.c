@@ -8,7 +8,9 @@
  * it does not share a line of code or a data structure with the HIP path.
  *
  * Pinned against the reference's own outputs: tests/test_oracle_golden.py (golden/quirks, golden/testdir,
- * golden/synth).
+ * golden/synth), tests/test_fuzz_golden.py (golden/fuzz), tests/test_oracle_cross_fuzz.py (golden/blanks, golden/fuzz7 — and, r06, fuzzed
+ * against oracle/oracle_py.py, which calls Python's own int() / float(), over the full 7-bit alphabet), tests/test_hg002_shape.py
+ * (golden/hg002shape: 4.65 M lines through the reference).
  *
  * build: gcc -O2 -shared -fPIC -o oracle/_build/liboracle.so oracle/svjg_oracle.c
  */

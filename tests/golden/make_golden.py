@@ -22,6 +22,10 @@ Fixture groups:
   utf8order/ G8  GAFs that are not UTF-8 and hold a malformed line: which exception the reference dies with
   longpath/  G9  tests/longpath_fuzz.py: long walks (65..216 nodes) with one late event on graphs of >= 2 000 nodes
   longtail/  G11 lines longer than 8 KB with one event in the tail at boundary positions (tests/longpath_fuzz.py: make_tail_case)
+  blanks/    G12 (r06) every blank-like byte around every decimal column, an id:f: value, the line's end (tests/alphabet_fuzz.py: blank_cases)
+  fuzz7/     G13 (r06) 12 000 mutants over the full 7-bit alphabet (tests/alphabet_fuzz.py: mutate7), each through the reference
+  hg002shape/ G14 (r06) BASELINE configs[4]'s shape: the graph built by the reference's construct-graph.py, 200 k lines and the whole 4.65 M-line
+                 block through its filter and genotyper
   contigs/   G10 GRCh38 analysis-set contig names (HLA-DRB1*15:03:01:01, chrUn_JTFH01001998v1_decoy, chr6_GL000250v2_alt, chrEBV)
   realshape/ G7  lines shaped like real minigraph output (read names, cg:Z: / ds:Z: tags, paths of up to 300 nodes,
                  UCSC contig names) on a 600-SV graph, with the reference's JSON and VCF
@@ -1560,7 +1564,8 @@ def make_full(which=("c2", "c3", "c4slice")):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz", "dover", "longpath", "contigs", "longtail"]
+    which = sys.argv[1:] or ["testdir", "quirks", "unicode", "lik", "lik_boundary", "vcf", "synth", "realshape", "utf8order", "nosv", "vcffuzz", "graphfuzz", "dover", "longpath", "contigs", "longtail",
+                             "blanks", "fuzz7"]          # (hg002shape: minutes and 7 GB of scratch — by name)
     for w in which:
         if w.startswith("full"):                   # full | full:c2,c3,c4slice
             make_full(tuple(w.split(":")[1].split(",")) if ":" in w else ("c2", "c3", "c4slice"))
