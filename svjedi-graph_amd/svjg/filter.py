@@ -220,6 +220,36 @@ def host_line(text):
     return out.encode("utf-8") + b"\n"
 
 
+def _name_error(line_bytes):
+    """A line the exact routine set aside TWICE: every column is plain, so it met a node name it could not read in a sum the reference forms —
+    the name of no graph node (those are canonical ASCII) with a coordinate of more than 12 digits or with bytes >= 0x80.  If Python's own
+    arithmetic on EVERY such name of the path (get_node_len, filter-alignments.py:343-349: int(end) first, then int(start)) dies with one and the
+    same exception class, the reference dies with it whichever of them it met: that exception.  Else (some such name is a number Python computes
+    with) None: the caller refuses the line."""
+    import re
+    try:
+        path = line_bytes.decode("utf-8").split("\t")[5]
+    except (UnicodeDecodeError, IndexError):
+        return None
+    names = [n for n in re.split("[<>]", path) if n] if path[:1] in "<>" else [n[:-1] for n in path.split(",") if n]
+    classes = set()
+    for nm in names:
+        coords = nm.split(":")[-1]
+        if "." in coords:
+            continue                                            # (an insertion node: its length is the GFA's, not arithmetic)
+        if coords.isascii() and all(len(run) <= 12 for run in re.findall("[0-9_]+", coords)):
+            continue
+        try:
+            parts = coords.split("-")
+            int(parts[1]) - int(parts[0]) + 1
+            return None                                         # a number the reference computes with and the kernels cannot hold
+        except (ValueError, IndexError) as e:
+            classes.add(type(e))
+    if len(classes) == 1:
+        return classes.pop()("node name the reference cannot read either (filter-alignments.py:343-349)")
+    return None
+
+
 def resolve_host_lines(ctxs, data, want_hits, error=None):
     """After every shard is classified (`error`: the exception of the first bad line the kernels met, if any): decide the lines the
     kernels set aside.  Raises the exception of the file's first bad line (a host line's own, or `error`); else resubmits the
@@ -271,9 +301,10 @@ def resolve_host_lines(ctxs, data, want_hits, error=None):
             # node that is no node of the graph (its length is arithmetic on its name, filter-alignments.py:343-349) with a coordinate of
             # more than 12 digits or of non-ASCII digits, in a sum the reference forms.  The reference computes on; this implementation
             # refuses unless an earlier line is fatal anyway.
-            o = int(orig[np.searchsorted(starts, np.uint64(int(np.min(again)) - HOST_BASE), side="right") - 1])
+            k = int(np.searchsorted(starts, np.uint64(int(np.min(again)) - HOST_BASE), side="right") - 1)
+            o = int(orig[k])
             if limit is None or o < limit:
-                ex = UnsupportedLine(f"GAF line at byte offset {o}: a path node that is no node of the graph has a coordinate of more than 12 digits "
+                ex = _name_error(accepted[k][1]) or UnsupportedLine(f"GAF line at byte offset {o}: a path node that is no node of the graph has a coordinate of more than 12 digits "
                                      "(or non-ASCII digits), or the path has more than 65 536 nodes; the reference computes with it, this implementation "
                                      "does not (DESIGN.md section 8)")
                 ex.svjg_offset = o

@@ -95,6 +95,49 @@ def mutate7(line, rng):
     return bytes(b)
 
 
+# valid UTF-8 the reference's int() / float() / str.rstrip() treat specially (Unicode decimal digits, blanks) or not at all (letters)
+UNI = ["\u0663", "\uff15", "\u0967", "\u00a0", "\u2003", "\u0085", "\u3000", "\u200b", "\u00e9", "\u6f22", "\U0001d7d8", "\u00b2", "\u2460"]
+
+
+def mutate_utf8(line, rng):
+    """one mutation of mutate7's kind, then ONE well-formed non-ASCII character at a place that matters: an end of a decimal column, of an id:f: value,
+    of the line, inside the read name, inside a node name"""
+    b = mutate7(line, rng) if rng.random() < 0.3 else bytes(line)
+    cols, term = _cols(b)
+    ch = rng.choice(UNI).encode("utf-8")
+    where = rng.randrange(6)
+    if where == 0 and len(cols) >= 12:
+        c = rng.choice(INT_COLS)
+        v = cols[c]
+        k = rng.randrange(3)
+        cols[c] = ch + v if k == 0 else v + ch if k == 1 else v[:1] + ch + v[1:]
+    elif where == 1 and len(cols) >= 12:
+        v = rng.choice((b"0.9", b"1", b"1e5", b".5"))
+        cols.append(b"id:f:" + (ch + v if rng.random() < 0.5 else v + ch))
+    elif where == 2:
+        return b"\t".join(cols) + ch + term
+    elif where == 3 and cols:
+        cols[0] = cols[0][:2] + ch + cols[0][2:]
+    elif where == 4 and len(cols) >= 12 and cols[5][:1] in (b"<", b">"):
+        p = rng.randrange(1, len(cols[5]) + 1)
+        cols[5] = cols[5][:p] + ch + cols[5][p:]
+    elif len(cols) >= 12:
+        cols[rng.choice(INT_COLS)] = "".join(rng.choice("\u0660\u0661\u0662\u0663\u0669\uff10\uff11\uff19" + "0123456789") for _ in range(rng.randrange(1, 6))).encode("utf-8")
+    return b"\t".join(cols) + term
+
+
+def mutants_utf8(lines, n, seed):
+    rng = random.Random(seed)
+    seen, out = set(), []
+    while len(out) < n:
+        m = mutate_utf8(rng.choice(lines), rng)
+        if m in seen:
+            continue
+        seen.add(m)
+        out.append(m)
+    return out
+
+
 def mutants(lines, n, seed):
     """n distinct mutants of the given lines"""
     rng = random.Random(seed)

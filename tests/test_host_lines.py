@@ -64,3 +64,19 @@ def test_the_other_columns_and_what_python_refuses():
     with pytest.raises(ValueError):
         flt.host_line(_line(c7="5\x1f"))                                                   # int() does not strip what rstrip() strips
     assert flt.host_line(_line(c7=" 5 ").rstrip("\n") + "\x1f\n").decode().split("\t")[7] == " 5 "
+
+
+def test_unreadable_node_names():
+    """a line set aside twice met a node name the exact routine cannot read; where Python's arithmetic on every such name dies with one exception class,
+    that is what the reference dies with — else (a number Python computes with) the line is refused"""
+    def line(path):
+        c = list(COLS); c[5] = path
+        return ("\t".join(c) + "\n").encode("utf-8")
+    assert isinstance(flt._name_error(line(">1:1-500>1:1 9051-20000")), ValueError)        # a blank INSIDE a number: int() dies
+    assert isinstance(flt._name_error(line(">1:1-500>1:5é-9>1:xé-9")), ValueError)
+    assert isinstance(flt._name_error(line("<1:é7>1:1-500")), IndexError)                  # no '-': coords.split("-")[1]
+    assert flt._name_error(line(">1:1-500>1:٣-9")) is None                                # Unicode digits: Python computes 9 - 3 + 1
+    assert flt._name_error(line(">1:1-500>1:1- 37500")) is None                           # a Unicode blank AROUND a number: int() strips it
+    assert flt._name_error(line(">1:1-500>1:1-99999999999999999999")) is None                  # twenty digits: Python computes
+    assert flt._name_error(line(">1:1-500>1:5é-9>1:é7")) is None                     # ValueError or IndexError, depending on which the reference meets: refused
+    assert flt._name_error(line(">1:1-500>1:501-900")) is None                                 # nothing unreadable: not this function's case

@@ -62,7 +62,7 @@ def with_the_host(frags, g, tables, wave):
     resolve_host_lines): every line on its own through the exact routine; a line set aside goes to host_line() — Python's own int() /
     float() — and, rewritten, through the exact routine again; the file's first fatal line wins.  "refused": a rewritten line was set
     aside again (UnsupportedLine: a coordinate of more than 12 digits in the name of a node the graph does not have)."""
-    from svjg.filter import host_line
+    from svjg.filter import host_line, _name_error
     out = []
     for f in frags:
         lines = io.TextIOWrapper(io.BytesIO(f), encoding="utf-8", newline=None).readlines()
@@ -79,9 +79,16 @@ def with_the_host(frags, g, tables, wave):
                 c2, e2 = sim.classify_cases(g, [again], tables, wave)
                 c, e = c2[0], e2[0]
                 if e is sim.HostLine:
-                    # the one refusal there is: a path node with a coordinate of more than 12 digits — anything else set aside twice is a bug
-                    path = again.split(b"\t")[5]
-                    assert any(len(run) > 12 for nm in re.split(rb"[<>,]", path) for run in re.findall(rb"[0-9_]+", nm.rsplit(b":", 1)[-1])), (ln, again)
+                    # set aside twice: a node name the exact routine cannot read.  Where Python cannot either, the reference's exception (svjg/filter.py:
+                    # _name_error); else the one refusal there is: a coordinate of more than 12 digits, or of non-ASCII digits, that Python
+                    # computes with — anything else set aside twice is a bug
+                    ex = _name_error(again)
+                    if ex is not None:
+                        verdict = ("died", type(ex).__name__)
+                        break
+                    path = again.decode("utf-8").split("\t")[5]
+                    assert any(not nm.rsplit(":", 1)[-1].isascii() or any(len(run) > 12 for run in re.findall("[0-9_]+", nm.rsplit(":", 1)[-1]))
+                               for nm in re.split("[<>,]", path)), (ln, again)
                     verdict = ("died", "refused")
                     break
             if e is not None:
@@ -177,3 +184,26 @@ def test_reference_run_fixtures(setup, golden, group):
         assert skipped < (0.15 if who == "C oracle" else 0.02) * len(frags), (who, skipped)
         if group.startswith("blanks"):
             assert skipped == 0
+
+
+def test_well_formed_non_ascii_characters(setup):
+    """Unicode decimal digits and blanks where int() / float() / str.rstrip() of the reference take them (filter-alignments.py:125, :188-194), other
+    non-ASCII characters where they do not: the exact routine hands such a line to the host (SVJG_EXC_ASK_HOST), whose part — Python's own int() /
+    float(), the line rewritten in ASCII — is taken to its end here as the product does; the verdict is the Python oracle's.  (The C oracle reads
+    ASCII only: not asked.)"""
+    lines, edges, alt, g, orc = setup
+    frags = AF.mutants_utf8(lines, 30000, 20261006)
+    want = [python_verdict(f, edges, alt) for f in frags]
+    n_host = 0
+    for tables, wave in ((True, 0), (True, 2), (True, 3), (True, 5)):
+        got = _verdicts(*sim.classify_cases(g, frags, tables, wave), g.sv_ids)
+        idx = [i for i, v in enumerate(got) if v == ("died", "HostLine")]
+        n_host += len(idx)
+        for i, v in zip(idx, with_the_host([frags[i] for i in idx], g, tables, wave)):
+            got[i] = v
+        for f, w, v in zip(frags, want, got):
+            if v == ("died", "refused"):
+                continue
+            assert v == w, (tables, wave, f, w, v)
+    assert n_host > 4 * 3000                                        # the host's part was really used
+    assert 0.1 < sum(w[0] == "died" for w in want) / len(want) < 0.9
